@@ -1,0 +1,310 @@
+"""ctypes bridge to ``libe2hip.so`` (the C ABI of ``include/e2hip.h``).
+
+PyTorch-ROCm is used here for device memory and streams only: every tensor
+handed to the library is a ``torch.float32`` CUDA(=HIP) tensor whose
+``data_ptr()`` and element strides are passed through ``e2_tensor5``.
+
+There is NO fallback: if the shared library is missing or does not load, the
+import of this module raises, and so does every op.  (The CPU oracle under
+``oracle/`` is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libe2hip.so")
+
+ACT = {"lin": 0, "relu": 1}
+
+
+class E2Error(RuntimeError):
+    pass
+
+
+class Tensor5(C.Structure):
+    _fields_ = [("ptr", C.c_void_p),
+                ("n", C.c_int32), ("c", C.c_int32), ("d", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32),
+                ("sn", C.c_int64), ("sc", C.c_int64), ("sd", C.c_int64),
+                ("sh", C.c_int64)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise E2Error(
+            "libe2hip.so not found at %s -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C elektronn2_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P5 = C.POINTER(Tensor5)
+    vp, i, sz, fp = C.c_void_p, C.c_int, C.c_size_t, C.c_void_p
+    sig = {
+        "e2_ctx_create": (C.c_int, [i, C.POINTER(vp)]),
+        "e2_ctx_destroy": (C.c_int, [vp]),
+        "e2_ctx_set_stream": (C.c_int, [vp, vp]),
+        "e2_last_error": (C.c_char_p, []),
+        "e2_version": (C.c_int, []),
+        "e2_conv3d_workspace_bytes": (sz, [i, i, i, i, i]),
+        "e2_conv3d_fwd": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz]),
+        "e2_conv3d_dgrad": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz]),
+        "e2_conv3d_pack": (C.c_int, [vp, fp, i, i, i, i, i, i, vp, sz]),
+        "e2_conv3d_fwd_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
+        "e2_conv3d_dgrad_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
+        "e2_conv3d_wgrad": (C.c_int, [vp, P5, P5, fp, i, i, i]),
+        "e2_pool_bias_act_fwd": (C.c_int, [vp, P5, fp, i, i, i, i, P5]),
+        "e2_pool_bias_act_bwd": (C.c_int, [vp, P5, P5, fp, i, i, i, i, P5, fp]),
+        "e2_maxpool3d_fwd": (C.c_int, [vp, P5, i, i, i, P5]),
+        "e2_maxpool3d_bwd": (C.c_int, [vp, P5, P5, i, i, i, P5, i]),
+        "e2_upconv3d_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
+        "e2_upconv3d_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, P5, vp, sz]),
+        "e2_upconv3d_bwd": (C.c_int, [vp, P5, fp, P5, P5, i, i, i, i, P5, fp, fp, vp, sz]),
+        "e2_transpose_ncdhw_to_ndhwc": (C.c_int, [vp, P5, fp]),
+        "e2_transpose_ndhwc_to_ncdhw": (C.c_int, [vp, fp, P5]),
+        "e2_copy5": (C.c_int, [vp, P5, P5, i]),
+        "e2_fill": (C.c_int, [vp, fp, sz, C.c_float]),
+        "e2_softmax_nll_fwd": (C.c_int, [vp, P5, P5, P5, fp]),
+        "e2_softmax_nll_bwd": (C.c_int, [vp, P5, P5, fp, P5, fp]),
+        "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
+        "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
+        "e2_graph_begin": (C.c_int, [vp]),
+        "e2_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+        "e2_graph_launch": (C.c_int, [vp, vp]),
+        "e2_graph_destroy": (C.c_int, [vp]),
+        "e2_event_create": (C.c_int, [C.POINTER(vp)]),
+        "e2_event_record": (C.c_int, [vp, vp]),
+        "e2_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
+        "e2_event_destroy": (C.c_int, [vp]),
+        "e2_stream_synchronize": (C.c_int, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+_lib, EXPORTED_SYMBOLS = _load()
+
+
+def lib():
+    return _lib
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        msg = _lib.e2_last_error()
+        raise E2Error("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def t5(t: torch.Tensor) -> Tensor5:
+    """Describe a 5-D float32 device tensor (any view with unit W stride)."""
+    if t.dim() != 5:
+        raise TypeError("expected a 5-D (b,f,z,x,y) tensor, got %s" % (tuple(t.shape),))
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    if not t.is_cuda:
+        raise E2Error("tensor is on %s; the HIP path needs a GPU tensor (no CPU fallback)"
+                      % t.device)
+    s = t.stride()
+    if t.shape[4] > 1 and s[4] != 1:
+        raise TypeError("innermost stride must be 1, got %s" % (s,))
+    return Tensor5(t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], t.shape[3],
+                   t.shape[4], s[0], s[1], s[2], s[3])
+
+
+def _fp(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise TypeError("expected a contiguous float32 GPU tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One HIP stream + the library handle (one per process / device)."""
+
+    def __init__(self, device: int = 0, stream: Optional[torch.cuda.Stream] = None):
+        if not torch.cuda.is_available():
+            raise E2Error("no GPU visible: the elektronn2_amd hot path is HIP-only")
+        torch.cuda.set_device(device)
+        h = C.c_void_p()
+        _chk(_lib.e2_ctx_create(device, C.byref(h)), "e2_ctx_create")
+        self.h = h
+        self.device = torch.device("cuda", device)
+        self.stream = None
+        self.set_stream(stream if stream is not None else torch.cuda.current_stream(device))
+        self._ws = {}
+
+    def set_stream(self, stream: torch.cuda.Stream):
+        self.stream = stream
+        _chk(_lib.e2_ctx_set_stream(self.h, C.c_void_p(stream.cuda_stream)),
+             "e2_ctx_set_stream")
+
+    def synchronize(self):
+        _chk(_lib.e2_stream_synchronize(self.h), "e2_stream_synchronize")
+
+    # ---- workspace -----------------------------------------------------
+    def workspace(self, key, nbytes: int) -> torch.Tensor:
+        w = self._ws.get(key)
+        if w is None or w.numel() * 4 < nbytes:
+            w = torch.empty((nbytes + 3) // 4 + 64, dtype=torch.float32, device=self.device)
+            self._ws[key] = w
+        return w
+
+    # ---- conv ------------------------------------------------------------
+    def conv_ws_bytes(self, cout, cin, k):
+        return int(_lib.e2_conv3d_workspace_bytes(cout, cin, k[0], k[1], k[2]))
+
+    def conv3d_fwd(self, x, w, y, ws=None):
+        cout, cin, kd, kh, kw = w.shape
+        nb = self.conv_ws_bytes(cout, cin, (kd, kh, kw))
+        ws = ws if ws is not None else self.workspace("conv", nb)
+        _chk(_lib.e2_conv3d_fwd(self.h, C.byref(t5(x)), _fp(w), cout, kd, kh, kw,
+                                C.byref(t5(y)), C.c_void_p(ws.data_ptr()), ws.numel() * 4),
+             "e2_conv3d_fwd")
+
+    def conv3d_dgrad(self, dy_pad, w, dx, ws=None):
+        cout, cin, kd, kh, kw = w.shape
+        nb = self.conv_ws_bytes(cout, cin, (kd, kh, kw))
+        ws = ws if ws is not None else self.workspace("conv", nb)
+        _chk(_lib.e2_conv3d_dgrad(self.h, C.byref(t5(dy_pad)), _fp(w), cin, kd, kh, kw,
+                                  C.byref(t5(dx)), C.c_void_p(ws.data_ptr()),
+                                  ws.numel() * 4), "e2_conv3d_dgrad")
+
+    def conv3d_pack(self, w, mode, ws):
+        cout, cin, kd, kh, kw = w.shape
+        _chk(_lib.e2_conv3d_pack(self.h, _fp(w), cout, cin, kd, kh, kw, mode,
+                                 C.c_void_p(ws.data_ptr()), ws.numel() * 4),
+             "e2_conv3d_pack")
+
+    def conv3d_fwd_packed(self, x, wp, cout, k, y):
+        _chk(_lib.e2_conv3d_fwd_packed(self.h, C.byref(t5(x)), C.c_void_p(wp.data_ptr()),
+                                       cout, k[0], k[1], k[2], C.byref(t5(y))),
+             "e2_conv3d_fwd_packed")
+
+    def conv3d_dgrad_packed(self, dy_pad, wp, cin, k, dx):
+        _chk(_lib.e2_conv3d_dgrad_packed(self.h, C.byref(t5(dy_pad)),
+                                         C.c_void_p(wp.data_ptr()), cin, k[0], k[1], k[2],
+                                         C.byref(t5(dx))), "e2_conv3d_dgrad_packed")
+
+    def conv3d_wgrad(self, x, dy, dw):
+        kd, kh, kw = dw.shape[2:]
+        _chk(_lib.e2_conv3d_wgrad(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw),
+                                  kd, kh, kw), "e2_conv3d_wgrad")
+
+    # ---- pool / bias / act ---------------------------------------------------
+    def pool_bias_act_fwd(self, y, bias, pool, act, out):
+        _chk(_lib.e2_pool_bias_act_fwd(self.h, C.byref(t5(y)), _fp(bias), pool[0], pool[1],
+                                       pool[2], ACT[act], C.byref(t5(out))),
+             "e2_pool_bias_act_fwd")
+
+    def pool_bias_act_bwd(self, dout, y, bias, pool, act, dy, dbias):
+        _chk(_lib.e2_pool_bias_act_bwd(self.h, C.byref(t5(dout)), C.byref(t5(y)), _fp(bias),
+                                       pool[0], pool[1], pool[2], ACT[act], C.byref(t5(dy)),
+                                       _fp(dbias)), "e2_pool_bias_act_bwd")
+
+    def maxpool3d_fwd(self, x, pool, out):
+        _chk(_lib.e2_maxpool3d_fwd(self.h, C.byref(t5(x)), pool[0], pool[1], pool[2],
+                                   C.byref(t5(out))), "e2_maxpool3d_fwd")
+
+    def maxpool3d_bwd(self, dout, x, pool, dx, accumulate=False):
+        _chk(_lib.e2_maxpool3d_bwd(self.h, C.byref(t5(dout)), C.byref(t5(x)), pool[0],
+                                   pool[1], pool[2], C.byref(t5(dx)), int(accumulate)),
+             "e2_maxpool3d_bwd")
+
+    # ---- upconv ------------------------------------------------------------------
+    def upconv_ws_bytes(self, cout, cin, pool, x_shape):
+        return int(_lib.e2_upconv3d_workspace_bytes(cout, cin, pool[0], pool[1], pool[2],
+                                                    x_shape[0], x_shape[2], x_shape[3],
+                                                    x_shape[4]))
+
+    def upconv3d_fwd(self, x, w, bias, pool, act, y, ws=None):
+        cout, cin = w.shape[:2]
+        nb = self.upconv_ws_bytes(cout, cin, pool, x.shape)
+        ws = ws if ws is not None else self.workspace("upconv", nb)
+        _chk(_lib.e2_upconv3d_fwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias), cout, pool[0],
+                                  pool[1], pool[2], ACT[act], C.byref(t5(y)),
+                                  C.c_void_p(ws.data_ptr()), ws.numel() * 4),
+             "e2_upconv3d_fwd")
+
+    def upconv3d_bwd(self, x, w, y, dout, pool, act, dx, dw, dbias, ws=None):
+        cout, cin = w.shape[:2]
+        nb = self.upconv_ws_bytes(cout, cin, pool, x.shape)
+        ws = ws if ws is not None else self.workspace("upconv", nb)
+        _chk(_lib.e2_upconv3d_bwd(self.h, C.byref(t5(x)), _fp(w), C.byref(t5(y)),
+                                  C.byref(t5(dout)), pool[0], pool[1], pool[2], ACT[act],
+                                  C.byref(t5(dx)) if dx is not None else None,
+                                  _fp(dw), _fp(dbias), C.c_void_p(ws.data_ptr()),
+                                  ws.numel() * 4), "e2_upconv3d_bwd")
+
+    # ---- layout ------------------------------------------------------------------
+    def to_ndhwc(self, src, dst):
+        _chk(_lib.e2_transpose_ncdhw_to_ndhwc(self.h, C.byref(t5(src)), _fp(dst)),
+             "e2_transpose_ncdhw_to_ndhwc")
+
+    def to_ncdhw(self, src, dst):
+        _chk(_lib.e2_transpose_ndhwc_to_ncdhw(self.h, _fp(src), C.byref(t5(dst))),
+             "e2_transpose_ndhwc_to_ncdhw")
+
+    def copy5(self, src, dst, accumulate=False):
+        _chk(_lib.e2_copy5(self.h, C.byref(t5(src)), C.byref(t5(dst)), int(accumulate)),
+             "e2_copy5")
+
+    def fill(self, t, value=0.0):
+        if not t.is_contiguous():
+            raise TypeError("fill needs a contiguous tensor")
+        _chk(_lib.e2_fill(self.h, C.c_void_p(t.data_ptr()), t.numel(), float(value)),
+             "e2_fill")
+
+    # ---- loss / optimiser ----------------------------------------------------------
+    def softmax_nll_fwd(self, logits, target, probs, stats):
+        _chk(_lib.e2_softmax_nll_fwd(self.h, C.byref(t5(logits)), C.byref(t5(target)),
+                                     C.byref(t5(probs)), _fp(stats)), "e2_softmax_nll_fwd")
+
+    def softmax_nll_bwd(self, probs, target, stats, dlogits, loss_out):
+        _chk(_lib.e2_softmax_nll_bwd(self.h, C.byref(t5(probs)), C.byref(t5(target)),
+                                     _fp(stats), C.byref(t5(dlogits)), _fp(loss_out)),
+             "e2_softmax_nll_bwd")
+
+    def adam_step(self, p, g, m, s, seg_off, seg_reg, hyper):
+        _chk(_lib.e2_adam_step(self.h, _fp(p), _fp(g), _fp(m), _fp(s), p.numel(),
+                               C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
+                               seg_reg.numel(), _fp(hyper)), "e2_adam_step")
+
+    def sgd_step(self, p, g, d, seg_off, seg_reg, hyper):
+        _chk(_lib.e2_sgd_step(self.h, _fp(p), _fp(g), _fp(d), p.numel(),
+                              C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
+                              seg_reg.numel(), _fp(hyper)), "e2_sgd_step")
+
+    # ---- graph capture / events --------------------------------------------------------
+    def graph_begin(self):
+        _chk(_lib.e2_graph_begin(self.h), "e2_graph_begin")
+
+    def graph_end(self):
+        g = C.c_void_p()
+        _chk(_lib.e2_graph_end(self.h, C.byref(g)), "e2_graph_end")
+        return g
+
+    def graph_launch(self, g):
+        _chk(_lib.e2_graph_launch(self.h, g), "e2_graph_launch")
+
+    def graph_destroy(self, g):
+        _chk(_lib.e2_graph_destroy(g), "e2_graph_destroy")
+
+    def event(self):
+        e = C.c_void_p()
+        _chk(_lib.e2_event_create(C.byref(e)), "e2_event_create")
+        return e
+
+    def record(self, e):
+        _chk(_lib.e2_event_record(self.h, e), "e2_event_record")
+
+    def elapsed_ms(self, e0, e1) -> float:
+        ms = C.c_float()
+        _chk(_lib.e2_event_elapsed_ms(e0, e1, C.byref(ms)), "e2_event_elapsed_ms")
+        return float(ms.value)

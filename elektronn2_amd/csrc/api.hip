@@ -1,0 +1,350 @@
+// api.hip -- extern "C" entry points of libe2hip.so (see include/e2hip.h).
+#include "common.hpp"
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void e2_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* e2_last_error(void) { return g_err; }
+extern "C" int e2_version(void) { return 1; }
+
+extern "C" int e2_ctx_create(int device, e2_ctx** out) {
+  E2_REQUIRE(out, "e2_ctx_create: null out");
+  int ndev = 0;
+  E2_CHECK_HIP(hipGetDeviceCount(&ndev));
+  E2_REQUIRE(device >= 0 && device < ndev, "e2_ctx_create: device %d of %d", device, ndev);
+  E2_CHECK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  E2_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  E2_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+             "e2_ctx_create: device %d is %s; this library is built for gfx950 only",
+             device, prop.gcnArchName);
+  e2_ctx* c = new e2_ctx;
+  c->device = device;
+  c->stream = nullptr;
+  c->num_cu = prop.multiProcessorCount;
+  c->capturing = false;
+  *out = c;
+  return 0;
+}
+
+extern "C" int e2_ctx_destroy(e2_ctx* ctx) {
+  delete ctx;
+  return 0;
+}
+
+extern "C" int e2_ctx_set_stream(e2_ctx* ctx, void* stream) {
+  E2_REQUIRE(ctx, "e2_ctx_set_stream: null ctx");
+  ctx->stream = reinterpret_cast<hipStream_t>(stream);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// conv
+// ---------------------------------------------------------------------------
+static int view_ok(const e2_tensor5* t, const char* name) {
+  E2_REQUIRE(t && t->ptr, "%s: null tensor", name);
+  E2_REQUIRE(t->n > 0 && t->c > 0 && t->d > 0 && t->h > 0 && t->w > 0,
+             "%s: empty tensor (%d,%d,%d,%d,%d)", name, t->n, t->c, t->d, t->h, t->w);
+  return 0;
+}
+
+extern "C" size_t e2_conv3d_workspace_bytes(int cout, int cin, int kd, int kh, int kw) {
+  // one packed image, big enough for either orientation (fwd or dgrad)
+  int ciP, coP, ciP2, coP2;
+  e2i_pack_dims(cout, cin, &ciP, &coP);
+  e2i_pack_dims(cin, cout, &ciP2, &coP2);
+  const size_t a = (size_t)ciP * coP, b = (size_t)ciP2 * coP2;
+  return sizeof(float) * (size_t)kd * kh * kw * (a > b ? a : b);
+}
+
+// mode 0: forward image (flip, oc = cout, ic = cin); mode 1: dgrad image
+// (no flip, oc = cin, ic = cout).
+extern "C" int e2_conv3d_pack(e2_ctx* ctx, const float* w, int cout, int cin, int kd,
+                              int kh, int kw, int mode, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && w && ws, "conv3d_pack: null argument");
+  E2_REQUIRE(ws_bytes >= e2_conv3d_workspace_bytes(cout, cin, kd, kh, kw),
+             "conv3d_pack: workspace too small");
+  const int T = kd * kh * kw;
+  int ciP, coP;
+  if (mode == 0) {
+    e2i_pack_dims(cout, cin, &ciP, &coP);
+    return e2i_pack_weights(ctx, w, (float*)ws, cout, cin, kd, kh, kw, (int64_t)cin * T, T,
+                            1, ciP, coP, 1, 1);
+  }
+  e2i_pack_dims(cin, cout, &ciP, &coP);
+  return e2i_pack_weights(ctx, w, (float*)ws, cin, cout, kd, kh, kw, T, (int64_t)cin * T, 0,
+                          ciP, coP, 1, 1);
+}
+
+extern "C" int e2_conv3d_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void* wp,
+                                    int cout, int kd, int kh, int kw, const e2_tensor5* y) {
+  E2_REQUIRE(ctx && wp, "conv3d_fwd: null argument");
+  if (int rc = view_ok(x, "conv3d_fwd x")) return rc;
+  if (int rc = view_ok(y, "conv3d_fwd y")) return rc;
+  E2_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1, "conv3d_fwd: bad kernel %d,%d,%d", kd, kh, kw);
+  E2_REQUIRE(y->n == x->n && y->c == cout && y->d == x->d - kd + 1 &&
+                 y->h == x->h - kh + 1 && y->w == x->w - kw + 1,
+             "conv3d_fwd: y is (%d,%d,%d,%d,%d), expected (%d,%d,%d,%d,%d)", y->n, y->c,
+             y->d, y->h, y->w, x->n, cout, x->d - kd + 1, x->h - kh + 1, x->w - kw + 1);
+  IgemmArgs a;
+  a.in = x->ptr; a.wp = (const float*)wp; a.out = y->ptr;
+  a.N = x->n; a.Cin = x->c; a.Cout = cout;
+  a.kd = kd; a.kh = kh; a.kw = kw;
+  a.Do = y->d; a.Ho = y->h; a.Wo = y->w;
+  a.isN = x->sn; a.isC = x->sc; a.isZ = x->sd; a.isY = x->sh;
+  a.osN = y->sn; a.osC = y->sc; a.osZ = y->sd; a.osY = y->sh;
+  e2i_pack_dims(cout, x->c, &a.ciP, &a.coP);
+  a.upz = a.upy = a.upx = 1;
+  return e2i_igemm_conv(ctx, a);
+}
+
+extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, const void* wp,
+                                      int cin, int kd, int kh, int kw,
+                                      const e2_tensor5* dx) {
+  E2_REQUIRE(ctx && wp, "conv3d_dgrad: null argument");
+  if (int rc = view_ok(dy_pad, "conv3d_dgrad dy_pad")) return rc;
+  if (int rc = view_ok(dx, "conv3d_dgrad dx")) return rc;
+  E2_REQUIRE(dx->n == dy_pad->n && dx->c == cin && dx->d == dy_pad->d - kd + 1 &&
+                 dx->h == dy_pad->h - kh + 1 && dx->w == dy_pad->w - kw + 1,
+             "conv3d_dgrad: dx is (%d,%d,%d,%d,%d) but padded dy (%d,%d,%d,%d,%d) with "
+             "kernel %d,%d,%d gives (%d,%d,%d,%d,%d)",
+             dx->n, dx->c, dx->d, dx->h, dx->w, dy_pad->n, dy_pad->c, dy_pad->d, dy_pad->h,
+             dy_pad->w, kd, kh, kw, dy_pad->n, cin, dy_pad->d - kd + 1, dy_pad->h - kh + 1,
+             dy_pad->w - kw + 1);
+  IgemmArgs a;
+  a.in = dy_pad->ptr; a.wp = (const float*)wp; a.out = dx->ptr;
+  a.N = dx->n; a.Cin = dy_pad->c; a.Cout = cin;
+  a.kd = kd; a.kh = kh; a.kw = kw;
+  a.Do = dx->d; a.Ho = dx->h; a.Wo = dx->w;
+  a.isN = dy_pad->sn; a.isC = dy_pad->sc; a.isZ = dy_pad->sd; a.isY = dy_pad->sh;
+  a.osN = dx->sn; a.osC = dx->sc; a.osZ = dx->sd; a.osY = dx->sh;
+  e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
+  a.upz = a.upy = a.upx = 1;
+  return e2i_igemm_conv(ctx, a);
+}
+
+extern "C" int e2_conv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w, int cout,
+                             int kd, int kh, int kw, const e2_tensor5* y, void* ws,
+                             size_t ws_bytes) {
+  E2_REQUIRE(ctx && w && ws, "conv3d_fwd: null argument");
+  if (int rc = view_ok(x, "conv3d_fwd x")) return rc;
+  if (int rc = e2_conv3d_pack(ctx, w, cout, x->c, kd, kh, kw, 0, ws, ws_bytes)) return rc;
+  return e2_conv3d_fwd_packed(ctx, x, ws, cout, kd, kh, kw, y);
+}
+
+extern "C" int e2_conv3d_dgrad(e2_ctx* ctx, const e2_tensor5* dy_pad, const float* w,
+                               int cin, int kd, int kh, int kw, const e2_tensor5* dx,
+                               void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && w && ws, "conv3d_dgrad: null argument");
+  if (int rc = view_ok(dy_pad, "conv3d_dgrad dy_pad")) return rc;
+  if (int rc = e2_conv3d_pack(ctx, w, dy_pad->c, cin, kd, kh, kw, 1, ws, ws_bytes)) return rc;
+  return e2_conv3d_dgrad_packed(ctx, dy_pad, ws, cin, kd, kh, kw, dx);
+}
+
+extern "C" int e2_conv3d_wgrad(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy,
+                               float* dw, int kd, int kh, int kw) {
+  E2_REQUIRE(ctx && dw, "conv3d_wgrad: null argument");
+  if (int rc = view_ok(x, "conv3d_wgrad x")) return rc;
+  if (int rc = view_ok(dy, "conv3d_wgrad dy")) return rc;
+  E2_REQUIRE(dy->n == x->n && dy->d == x->d - kd + 1 && dy->h == x->h - kh + 1 &&
+                 dy->w == x->w - kw + 1,
+             "conv3d_wgrad: dy spatial (%d,%d,%d) != x (%d,%d,%d) - k + 1", dy->d, dy->h,
+             dy->w, x->d, x->h, x->w);
+  WgradArgs a;
+  a.x = x->ptr; a.dy = dy->ptr; a.dw = dw;
+  a.N = x->n; a.Cin = x->c; a.Cout = dy->c;
+  a.kd = kd; a.kh = kh; a.kw = kw;
+  a.Do = dy->d; a.Ho = dy->h; a.Wo = dy->w;
+  a.xsN = x->sn; a.xsC = x->sc; a.xsZ = x->sd; a.xsY = x->sh;
+  a.dsN = dy->sn; a.dsC = dy->sc; a.dsZ = dy->sd; a.dsY = dy->sh;
+  a.flip = 1;
+  a.upR = 1;
+  return e2i_wgrad_conv(ctx, a);
+}
+
+// ---------------------------------------------------------------------------
+// UpConv: 1x1x1 GEMMs + depth-to-space scatter / space-to-depth gather
+// ---------------------------------------------------------------------------
+static size_t up_pack_floats(int cout, int cin, int R) {
+  int ciP, coP, ciP2, coP2;
+  e2i_pack_dims(cout * R, cin, &ciP, &coP);      // fwd: oc' = co*R + r
+  e2i_pack_dims(cin, cout * R, &ciP2, &coP2);    // dgrad: ic' = co*R + r
+  const size_t a = (size_t)ciP * coP, b = (size_t)ciP2 * coP2;
+  return a > b ? a : b;
+}
+
+extern "C" size_t e2_upconv3d_workspace_bytes(int cout, int cin, int pz, int py, int px,
+                                              int n, int d, int h, int w) {
+  const int R = pz * py * px;
+  // packed weights + the space-to-depth image of dpre used by the backward
+  return sizeof(float) * (up_pack_floats(cout, cin, R) +
+                          (size_t)n * cout * R * d * h * w) + 256;
+}
+
+extern "C" int e2_upconv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
+                               const float* bias, int cout, int pz, int py, int px, int act,
+                               const e2_tensor5* y, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && w && ws, "upconv3d_fwd: null argument");
+  if (int rc = view_ok(x, "upconv3d_fwd x")) return rc;
+  if (int rc = view_ok(y, "upconv3d_fwd y")) return rc;
+  E2_REQUIRE(pz >= 1 && py >= 1 && px >= 1, "upconv3d_fwd: bad factors");
+  E2_REQUIRE(y->n == x->n && y->c == cout && y->d == x->d * pz && y->h == x->h * py &&
+                 y->w == x->w * px, "upconv3d_fwd: y shape mismatch");
+  E2_REQUIRE(bias || act == E2_ACT_LIN, "upconv3d_fwd: act needs bias");
+  const int R = pz * py * px;
+  E2_REQUIRE(ws_bytes >= sizeof(float) * up_pack_floats(cout, x->c, R),
+             "upconv3d_fwd: workspace too small");
+  IgemmArgs a;
+  e2i_pack_dims(cout * R, x->c, &a.ciP, &a.coP);
+  if (int rc = e2i_pack_weights(ctx, w, (float*)ws, cout * R, x->c, 1, 1, 1,
+                                (int64_t)x->c * R, R, 0, a.ciP, a.coP, R, 1))
+    return rc;
+  a.in = x->ptr; a.wp = (const float*)ws; a.out = y->ptr;
+  a.N = x->n; a.Cin = x->c; a.Cout = cout * R;
+  a.kd = a.kh = a.kw = 1;
+  a.Do = x->d; a.Ho = x->h; a.Wo = x->w;
+  a.isN = x->sn; a.isC = x->sc; a.isZ = x->sd; a.isY = x->sh;
+  a.osN = y->sn; a.osC = y->sc; a.osZ = y->sd; a.osY = y->sh;
+  a.upz = pz; a.upy = py; a.upx = px;
+  if (int rc = e2i_igemm_conv(ctx, a)) return rc;
+  if (bias) return e2_pool_bias_act_fwd(ctx, y, bias, 1, 1, 1, act, y);
+  return 0;
+}
+
+extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
+                               const e2_tensor5* y, const e2_tensor5* dout, int pz, int py,
+                               int px, int act, const e2_tensor5* dx, float* dw,
+                               float* dbias, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && w && ws, "upconv3d_bwd: null argument");
+  if (int rc = view_ok(x, "upconv3d_bwd x")) return rc;
+  if (int rc = view_ok(y, "upconv3d_bwd y")) return rc;
+  if (int rc = view_ok(dout, "upconv3d_bwd dout")) return rc;
+  const int cout = y->c, cin = x->c, R = pz * py * px;
+  E2_REQUIRE(dout->n == y->n && dout->c == cout && dout->d == y->d && dout->h == y->h &&
+                 dout->w == y->w && y->d == x->d * pz && y->h == x->h * py &&
+                 y->w == x->w * px, "upconv3d_bwd: shape mismatch");
+  E2_REQUIRE(ws_bytes >= e2_upconv3d_workspace_bytes(cout, cin, pz, py, px, x->n, x->d,
+                                                     x->h, x->w),
+             "upconv3d_bwd: workspace too small");
+  float* wp = (float*)ws;
+  size_t off = (up_pack_floats(cout, cin, R) + 63) & ~(size_t)63;
+  float* s2d = wp + off;
+  if (dbias) E2_CHECK_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * cout, ctx->stream));
+  if (int rc = e2i_upconv_dpre_s2d(ctx, dout, y, pz, py, px, act, s2d, dbias)) return rc;
+  const long S = (long)x->d * x->h * x->w;
+  if (dx) {
+    if (int rc = view_ok(dx, "upconv3d_bwd dx")) return rc;
+    E2_REQUIRE(dx->n == x->n && dx->c == cin && dx->d == x->d && dx->h == x->h &&
+                   dx->w == x->w, "upconv3d_bwd: dx shape mismatch");
+    IgemmArgs a;
+    e2i_pack_dims(cin, cout * R, &a.ciP, &a.coP);
+    // Wp[ic' = co*R + r][oc = ci] = w[co][ci][r]
+    if (int rc = e2i_pack_weights(ctx, w, wp, cin, cout * R, 1, 1, 1, R, (int64_t)cin * R,
+                                  0, a.ciP, a.coP, 1, R))
+      return rc;
+    a.in = s2d; a.wp = wp; a.out = dx->ptr;
+    a.N = x->n; a.Cin = cout * R; a.Cout = cin;
+    a.kd = a.kh = a.kw = 1;
+    a.Do = x->d; a.Ho = x->h; a.Wo = x->w;
+    a.isN = (long)cout * R * S; a.isC = S; a.isZ = (long)x->h * x->w; a.isY = x->w;
+    a.osN = dx->sn; a.osC = dx->sc; a.osZ = dx->sd; a.osY = dx->sh;
+    a.upz = a.upy = a.upx = 1;
+    if (int rc = e2i_igemm_conv(ctx, a)) return rc;
+  }
+  if (dw) {
+    WgradArgs g;
+    g.x = x->ptr; g.dy = s2d; g.dw = dw;
+    g.N = x->n; g.Cin = cin; g.Cout = cout * R;
+    g.kd = g.kh = g.kw = 1;
+    g.Do = x->d; g.Ho = x->h; g.Wo = x->w;
+    g.xsN = x->sn; g.xsC = x->sc; g.xsZ = x->sd; g.xsY = x->sh;
+    g.dsN = (long)cout * R * S; g.dsC = S; g.dsZ = (long)x->h * x->w; g.dsY = x->w;
+    g.flip = 0;
+    g.upR = R;
+    if (int rc = e2i_wgrad_conv(ctx, g)) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// graph capture / events
+// ---------------------------------------------------------------------------
+struct e2_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+extern "C" int e2_graph_begin(e2_ctx* ctx) {
+  E2_REQUIRE(ctx, "graph_begin: null ctx");
+  E2_REQUIRE(ctx->stream != nullptr,
+             "graph_begin: capture needs a non-default stream (e2_ctx_set_stream)");
+  E2_CHECK_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
+  return 0;
+}
+
+extern "C" int e2_graph_end(e2_ctx* ctx, e2_graph** out) {
+  E2_REQUIRE(ctx && out, "graph_end: null argument");
+  hipGraph_t g = nullptr;
+  ctx->capturing = false;
+  E2_CHECK_HIP(hipStreamEndCapture(ctx->stream, &g));
+  hipGraphExec_t ex = nullptr;
+  E2_CHECK_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+  e2_graph* r = new e2_graph{g, ex};
+  *out = r;
+  return 0;
+}
+
+extern "C" int e2_graph_launch(e2_ctx* ctx, e2_graph* g) {
+  E2_REQUIRE(ctx && g, "graph_launch: null argument");
+  E2_CHECK_HIP(hipGraphLaunch(g->exec, ctx->stream));
+  return 0;
+}
+
+extern "C" int e2_graph_destroy(e2_graph* g) {
+  if (!g) return 0;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
+struct e2_event { hipEvent_t ev; };
+
+extern "C" int e2_event_create(e2_event** out) {
+  E2_REQUIRE(out, "event_create: null out");
+  hipEvent_t ev;
+  E2_CHECK_HIP(hipEventCreate(&ev));
+  *out = new e2_event{ev};
+  return 0;
+}
+extern "C" int e2_event_record(e2_ctx* ctx, e2_event* e) {
+  E2_REQUIRE(ctx && e, "event_record: null argument");
+  E2_CHECK_HIP(hipEventRecord(e->ev, ctx->stream));
+  return 0;
+}
+extern "C" int e2_event_elapsed_ms(e2_event* start, e2_event* stop, float* ms) {
+  E2_REQUIRE(start && stop && ms, "event_elapsed_ms: null argument");
+  E2_CHECK_HIP(hipEventSynchronize(stop->ev));
+  E2_CHECK_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+  return 0;
+}
+extern "C" int e2_event_destroy(e2_event* e) {
+  if (!e) return 0;
+  (void)hipEventDestroy(e->ev);
+  delete e;
+  return 0;
+}
+extern "C" int e2_stream_synchronize(e2_ctx* ctx) {
+  E2_REQUIRE(ctx, "stream_synchronize: null ctx");
+  E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}

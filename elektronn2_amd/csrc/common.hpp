@@ -1,0 +1,86 @@
+// Internal helpers shared by the libe2hip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/e2hip.h"
+
+struct e2_ctx {
+  int device;
+  hipStream_t stream;
+  int num_cu;
+  bool capturing;
+};
+
+void e2_set_error(const char* fmt, ...);
+
+#define E2_CHECK_HIP(expr)                                                   \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      e2_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,             \
+                   hipGetErrorString(_e));                                   \
+      return 1;                                                              \
+    }                                                                        \
+  } while (0)
+
+#define E2_REQUIRE(cond, ...)                                                \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      e2_set_error(__VA_ARGS__);                                             \
+      return 2;                                                              \
+    }                                                                        \
+  } while (0)
+
+static inline int e2_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t e2_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- internal launchers (defined in the .hip files) ---------------------
+
+// Generic strided "valid" correlation as implicit GEMM on fp32 MFMA.
+//   out[n][oc][z][y][x] (+)= sum_ic sum_t Wp[dz][t][ic][oc] * in[n][ic][z+dz][y+ty][x+tx]
+// Wp is the PACKED weight image produced by e2i_pack_weights (flip folded in).
+struct IgemmArgs {
+  const float* in;
+  const float* wp;
+  float* out;
+  int N, Cin, Cout;
+  int kd, kh, kw;
+  int Do, Ho, Wo;          // output spatial
+  int64_t isN, isC, isZ, isY;
+  int64_t osN, osC, osZ, osY;
+  int ciP, coP;            // padded channel counts of the packed image
+  // upconv scatter mode: out channel oc' = co*R + r, stored at
+  // out[n][co][pz*z+rz][py*y+ry][px*x+rx]; R = pz*py*px (1 = off)
+  int upz, upy, upx;
+};
+int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
+
+// Wp[dz][t][ic(ciP)][oc(coP)] = w[(oc/Rout)*wsO + (ic/Rin)*wsI + tap + oc%Rout + ic%Rin],
+// tap = (dz*kh*kw+t), reversed when flip.  Zero in the padding.  Cout/Cin are
+// the GEMM's channel counts (already multiplied by Rout/Rin).  Rout/Rin > 1 fold
+// UpConv's sub-position r into the out / in channel index (kd=kh=kw=1 then).
+int e2i_pack_weights(e2_ctx*, const float* w, float* wp, int Cout, int Cin,
+                     int kd, int kh, int kw, int64_t wsO, int64_t wsI, int flip,
+                     int ciP, int coP, int Rout, int Rin);
+void e2i_pack_dims(int cout, int cin, int* ciP, int* coP);
+
+struct WgradArgs {
+  const float* x;     // input activations view
+  const float* dy;    // output-gradient view (unpadded dims)
+  float* dw;          // [M][Cin*T] dense, accumulated atomically (pre-zeroed)
+  int N, Cin, Cout;
+  int kd, kh, kw;
+  int Do, Ho, Wo;
+  int64_t xsN, xsC, xsZ, xsY;
+  int64_t dsN, dsC, dsZ, dsY;
+  int flip;           // store tap index reversed
+  int upR;            // >1: rows are (co*R + r); store dw[co][col][r] (UpConv)
+};
+int e2i_upconv_dpre_s2d(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* yout, int pz,
+                        int py, int px, int act, float* s2d, float* dbias);
+int e2i_wgrad_conv(e2_ctx*, const WgradArgs& a);
+
+// view helpers (pointwise.hip)
+int e2i_fill_view(e2_ctx*, const e2_tensor5* v, float value);

@@ -1,0 +1,578 @@
+// pointwise.hip -- the HBM-bound kernels of the step: max-pool + bias +
+// activation (forward and backward), stand-alone pool, view fill / copy,
+// NCDHW<->NDHWC transposes through LDS, depth-to-space helpers for UpConv,
+// channel softmax + MultinoulliNLL, and the reference's Adam / SGD updates.
+// All are one-element-per-lane, W-contiguous (coalesced) streaming kernels;
+// reductions go wave-shuffle -> LDS -> one atomic per work-group.
+#include "common.hpp"
+#include <algorithm>
+
+#define E2_EPS_NLL 1e-5f
+#define E2_EPS_ADAM 1e-5f
+
+struct View5 {
+  float* p;
+  int n, c, d, h, w;
+  long sn, sc, sd, sh;
+};
+static inline View5 mk(const e2_tensor5* t) {
+  return View5{t->ptr, t->n, t->c, t->d, t->h, t->w, (long)t->sn, (long)t->sc,
+               (long)t->sd, (long)t->sh};
+}
+__device__ __forceinline__ long vidx(const View5& v, int n, int c, int z, int y, int x) {
+  return (long)n * v.sn + (long)c * v.sc + (long)z * v.sd + (long)y * v.sh + x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// sum over a 256-thread block; result valid in thread 0
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// fill / copy
+// ---------------------------------------------------------------------------
+__global__ void fill_flat_kernel(float* p, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+__global__ void fill_view_kernel(View5 v, float val) {
+  // grid: (ceil(d*h*w/256), c, n)
+  const long S = (long)v.d * v.h * v.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  if (s >= S) return;
+  const int x = (int)(s % v.w);
+  const long t = s / v.w;
+  const int y = (int)(t % v.h), z = (int)(t / v.h);
+  v.p[vidx(v, blockIdx.z, blockIdx.y, z, y, x)] = val;
+}
+
+__global__ void copy_view_kernel(View5 src, View5 dst, int accumulate) {
+  const long S = (long)src.d * src.h * src.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  if (s >= S) return;
+  const int x = (int)(s % src.w);
+  const long t = s / src.w;
+  const int y = (int)(t % src.h), z = (int)(t / src.h);
+  const float v = src.p[vidx(src, blockIdx.z, blockIdx.y, z, y, x)];
+  float* d = dst.p + vidx(dst, blockIdx.z, blockIdx.y, z, y, x);
+  *d = accumulate ? (*d + v) : v;
+}
+
+// ---------------------------------------------------------------------------
+// max-pool (+bias +act) forward:  out = act(max_window(y) + b[c])
+// ---------------------------------------------------------------------------
+template <bool HAS_BIAS>
+__global__ void pool_fwd_kernel(View5 y, const float* __restrict__ bias, int pz, int py,
+                                int px, int act, View5 out) {
+  const long S = (long)out.d * out.h * out.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  if (s >= S) return;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int xo = (int)(s % out.w);
+  const long t = s / out.w;
+  const int yo = (int)(t % out.h), zo = (int)(t / out.h);
+  const float* src = y.p + vidx(y, n, c, zo * pz, yo * py, xo * px);
+  float m = src[0];
+  for (int a = 0; a < pz; ++a)
+    for (int b = 0; b < py; ++b) {
+      const float* row = src + a * y.sd + b * y.sh;
+      for (int e = 0; e < px; ++e) m = fmaxf(m, row[e]);
+    }
+  float v = m;
+  if (HAS_BIAS) v += bias[c];
+  if (act == E2_ACT_RELU) v = fmaxf(v, 0.f);
+  out.p[vidx(out, n, c, zo, yo, xo)] = v;
+}
+
+// backward: dy[window] = (y == max) ? dout * act'(max + b) : 0 ; dbias += sum
+template <bool HAS_BIAS>
+__global__ void pool_bwd_kernel(View5 dout, View5 y, const float* __restrict__ bias,
+                                int pz, int py, int px, int act, View5 dy,
+                                float* __restrict__ dbias, int accumulate) {
+  __shared__ float red[4];
+  const long S = (long)dout.d * dout.h * dout.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  const int c = blockIdx.y, n = blockIdx.z;
+  float g = 0.f;
+  if (s < S) {
+    const int xo = (int)(s % dout.w);
+    const long t = s / dout.w;
+    const int yo = (int)(t % dout.h), zo = (int)(t / dout.h);
+    const float* src = y.p + vidx(y, n, c, zo * pz, yo * py, xo * px);
+    float m = src[0];
+    for (int a = 0; a < pz; ++a)
+      for (int b = 0; b < py; ++b) {
+        const float* row = src + a * y.sd + b * y.sh;
+        for (int e = 0; e < px; ++e) m = fmaxf(m, row[e]);
+      }
+    g = dout.p[vidx(dout, n, c, zo, yo, xo)];
+    if (act == E2_ACT_RELU) {
+      const float pre = HAS_BIAS ? (m + bias[c]) : m;
+      g *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
+    }
+    float* dst = dy.p + vidx(dy, n, c, zo * pz, yo * py, xo * px);
+    for (int a = 0; a < pz; ++a)
+      for (int b = 0; b < py; ++b) {
+        const float* row = src + a * y.sd + b * y.sh;
+        float* drow = dst + a * dy.sd + b * dy.sh;
+        for (int e = 0; e < px; ++e) {
+          const float v = (row[e] == m) ? g : 0.f;
+          drow[e] = accumulate ? (drow[e] + v) : v;
+        }
+      }
+  }
+  if (dbias != nullptr) {
+    const float tot = block_sum256(g, red);
+    if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(dbias + c, tot);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// UpConv helpers: dpre in space-to-depth layout
+//   s2d[n][co*R + r][z][y][x] = dout[n][co][pz*z+rz][py*y+ry][px*x+rx] * act'(yout)
+// one thread per dout element (reads coalesced), dbias[co] += sum
+// ---------------------------------------------------------------------------
+__global__ void upconv_dpre_s2d_kernel(View5 dout, View5 yout, int pz, int py, int px,
+                                       int act, float* __restrict__ s2d,
+                                       float* __restrict__ dbias) {
+  __shared__ float red[4];
+  const long S = (long)dout.d * dout.h * dout.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  const int c = blockIdx.y, n = blockIdx.z;
+  float g = 0.f;
+  if (s < S) {
+    const int x = (int)(s % dout.w);
+    const long t = s / dout.w;
+    const int y = (int)(t % dout.h), z = (int)(t / dout.h);
+    g = dout.p[vidx(dout, n, c, z, y, x)];
+    if (act == E2_ACT_RELU) {
+      const float o = yout.p[vidx(yout, n, c, z, y, x)];
+      g = (o > 0.f) ? g : 0.f;
+    }
+    const int zi = z / pz, rz = z - zi * pz;
+    const int yi = y / py, ry = y - yi * py;
+    const int xi = x / px, rx = x - xi * px;
+    const int R = pz * py * px;
+    const int r = (rz * py + ry) * px + rx;
+    const int di = dout.d / pz, hi = dout.h / py, wi = dout.w / px;
+    const long o = ((((long)n * dout.c + c) * R + r) * di + zi) * (long)hi * wi +
+                   (long)yi * wi + xi;
+    s2d[o] = g;
+  }
+  if (dbias != nullptr) {
+    const float tot = block_sum256(g, red);
+    if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(dbias + c, tot);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// transposes through a 32x33 LDS tile:  [C][S] <-> [S][C]
+// ---------------------------------------------------------------------------
+__global__ void ncdhw_to_ndhwc_kernel(View5 src, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const long S = (long)src.d * src.h * src.w;
+  const int n = blockIdx.z;
+  const long s0 = blockIdx.x * 32L;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i;
+    const long s = s0 + tx;
+    float v = 0.f;
+    if (c < src.c && s < S) {
+      const int x = (int)(s % src.w);
+      const long t = s / src.w;
+      v = src.p[vidx(src, n, c, (int)(t / src.h), (int)(t % src.h), x)];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const long s = s0 + i;
+    const int c = c0 + tx;
+    if (c < src.c && s < S) dst[((long)n * S + s) * src.c + c] = tile[tx][i];
+  }
+}
+
+__global__ void ndhwc_to_ncdhw_kernel(const float* __restrict__ src, View5 dst) {
+  __shared__ float tile[32][33];
+  const long S = (long)dst.d * dst.h * dst.w;
+  const int n = blockIdx.z;
+  const long s0 = blockIdx.x * 32L;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const long s = s0 + i;
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (c < dst.c && s < S) v = src[((long)n * S + s) * dst.c + c];
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i;
+    const long s = s0 + tx;
+    if (c < dst.c && s < S) {
+      const int x = (int)(s % dst.w);
+      const long t = s / dst.w;
+      dst.p[vidx(dst, n, c, (int)(t / dst.h), (int)(t % dst.h), x)] = tile[tx][i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// channel softmax + MultinoulliNLL (sparse target), thread per position
+// ---------------------------------------------------------------------------
+__global__ void softmax_nll_fwd_kernel(View5 lg, View5 tg, View5 pr,
+                                       float* __restrict__ stats) {
+  __shared__ float red[4];
+  const long S = (long)lg.d * lg.h * lg.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  const int n = blockIdx.z;
+  float lsum = 0.f, nlab = 0.f;
+  if (s < S) {
+    const int x = (int)(s % lg.w);
+    const long t = s / lg.w;
+    const int y = (int)(t % lg.h), z = (int)(t / lg.h);
+    const float* lp = lg.p + vidx(lg, n, 0, z, y, x);
+    float m = lp[0];
+    for (int c = 1; c < lg.c; ++c) m = fmaxf(m, lp[c * lg.sc]);
+    float den = 0.f;
+    for (int c = 0; c < lg.c; ++c) den += expf(lp[c * lg.sc] - m);
+    const float tv = tg.p[vidx(tg, n, 0, z, y, x)];
+    float* pp = pr.p + vidx(pr, n, 0, z, y, x);
+    for (int c = 0; c < lg.c; ++c) {
+      const float pc = expf(lp[c * lg.sc] - m) / den;
+      pp[c * pr.sc] = pc;
+      if (tv == (float)c) { lsum -= logf(pc + E2_EPS_NLL); nlab += 1.f; }
+    }
+  }
+  const float a = block_sum256(lsum, red);
+  const float b = block_sum256(nlab, red);
+  if (threadIdx.x == 0) {
+    if (a != 0.f) unsafeAtomicAdd(stats + 0, a);
+    if (b != 0.f) unsafeAtomicAdd(stats + 1, b);
+  }
+}
+
+__global__ void softmax_nll_bwd_kernel(View5 pr, View5 tg, const float* __restrict__ stats,
+                                       View5 dl, float* __restrict__ loss_out) {
+  const long S = (long)pr.d * pr.h * pr.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  const int n = blockIdx.z;
+  const float inv = 1.f / (stats[1] + E2_EPS_NLL);
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0 && loss_out)
+    loss_out[0] = stats[0] * inv;
+  if (s >= S) return;
+  const int x = (int)(s % pr.w);
+  const long t = s / pr.w;
+  const int y = (int)(t % pr.h), z = (int)(t / pr.h);
+  const float tv = tg.p[vidx(tg, n, 0, z, y, x)];
+  const float* pp = pr.p + vidx(pr, n, 0, z, y, x);
+  float* dp = dl.p + vidx(dl, n, 0, z, y, x);
+  float pt = 0.f;
+  int tc = -1;
+  for (int c = 0; c < pr.c; ++c)
+    if (tv == (float)c) { tc = c; pt = pp[c * pr.sc]; }
+  // dL/dp_t = -inv/(p_t+eps);  dlogit_c = p_c*(dp_c - sum_k dp_k p_k)
+  const float gpt = (tc >= 0) ? (-inv / (pt + E2_EPS_NLL)) * pt : 0.f;
+  for (int c = 0; c < pr.c; ++c) {
+    const float pc = pp[c * pr.sc];
+    dp[c * dl.sc] = gpt * ((c == tc ? 1.f : 0.f) - pc);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// optimisers on a flat arena (hyper = {lr, mom, beta2, wd, t, factor})
+// ---------------------------------------------------------------------------
+__global__ void adam_tick_kernel(float* hyper) {
+  const float t = hyper[4] + 1.f;
+  hyper[4] = t;
+  hyper[5] = sqrtf(1.f - powf(hyper[2], t)) / (1.f - powf(hyper[1], t));
+}
+
+__device__ __forceinline__ float seg_mult(const int64_t* seg_off, const float* seg_reg,
+                                          int n_seg, size_t i) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((size_t)seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return seg_reg[lo];
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ s, size_t n,
+                            const int64_t* __restrict__ seg_off,
+                            const float* __restrict__ seg_reg, int n_seg,
+                            const float* __restrict__ hyper) {
+  const float lr = hyper[0], mom = hyper[1], b2 = hyper[2], wd = hyper[3], fac = hyper[5];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float nm = mom * m[i] + (1.f - mom) * gi;
+    const float ns = b2 * s[i] + (1.f - b2) * gi * gi;
+    float dir = fac * nm / sqrtf(ns + E2_EPS_ADAM);
+    const float mult = seg_mult(seg_off, seg_reg, n_seg, i);
+    const float pi = p[i];
+    if (mult != 0.f) dir += wd * pi * mult;
+    m[i] = nm; s[i] = ns;
+    p[i] = pi - lr * dir;
+  }
+}
+
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                           float* __restrict__ d, size_t n,
+                           const int64_t* __restrict__ seg_off,
+                           const float* __restrict__ seg_reg, int n_seg,
+                           const float* __restrict__ hyper) {
+  const float lr = hyper[0], mom = hyper[1], wd = hyper[3];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float nd = g[i] + mom * d[i];
+    const float mult = seg_mult(seg_off, seg_reg, n_seg, i);
+    const float pi = p[i];
+    float step = nd;
+    if (mult != 0.f) step += wd * pi * mult;
+    d[i] = nd;
+    p[i] = pi - lr * step;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host wrappers
+// ---------------------------------------------------------------------------
+static int check_view(const e2_tensor5* t, const char* name) {
+  E2_REQUIRE(t && t->ptr, "%s: null tensor", name);
+  E2_REQUIRE(t->n > 0 && t->c > 0 && t->d > 0 && t->h > 0 && t->w > 0,
+             "%s: empty tensor (%d,%d,%d,%d,%d)", name, t->n, t->c, t->d, t->h, t->w);
+  E2_REQUIRE(t->c < 65536 && t->n < 65536, "%s: n/c too large for grid", name);
+  return 0;
+}
+static dim3 grid_for(const View5& v) {
+  const long S = (long)v.d * v.h * v.w;
+  return dim3((unsigned)((S + 255) / 256), (unsigned)v.c, (unsigned)v.n);
+}
+
+int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
+  if (int rc = check_view(t, "fill_view")) return rc;
+  View5 v = mk(t);
+  hipLaunchKernelGGL(fill_view_kernel, grid_for(v), dim3(256), 0, ctx->stream, v, value);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_fill(e2_ctx* ctx, float* ptr, size_t n, float value) {
+  E2_REQUIRE(ctx && ptr, "e2_fill: null argument");
+  if (n == 0) return 0;
+  if (value == 0.f) {
+    E2_CHECK_HIP(hipMemsetAsync(ptr, 0, n * sizeof(float), ctx->stream));
+    return 0;
+  }
+  int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(fill_flat_kernel, dim3(grid), dim3(256), 0, ctx->stream, ptr, n, value);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_copy5(e2_ctx* ctx, const e2_tensor5* src, const e2_tensor5* dst,
+                        int accumulate) {
+  E2_REQUIRE(ctx, "e2_copy5: null ctx");
+  if (int rc = check_view(src, "copy5 src")) return rc;
+  if (int rc = check_view(dst, "copy5 dst")) return rc;
+  E2_REQUIRE(src->n == dst->n && src->c == dst->c && src->d == dst->d &&
+                 src->h == dst->h && src->w == dst->w,
+             "e2_copy5: size mismatch");
+  View5 s = mk(src), d = mk(dst);
+  hipLaunchKernelGGL(copy_view_kernel, grid_for(s), dim3(256), 0, ctx->stream, s, d,
+                     accumulate);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int pool_shapes_ok(const e2_tensor5* big, const e2_tensor5* small, int pz, int py,
+                          int px, const char* name) {
+  E2_REQUIRE(pz >= 1 && py >= 1 && px >= 1, "%s: pool factors must be >= 1", name);
+  E2_REQUIRE(big->n == small->n && big->c == small->c, "%s: n/c mismatch", name);
+  E2_REQUIRE(big->d / pz == small->d && big->h / py == small->h && big->w / px == small->w,
+             "%s: pooled shape mismatch: (%d,%d,%d)/(%d,%d,%d) != (%d,%d,%d)", name,
+             big->d, big->h, big->w, pz, py, px, small->d, small->h, small->w);
+  return 0;
+}
+
+extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const float* bias,
+                                    int pz, int py, int px, int act,
+                                    const e2_tensor5* out) {
+  E2_REQUIRE(ctx, "pool_bias_act_fwd: null ctx");
+  if (int rc = check_view(y, "pool_bias_act_fwd y")) return rc;
+  if (int rc = check_view(out, "pool_bias_act_fwd out")) return rc;
+  if (int rc = pool_shapes_ok(y, out, pz, py, px, "pool_bias_act_fwd")) return rc;
+  E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "pool_bias_act_fwd: bad act %d", act);
+  View5 vy = mk(y), vo = mk(out);
+  if (bias)
+    hipLaunchKernelGGL((pool_fwd_kernel<true>), grid_for(vo), dim3(256), 0, ctx->stream, vy,
+                       bias, pz, py, px, act, vo);
+  else
+    hipLaunchKernelGGL((pool_fwd_kernel<false>), grid_for(vo), dim3(256), 0, ctx->stream,
+                       vy, bias, pz, py, px, act, vo);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int pool_bwd_common(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* y,
+                           const float* bias, int pz, int py, int px, int act,
+                           const e2_tensor5* dy, float* dbias, int accumulate) {
+  if (int rc = check_view(dout, "pool_bwd dout")) return rc;
+  if (int rc = check_view(y, "pool_bwd y")) return rc;
+  if (int rc = check_view(dy, "pool_bwd dy")) return rc;
+  if (int rc = pool_shapes_ok(y, dout, pz, py, px, "pool_bwd")) return rc;
+  E2_REQUIRE(dy->n == y->n && dy->c == y->c && dy->d == y->d && dy->h == y->h &&
+                 dy->w == y->w, "pool_bwd: dy/y shape mismatch");
+  // floor semantics: rows/cols beyond the pooled extent receive no gradient
+  if (!accumulate && (y->d % pz || y->h % py || y->w % px)) {
+    if (int rc = e2i_fill_view(ctx, dy, 0.f)) return rc;
+  }
+  View5 vd = mk(dout), vy = mk(y), vdy = mk(dy);
+  if (bias)
+    hipLaunchKernelGGL((pool_bwd_kernel<true>), grid_for(vd), dim3(256), 0, ctx->stream, vd,
+                       vy, bias, pz, py, px, act, vdy, dbias, accumulate);
+  else
+    hipLaunchKernelGGL((pool_bwd_kernel<false>), grid_for(vd), dim3(256), 0, ctx->stream,
+                       vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_pool_bias_act_bwd(e2_ctx* ctx, const e2_tensor5* dout,
+                                    const e2_tensor5* y, const float* bias, int pz, int py,
+                                    int px, int act, const e2_tensor5* dy, float* dbias) {
+  E2_REQUIRE(ctx, "pool_bias_act_bwd: null ctx");
+  E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "pool_bias_act_bwd: bad act %d", act);
+  return pool_bwd_common(ctx, dout, y, bias, pz, py, px, act, dy, dbias, 0);
+}
+
+extern "C" int e2_maxpool3d_fwd(e2_ctx* ctx, const e2_tensor5* x, int pz, int py, int px,
+                                const e2_tensor5* out) {
+  return e2_pool_bias_act_fwd(ctx, x, nullptr, pz, py, px, E2_ACT_LIN, out);
+}
+
+extern "C" int e2_maxpool3d_bwd(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* x,
+                                int pz, int py, int px, const e2_tensor5* dx,
+                                int accumulate) {
+  E2_REQUIRE(ctx, "maxpool3d_bwd: null ctx");
+  return pool_bwd_common(ctx, dout, x, nullptr, pz, py, px, E2_ACT_LIN, dx, nullptr,
+                         accumulate);
+}
+
+int e2i_upconv_dpre_s2d(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* yout, int pz,
+                        int py, int px, int act, float* s2d, float* dbias) {
+  View5 vd = mk(dout), vy = mk(yout);
+  hipLaunchKernelGGL(upconv_dpre_s2d_kernel, grid_for(vd), dim3(256), 0, ctx->stream, vd,
+                     vy, pz, py, px, act, s2d, dbias);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_transpose_ncdhw_to_ndhwc(e2_ctx* ctx, const e2_tensor5* src, float* dst) {
+  E2_REQUIRE(ctx && dst, "transpose: null argument");
+  if (int rc = check_view(src, "transpose src")) return rc;
+  View5 v = mk(src);
+  const long S = (long)v.d * v.h * v.w;
+  dim3 grid((unsigned)((S + 31) / 32), (unsigned)((v.c + 31) / 32), (unsigned)v.n);
+  hipLaunchKernelGGL(ncdhw_to_ndhwc_kernel, grid, dim3(256), 0, ctx->stream, v, dst);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_transpose_ndhwc_to_ncdhw(e2_ctx* ctx, const float* src,
+                                           const e2_tensor5* dst) {
+  E2_REQUIRE(ctx && src, "transpose: null argument");
+  if (int rc = check_view(dst, "transpose dst")) return rc;
+  View5 v = mk(dst);
+  const long S = (long)v.d * v.h * v.w;
+  dim3 grid((unsigned)((S + 31) / 32), (unsigned)((v.c + 31) / 32), (unsigned)v.n);
+  hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel, grid, dim3(256), 0, ctx->stream, src, v);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_softmax_nll_fwd(e2_ctx* ctx, const e2_tensor5* logits,
+                                  const e2_tensor5* target, const e2_tensor5* probs,
+                                  float* stats) {
+  E2_REQUIRE(ctx && stats, "softmax_nll_fwd: null argument");
+  if (int rc = check_view(logits, "softmax_nll_fwd logits")) return rc;
+  if (int rc = check_view(target, "softmax_nll_fwd target")) return rc;
+  if (int rc = check_view(probs, "softmax_nll_fwd probs")) return rc;
+  E2_REQUIRE(target->c == 1 && target->n == logits->n && target->d == logits->d &&
+                 target->h == logits->h && target->w == logits->w,
+             "softmax_nll_fwd: target must be (n,1,d,h,w) matching logits");
+  E2_REQUIRE(probs->c == logits->c && probs->d == logits->d && probs->h == logits->h &&
+                 probs->w == logits->w && probs->n == logits->n,
+             "softmax_nll_fwd: probs/logits shape mismatch");
+  View5 l = mk(logits), t = mk(target), p = mk(probs);
+  const long S = (long)l.d * l.h * l.w;
+  dim3 grid((unsigned)((S + 255) / 256), 1, (unsigned)l.n);
+  hipLaunchKernelGGL(softmax_nll_fwd_kernel, grid, dim3(256), 0, ctx->stream, l, t, p, stats);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_softmax_nll_bwd(e2_ctx* ctx, const e2_tensor5* probs,
+                                  const e2_tensor5* target, const float* stats,
+                                  const e2_tensor5* dlogits, float* loss_out) {
+  E2_REQUIRE(ctx && stats, "softmax_nll_bwd: null argument");
+  if (int rc = check_view(probs, "softmax_nll_bwd probs")) return rc;
+  if (int rc = check_view(target, "softmax_nll_bwd target")) return rc;
+  if (int rc = check_view(dlogits, "softmax_nll_bwd dlogits")) return rc;
+  E2_REQUIRE(dlogits->c == probs->c && dlogits->d == probs->d && dlogits->h == probs->h &&
+                 dlogits->w == probs->w && dlogits->n == probs->n && target->c == 1 &&
+                 target->d == probs->d && target->h == probs->h && target->w == probs->w,
+             "softmax_nll_bwd: shape mismatch");
+  View5 p = mk(probs), t = mk(target), d = mk(dlogits);
+  const long S = (long)p.d * p.h * p.w;
+  dim3 grid((unsigned)((S + 255) / 256), 1, (unsigned)p.n);
+  hipLaunchKernelGGL(softmax_nll_bwd_kernel, grid, dim3(256), 0, ctx->stream, p, t, stats, d,
+                     loss_out);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_adam_step(e2_ctx* ctx, float* p, const float* g, float* m, float* s,
+                            size_t n, const int64_t* seg_off, const float* seg_reg,
+                            int n_seg, const float* hyper) {
+  E2_REQUIRE(ctx && p && g && m && s && seg_off && seg_reg && hyper && n_seg > 0,
+             "adam_step: null argument");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ctx->stream,
+                     const_cast<float*>(hyper));
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, g, m, s, n,
+                     seg_off, seg_reg, n_seg, hyper);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_sgd_step(e2_ctx* ctx, float* p, const float* g, float* d, size_t n,
+                           const int64_t* seg_off, const float* seg_reg, int n_seg,
+                           const float* hyper) {
+  E2_REQUIRE(ctx && p && g && d && seg_off && seg_reg && hyper && n_seg > 0,
+             "sgd_step: null argument");
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, g, d, n, seg_off,
+                     seg_reg, n_seg, hyper);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}

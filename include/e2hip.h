@@ -1,0 +1,187 @@
+/* e2hip.h -- C ABI of libe2hip.so: MI355X (gfx950) kernels for the 3-D
+ * conv / pool / upconv training step behind ELEKTRONN2's neuromancer
+ * Conv / Pool / UpConv nodes.
+ *
+ * The reference has NO FFI for this path: its seam is the Theano op calls in
+ * elektronn2/neuromancer/computations.py and the one theano.function() call in
+ * graphutils.py:376-387.  Each entry point below names the reference call it
+ * replaces (paths relative to /root/reference/elektronn2/).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from e2_last_error() (thread-local).
+ *   - all data pointers are DEVICE pointers owned by the caller; the library
+ *     never allocates device memory behind the caller's back (workspace sizes
+ *     come from e2_*_workspace_bytes()).
+ *   - layouts: activations (b,f,z,x,y) = NCDHW, fp32; weights
+ *     (n_f, n_in, kz, kx, ky) = KCDHW, fp32  (neural.py:615-623 'dnn' order).
+ *     Tensors are described by e2_tensor5: sizes + element strides, so crops,
+ *     channel-concat slices and zero-padded gradient buffers are views.
+ *     The innermost (y / "W") stride must be 1.
+ *   - one hipStream_t per context; launches are asynchronous on it; no
+ *     internal threads; nothing here synchronises the device, so every call is
+ *     legal inside hipStreamBeginCapture/EndCapture (e2_graph_*).
+ */
+#ifndef E2HIP_H
+#define E2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct e2_ctx e2_ctx;
+
+/* 5-D fp32 tensor view. n = batch, c = features, d/h/w = z/x/y spatial.
+ * Strides in ELEMENTS; the w stride is implicitly 1. */
+typedef struct e2_tensor5 {
+  float*  ptr;
+  int32_t n, c, d, h, w;
+  int64_t sn, sc, sd, sh;
+} e2_tensor5;
+
+enum { E2_ACT_LIN = 0, E2_ACT_RELU = 1 };
+
+/* ---- context / stream / errors --------------------------------------- */
+int  e2_ctx_create(int device, e2_ctx** out);
+int  e2_ctx_destroy(e2_ctx* ctx);
+/* stream: a hipStream_t (as void*); NULL = the default stream. */
+int  e2_ctx_set_stream(e2_ctx* ctx, void* stream);
+const char* e2_last_error(void);
+int  e2_version(void);
+
+/* ---- conv  (computations.py:364-428 conv(), 3-D branch; F1: true
+ *      convolution, kernel flipped in every spatial dim, 'valid') --------- */
+/* bytes of workspace conv fwd / dgrad need for the packed weight image. */
+size_t e2_conv3d_workspace_bytes(int cout, int cin, int kd, int kh, int kw);
+
+/* y = conv_valid_flip(x, w).  y must be (n, cout, d-kd+1, h-kh+1, w-kw+1).
+ * w: dense KCDHW [cout][cin][kd][kh][kw].  ws: workspace (device). */
+int e2_conv3d_fwd(e2_ctx*, const e2_tensor5* x, const float* w,
+                  int cout, int kd, int kh, int kw,
+                  const e2_tensor5* y, void* ws, size_t ws_bytes);
+
+/* dx = d(loss)/dx given dy (replaces Theano's GpuDnnConv3dGradI /
+ * conv3d2d grad born at model.py:182).  dy_pad is dy stored in the interior
+ * of a buffer zero-padded by (kd-1, kh-1, kw-1) on every side:
+ * dy_pad dims = (n, cout, do+2(kd-1), ho+2(kh-1), wo+2(kw-1)); the border
+ * MUST be zero.  dx dims = (n, cin, do+kd-1, ho+kh-1, wo+kw-1). */
+int e2_conv3d_dgrad(e2_ctx*, const e2_tensor5* dy_pad, const float* w,
+                    int cin, int kd, int kh, int kw,
+                    const e2_tensor5* dx, void* ws, size_t ws_bytes);
+
+/* Split form of the two calls above: the packed weight image depends only on
+ * w, so a caller that runs many convolutions with the same weights (or wants
+ * the repack off the critical path) packs once.  mode 0 = forward image,
+ * mode 1 = dgrad image.  ws must hold e2_conv3d_workspace_bytes(). */
+int e2_conv3d_pack(e2_ctx*, const float* w, int cout, int cin, int kd, int kh,
+                   int kw, int mode, void* ws, size_t ws_bytes);
+int e2_conv3d_fwd_packed(e2_ctx*, const e2_tensor5* x, const void* wp, int cout,
+                         int kd, int kh, int kw, const e2_tensor5* y);
+int e2_conv3d_dgrad_packed(e2_ctx*, const e2_tensor5* dy_pad, const void* wp,
+                           int cin, int kd, int kh, int kw, const e2_tensor5* dx);
+
+/* dw[cout][cin][kd][kh][kw] = d(loss)/dw (replaces GpuDnnConv3dGradW).
+ * dy is the UNPADDED view (n, cout, do, ho, wo) (it may be the interior view
+ * of a padded buffer).  dw is overwritten. */
+int e2_conv3d_wgrad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy,
+                    float* dw, int kd, int kh, int kw);
+
+/* ---- pool + bias + activation  (computations.py:538-631 pooling();
+ *      neural.py:705-712; computations.py:57-134 apply_activation) -------- */
+/* out = act(maxpool(y, pool) + bias[c]) ; pool == stride, floor semantics. */
+int e2_pool_bias_act_fwd(e2_ctx*, const e2_tensor5* y, const float* bias,
+                         int pz, int py, int px, int act,
+                         const e2_tensor5* out);
+/* Given dout = dL/dout: dy = dL/dy (every element equal to its window max
+ * receives the gradient -- Theano CPU tie rule; relu'(0) = 0.5) written to the
+ * view dy (typically the interior of the zero-padded dgrad buffer), and
+ * dbias[c] += sum(dL/dpre).  dbias must be zeroed by the caller. */
+int e2_pool_bias_act_bwd(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* y,
+                         const float* bias, int pz, int py, int px, int act,
+                         const e2_tensor5* dy, float* dbias);
+
+/* stand-alone max-pool (neural.py:1520-1523 Pool node) */
+int e2_maxpool3d_fwd(e2_ctx*, const e2_tensor5* x, int pz, int py, int px,
+                     const e2_tensor5* out);
+/* dx (+)= pool-backward(dout); accumulate != 0 adds into dx. */
+int e2_maxpool3d_bwd(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* x,
+                     int pz, int py, int px, const e2_tensor5* dx,
+                     int accumulate);
+
+/* ---- UpConv  (neural.py:989-1072; computations.py:216-255 upconv(),
+ *      749-782 unpooling_nd; F2: y[n,co,p*i+r] = sum_ci w[co,ci,r] x[n,ci,i]) */
+/* (n,d,h,w) = dims of the UpConv INPUT x. */
+size_t e2_upconv3d_workspace_bytes(int cout, int cin, int pz, int py, int px,
+                                   int n, int d, int h, int w);
+/* y = act(upconv(x, w) + bias); w [cout][cin][pz][py][px]; bias may be NULL
+ * (then act must be LIN). */
+int e2_upconv3d_fwd(e2_ctx*, const e2_tensor5* x, const float* w,
+                    const float* bias, int cout, int pz, int py, int px,
+                    int act, const e2_tensor5* y, void* ws, size_t ws_bytes);
+/* dpre = dout * act'(y) is formed internally from the forward OUTPUT y
+ * (relu: y > 0).  dx overwritten; dw overwritten; dbias overwritten.
+ * Any of dx / dw / dbias may be NULL to skip it. */
+int e2_upconv3d_bwd(e2_ctx*, const e2_tensor5* x, const float* w,
+                    const e2_tensor5* y, const e2_tensor5* dout,
+                    int pz, int py, int px, int act,
+                    const e2_tensor5* dx, float* dw, float* dbias,
+                    void* ws, size_t ws_bytes);
+
+/* ---- layout / copies (computations.py:398-401,414-428 dimshuffles;
+ *      neural.py:1152-1168 Crop; node_basic.py:1433-1440 Concat) ---------- */
+/* dst[n][d][h][w][c] (dense NDHWC) <- src (NCDHW view) and back; staged
+ * through LDS tiles so both sides are coalesced. */
+int e2_transpose_ncdhw_to_ndhwc(e2_ctx*, const e2_tensor5* src, float* dst);
+int e2_transpose_ndhwc_to_ncdhw(e2_ctx*, const float* src, const e2_tensor5* dst);
+/* dst (+)= src, both arbitrary views of identical sizes. */
+int e2_copy5(e2_ctx*, const e2_tensor5* src, const e2_tensor5* dst,
+             int accumulate);
+int e2_fill(e2_ctx*, float* ptr, size_t n, float value);
+
+/* ---- loss (computations.py:175-176 softmax; loss.py:261-347
+ *      MultinoulliNLL(target_is_sparse); loss.py:1357-1363 AggregateLoss) - */
+/* probs = softmax_c(logits); loss_sum += sum_pos -log(p[target]+1e-5);
+ * n_lab += #labelled (target in [0,C)).  stats = {loss_sum, n_lab} must be
+ * zeroed by the caller.  target: (n,1,d,h,w) float class ids. */
+int e2_softmax_nll_fwd(e2_ctx*, const e2_tensor5* logits,
+                       const e2_tensor5* target, const e2_tensor5* probs,
+                       float* stats);
+/* dlogits = d(loss)/d(logits) with loss = loss_sum/(n_lab+1e-5);
+ * also writes loss_out[0] = loss (device scalar). */
+int e2_softmax_nll_bwd(e2_ctx*, const e2_tensor5* probs,
+                       const e2_tensor5* target, const float* stats,
+                       const e2_tensor5* dlogits, float* loss_out);
+
+/* ---- optimiser (optimiser.py:273-334 Adam; 135-165 SGD) on one flat
+ *      parameter arena.  wd_mult[i] = weight-decay multiplier per element
+ *      segment is given by seg tables: for segment s, elements
+ *      [seg_off[s], seg_off[s+1]) use decay multiplier seg_reg[s]. --------- */
+int e2_adam_step(e2_ctx*, float* p, const float* g, float* m, float* s,
+                 size_t n, const int64_t* seg_off, const float* seg_reg,
+                 int n_seg, const float* hyper /* device: lr,mom,beta2,wd,t */);
+int e2_sgd_step(e2_ctx*, float* p, const float* g, float* d, size_t n,
+                const int64_t* seg_off, const float* seg_reg, int n_seg,
+                const float* hyper /* device: lr,mom,_,wd,_ */);
+
+/* ---- step capture (replaces theano.function, graphutils.py:376-387) ---- */
+typedef struct e2_graph e2_graph;
+int e2_graph_begin(e2_ctx*);                 /* hipStreamBeginCapture      */
+int e2_graph_end(e2_ctx*, e2_graph** out);   /* EndCapture + Instantiate   */
+int e2_graph_launch(e2_ctx*, e2_graph*);     /* hipGraphLaunch on the stream*/
+int e2_graph_destroy(e2_graph*);
+
+/* ---- timing helpers (HIP events on the context's stream) -------------- */
+typedef struct e2_event e2_event;
+int e2_event_create(e2_event** out);
+int e2_event_record(e2_ctx*, e2_event*);
+int e2_event_elapsed_ms(e2_event* start, e2_event* stop, float* ms); /* syncs stop */
+int e2_event_destroy(e2_event*);
+int e2_stream_synchronize(e2_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2HIP_H */

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """The HIP context.  Fails loudly (no fallback) if the library or GPU is absent."""
+    import torch
+    from elektronn2_amd import backend
+    assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
+    return backend.Context(0)
