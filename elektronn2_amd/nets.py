@@ -1,0 +1,64 @@
+"""The reference example networks, built through the neuromancer-shaped API.
+``create_model`` bodies follow examples/neuro3d_lite.py:46-75,
+examples/neuro3d.py:46-76, examples/unet3d_lite.py:59-118 line by line (only
+the import differs)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def neuro3d_lite(in_sh=(None, 1, 23, 183, 183), params=None, name=None):
+    from . import neuromancer as nm
+    if name is not None:
+        nm.model_manager.newmodel(name)
+    P = _pget(params)
+    inp = nm.Input(in_sh, 'b,f,z,x,y', name='raw')
+    out = nm.Conv(inp, 20, (1, 4, 4), (1, 2, 2), **P(0))
+    out = nm.Conv(out, 40, (3, 3, 3), (1, 2, 2), **P(1))
+    out = nm.Conv(out, 150, (2, 4, 4), (2, 1, 1), **P(2))
+    out = nm.Conv(out, 200, (1, 3, 3), **P(3))
+    out = nm.Conv(out, 200, (1, 3, 3), **P(4))
+    out = nm.Conv(out, 200, (1, 1, 1), **P(5))
+    out = nm.Conv(out, 2, (1, 1, 1), activation_func='lin', **P(6))
+    return _finish(nm, inp, out, name)
+
+
+def neuro3d(in_sh=(None, 1, 23, 185, 185), params=None, name=None):
+    from . import neuromancer as nm
+    if name is not None:
+        nm.model_manager.newmodel(name)
+    P = _pget(params)
+    inp = nm.Input(in_sh, 'b,f,z,x,y', name='raw')
+    out = nm.Conv(inp, 20, (1, 6, 6), (1, 2, 2), **P(0))
+    out = nm.Conv(out, 30, (1, 5, 5), (1, 2, 2), **P(1))
+    out = nm.Conv(out, 40, (1, 5, 5), **P(2))
+    out = nm.Conv(out, 80, (4, 4, 4), (2, 1, 1), **P(3))
+    out = nm.Conv(out, 100, (3, 4, 4), **P(4))
+    out = nm.Conv(out, 100, (3, 4, 4), **P(5))
+    out = nm.Conv(out, 150, (2, 4, 4), **P(6))
+    out = nm.Conv(out, 200, (1, 4, 4), **P(7))
+    out = nm.Conv(out, 200, (1, 4, 4), **P(8))
+    out = nm.Conv(out, 200, (1, 1, 1), **P(9))
+    out = nm.Conv(out, 2, (1, 1, 1), activation_func='lin', **P(10))
+    return _finish(nm, inp, out, name)
+
+
+def _pget(params):
+    def P(i):
+        if params is None:
+            return {}
+        w, b = params[i]
+        return dict(w=np.asarray(w, np.float32), b=np.asarray(b, np.float32))
+    return P
+
+
+def _finish(nm, inp, out, name):
+    probs = nm.Softmax(out)
+    target = nm.Input_like(probs, override_f=1, name='target')
+    loss_pix = nm.MultinoulliNLL(probs, target, target_is_sparse=True)
+    loss = nm.AggregateLoss(loss_pix, name='loss')
+    errors = nm.Errors(probs, target, target_is_sparse=True)
+    model = nm.model_manager.current if name is not None else nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, target_node=target, loss_node=loss,
+                          prediction_node=probs, prediction_ext=[loss, errors, probs])
+    return model

@@ -1,0 +1,229 @@
+"""Softmax / MultinoulliNLL / AggregateLoss / Errors with the reference's
+constructor signatures (elektronn2/neuromancer/loss.py:33-93, 141-351,
+693-826, 1279-1370).
+
+HIP execution covers the pattern every BASELINE config uses:
+``AggregateLoss(MultinoulliNLL(Softmax(lin-Conv), target, target_is_sparse=True))``
+which reduces to  loss = sum_labelled -log(p_target + 1e-5) / (n_labelled + 1e-5)
+(the pred.size / n_class / mean factors of loss.py:342-346,1357-1363 cancel).
+Class / example weights, masks, weakness, dense targets and n_indep > 1 are
+outside the hot path and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .graphutils import TaggedShape, floatX
+from .node_basic import Node, Sym
+from .variables import VariableParam
+
+__all__ = ['Softmax', 'MultinoulliNLL', 'AggregateLoss', 'Classification', 'Errors']
+
+EPS = 1e-5     # loss.py:30
+
+
+class Softmax(Node):
+    def __init__(self, parent, n_class='auto', n_indep=1, name="softmax", print_repr=True):
+        super(Softmax, self).__init__(parent, name, print_repr)
+        n_f = parent.shape['f']
+        if hasattr(parent, 'activation_func'):
+            if parent.activation_func != 'lin':
+                raise ValueError("The parent of a Softmax-node must have a "
+                                 "linear activation function.")
+        if n_class == 'auto':
+            if n_f % n_indep == 0:
+                n_class = n_f // n_indep
+            else:
+                raise ValueError("Cannot create %i-fold %i-class softmax from %i features."
+                                 % (n_indep, n_f // n_indep, n_f))
+        elif n_class * n_indep != n_f:
+            raise ValueError("Cannot create %i-fold %i-class softmax " % (n_indep, n_class))
+        if n_indep != 1:
+            raise NotImplementedError("n_indep > 1 is outside the HIP hot path")
+        self.n_class = n_class
+        self.n_indep = n_indep
+
+    def _calc_comp_cost(self):
+        self.computational_cost = self.parent.shape.stripnone_prod
+
+    def _plan_alloc(self, plan):
+        plan.alloc_out(self)
+        plan.scratch[self, 'stats'] = plan.zeros_flat(2)
+        plan.scratch[self, 'dummy_t'] = None
+
+    def _plan_fwd(self, plan):
+        # probs only; when an NLL node hangs on this softmax it re-runs the same
+        # kernel with the target and also fills the loss statistics.
+        if plan.scratch.get((self, 'fused_nll')):
+            return
+        t = plan.scratch.get((self, 'dummy_t'))
+        if t is None:
+            sh = list(plan.out_shape(self))
+            sh[1] = 1
+            t = plan.full(tuple(sh), -1.0)
+            plan.scratch[self, 'dummy_t'] = t
+        plan.ctx.softmax_nll_fwd(plan.out[self.parent], t, plan.out[self],
+                                 plan.scratch[self, 'stats'])
+
+    def _plan_bwd(self, plan):
+        if plan.scratch.get((self, 'fused_nll')):
+            return            # MultinoulliNLL wrote d(loss)/d(logits) directly
+        raise NotImplementedError("gradient through a bare Softmax node")
+
+
+class MultinoulliNLL(Node):
+    def __init__(self, pred, target, target_is_sparse=False, class_weights=None,
+                 example_weights=None, weakness=0, mask_class_labeled=None,
+                 mask_class_not_present=None, name="nll", print_repr=True):
+        super(MultinoulliNLL, self).__init__([pred, target], name, print_repr)
+        if not isinstance(pred, Softmax):
+            raise ValueError("The prob input to a MultinoulliNLL-node must be "
+                             "a Softmax-Node.")
+        if (class_weights is not None or example_weights is not None or weakness or
+                mask_class_labeled is not None or mask_class_not_present is not None):
+            raise NotImplementedError("class/example weights, masks and weak training "
+                                      "are outside the HIP hot path")
+        if not target_is_sparse:
+            raise NotImplementedError("dense (one-hot) targets are outside the HIP hot path")
+        self.target = target
+        self.pred = pred
+        self.axis = pred.shape.tag2index('f')
+        self.n_class = pred.n_class
+        self.n_indep = pred.n_indep
+        self.target_is_sparse = target_is_sparse
+        self.class_weights = None
+        self.example_weights = None
+        self.weakness = 0
+
+    def _calc_shape(self):
+        self.shape = self.parent[0].shape.updateshape(self.axis, 1)
+
+    def _calc_comp_cost(self):
+        self.computational_cost = self.parent[0].shape.stripnone_prod
+
+    def _plan_alloc(self, plan):
+        plan.scratch[self.pred, 'fused_nll'] = True
+        plan.scratch[self, 'loss'] = plan.zeros_flat(1)
+        plan.out[self] = None        # the element-wise nll array is never materialised
+
+    def _plan_fwd(self, plan):
+        stats = plan.scratch[self.pred, 'stats']
+        plan.ctx.fill(stats, 0.0)
+        plan.ctx.softmax_nll_fwd(plan.out[self.pred.parent], plan.out[self.target],
+                                 plan.out[self.pred], stats)
+
+    def _plan_bwd(self, plan):
+        logits = self.pred.parent
+        dst, first = plan.grad_slot(logits)
+        if not first:
+            raise NotImplementedError("logits consumed by several nodes")
+        plan.ctx.softmax_nll_bwd(plan.out[self.pred], plan.out[self.target],
+                                 plan.scratch[self.pred, 'stats'], dst,
+                                 plan.scratch[self, 'loss'])
+
+    def loss_value(self, plan):
+        """device scalar: loss_sum / (n_labelled + EPS)."""
+        s = plan.scratch[self.pred, 'stats']
+        return s[0] / (s[1] + EPS)
+
+
+class AggregateLoss(Node):
+    def __init__(self, parent_nodes, mixing_weights=None, name="total_loss", print_repr=True):
+        if not isinstance(parent_nodes, (tuple, list)):
+            parent_nodes = [parent_nodes, ]
+        super(AggregateLoss, self).__init__(parent_nodes, name, print_repr)
+        if mixing_weights is None:
+            mixing_weights = np.ones(len(parent_nodes))
+        if isinstance(mixing_weights, (tuple, list, np.ndarray)):
+            if len(parent_nodes) != len(mixing_weights):
+                raise ValueError("Mismatch: len(parent_nodes)=%i, len(weights)=%i"
+                                 % (len(parent_nodes), len(mixing_weights)))
+            mixing_weights = VariableParam(value=np.array(mixing_weights, dtype=floatX),
+                                           name="loss_mixing_weights", dtype=floatX,
+                                           apply_train=False)
+        else:
+            raise ValueError("Unsupported weight format")
+        self.params['mixing_weights'] = mixing_weights
+        self.mixing_weights = mixing_weights
+        if len(parent_nodes) != 1 or not isinstance(parent_nodes[0], MultinoulliNLL):
+            raise NotImplementedError("the HIP hot path aggregates exactly one "
+                                      "MultinoulliNLL loss")
+
+    def _calc_shape(self):
+        self.shape = TaggedShape([1, ], ['f', ])
+
+    def _calc_comp_cost(self):
+        self.computational_cost = np.sum([inp.shape.stripnone_prod for inp in self.parent])
+
+    def _plan_alloc(self, plan):
+        plan.out[self] = None
+
+    def _plan_fwd(self, plan):
+        pass
+
+    def _plan_bwd(self, plan):
+        pass          # d(total)/d(nll) = mixing_weight(=1) / 1 ; folded into the NLL backward
+
+    def host_value(self, plan):
+        w = float(self.mixing_weights.get_value()[0])
+        return np.float32(float(self.parent[0].loss_value(plan).item()) * w)
+
+
+class Classification(Node):
+    def __init__(self, pred, n_class='auto', n_indep='auto', name="cls", print_repr=True):
+        super(Classification, self).__init__(pred, name, print_repr)
+        if not isinstance(pred, Softmax):
+            raise NotImplementedError("Classification of non-softmax predictions")
+        self.n_class = pred.n_class
+        self.n_indep = pred.n_indep
+        self.sm_input = True
+        self.pred = pred
+
+    def _calc_shape(self):
+        self.shape = self.parent.shape.updateshape(self.pred.shape.tag2index('f'),
+                                                   self.n_indep)
+
+    def _plan_alloc(self, plan):
+        plan.out[self] = None
+
+    def _plan_fwd(self, plan):
+        pass
+
+
+class _Errors(Node):
+    def __init__(self, cls, target, target_is_sparse=False, name="errors", print_repr=True):
+        super(_Errors, self).__init__([cls, target], name, print_repr)
+        self.n_class = cls.n_class
+        self.n_indep = cls.n_indep
+        self.target = target
+        self.cls = cls
+        self.target_is_sparse = target_is_sparse
+        if not target_is_sparse:
+            raise NotImplementedError("dense targets are outside the HIP hot path")
+
+    def _calc_shape(self):
+        self.shape = TaggedShape([1, ], ['f', ])
+
+    def _plan_alloc(self, plan):
+        plan.out[self] = None
+
+    def _plan_fwd(self, plan):
+        pass
+
+    def host_value(self, plan):
+        """mean(int16(target) != argmax_f(pred))  (loss.py:789-817); evaluated
+        with torch ops on the device tensors, outside any captured graph."""
+        import torch
+        probs = plan.out[self.cls.pred]
+        cls = torch.argmax(probs, dim=1, keepdim=True)
+        gt = plan.out[self.target].to(torch.int16).to(cls.dtype)
+        return np.float32((gt != cls).float().mean().item())
+
+
+def Errors(pred, target, target_is_sparse=False, n_class='auto', n_indep='auto',
+           name="errors", print_repr=True):
+    if not isinstance(pred, Classification):
+        pred = Classification(pred, n_class=n_class, n_indep=n_indep,
+                              name='cls for errors', print_repr=False)
+    return _Errors(pred, target, target_is_sparse=target_is_sparse, name=name,
+                   print_repr=print_repr)

@@ -1,0 +1,516 @@
+"""Conv / UpConv / Pool / Crop / AutoMerge nodes with the reference's
+constructor signatures, parameter initialisation and shape / stride / fov
+bookkeeping (elektronn2/neuromancer/neural.py), executing through libe2hip.so.
+
+  Conv      neural.py:500-859   conv -> max-pool -> +bias -> act   (F3 order)
+  UpConv    neural.py:907-1129  F2 closed form, identity_init
+  Crop      neural.py:1132-1190 zero-copy view
+  AutoMerge neural.py:1282-1407 (= UpConvMerge)
+  Pool      neural.py:1409-1559
+
+Outside the hot path and therefore rejected with NotImplementedError here:
+batch normalisation, dropout, MFP, gradnet, activations other than
+'relu' / 'lin', conv modes other than 'valid', 1-D/2-D convolutions.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+from .graphutils import floatX
+from .node_basic import Node, Concat, Add, Sym
+from .variables import VariableWeight, ConstantParam, VariableParam
+
+logger = logging.getLogger('elektronn2log')
+
+__all__ = ['Conv', 'UpConv', 'Pool', 'Crop', 'AutoMerge', 'UpConvMerge', 'NeuralLayer']
+
+_HIP_ACTS = ('relu', 'lin')
+
+
+class NeuralLayer(Node):
+    """Parameter plumbing shared by Conv / UpConv (neural.py:37-256)."""
+
+    def _register_param(self, param, shape, name, init_kwargs=None,
+                        apply_train=False, apply_reg=False):
+        add_to_params = True
+        if self.name == '':
+            p_name = '<%s%s>' % (name, tuple(shape))
+        else:
+            p_name = '<%s_%s%s>' % (self.name, name, tuple(shape))
+        if param is None:
+            p = VariableWeight(shape=shape, init_kwargs=init_kwargs, name=p_name,
+                               apply_train=apply_train, apply_reg=apply_reg)
+        elif isinstance(param, np.ndarray):
+            if param.shape != tuple(shape):
+                if not (param.ndim == 0 and tuple(shape) == (1,)):
+                    raise ValueError("Shape mismatch. Required %s, given %s"
+                                     % (shape, param.shape))
+            p = VariableWeight(value=param, name=p_name, apply_train=apply_train,
+                               apply_reg=apply_reg, dtype=floatX)
+        elif isinstance(param, (VariableParam, ConstantParam)):   # shared from elsewhere
+            if tuple(param.get_value().shape) != tuple(shape):
+                raise ValueError("Shape mismatch. Required %s, given %s"
+                                 % (shape, param.get_value().shape))
+            p = param
+            add_to_params = False
+        elif isinstance(param, (list, tuple)):
+            if not isinstance(param[0], np.ndarray) or param[1] not in ('const', 'trainable'):
+                raise ValueError("If a parameter is passed as a list, the first entry "
+                                 "must be an np.ndarray and the second 'const' or "
+                                 "'trainable'.")
+            if param[0].shape != tuple(shape):
+                raise ValueError("Shape mismatch. Required %s, given %s"
+                                 % (shape, param[0].shape))
+            value = np.ascontiguousarray(param[0], dtype=floatX)
+            if param[1] == 'const':
+                p = ConstantParam(value, p_name)
+            else:
+                p = VariableWeight(value=value, name=p_name, apply_train=True,
+                                   apply_reg=apply_reg)
+        else:
+            raise ValueError("Parameter %s must be either <np.ndarray>, a shared "
+                             "parameter, a tuple or None (to create new param)" % (name,))
+        setattr(self, name, p)
+        if add_to_params:
+            self.params[name] = p
+
+    def _setup_params(self, w_sh, w, b, gamma, mean, std, dropout_rate,
+                      pool_shape=None, gradnet_rate=None):
+        """neural.py:146-256 (BN / dropout / gradnet branches are out of scope)."""
+        from .. import config
+        self.w = None
+        mode = 'ortho' if config.use_ortho_init else 'normal'
+        w_init = dict(scale='glorot', mode=mode, pool=pool_shape,
+                      spatial_axes=self.spatial_axes)
+        self._register_param(w, w_sh, 'w', init_kwargs=w_init, apply_train=True,
+                             apply_reg=True)
+        act = self.activation_func
+        n_f = self.n_f
+        self.b = None
+        b_sh = (n_f,)
+        if act == 'relu' or act.startswith("maxout"):
+            norm = 1.0
+            if len(w_sh) > 2:
+                fov = 1
+                for i in self.spatial_axes:
+                    fov = fov * w_sh[i]
+                norm = fov
+            b_init = dict(scale=1.0 / norm, mode='const')
+        elif act == 'sigmoid':
+            b_init = dict(scale=0.5, mode='const')
+        elif act == 'prelu':
+            raise NotImplementedError("prelu is outside the HIP hot path")
+        else:
+            b_init = dict(scale=1e-6, mode='fix-uni')
+        self._register_param(b, b_sh, 'b', init_kwargs=b_init, apply_train=True,
+                             apply_reg=False)
+        if self.batch_normalisation:
+            raise NotImplementedError(
+                "batch_normalisation=%r: batch-norm is outside the 3-D HIP hot path "
+                "(SURVEY.md §8: mnist/CPU plumbing only)" % (self.batch_normalisation,))
+        self.gamma = self.mean = self.std = None
+        self.dropout_rate = None
+        if dropout_rate:
+            raise NotImplementedError("dropout is outside the HIP hot path")
+        self.gradnet_rate = None
+        if gradnet_rate:
+            raise NotImplementedError("gradnet is outside the HIP hot path")
+
+
+class Conv(NeuralLayer):
+    """Convolutional layer with subsequent pooling (neural.py:500-859).
+
+    Op order (F3): conv(true convolution, F1) -> max-pool -> + b -> activation.
+    """
+
+    def __init__(self, parent, n_f, filter_shape, pool_shape=None,
+                 conv_mode='valid', activation_func='relu',
+                 mfp=False, batch_normalisation=False, dropout_rate=0,
+                 name="conv", print_repr=True, w=None, b=None, gamma=None,
+                 mean=None, std=None, gradnet_mode=None, invalidate_fov=False):
+        Node.__init__(self, parent, name, print_repr)
+        self.n_f = n_f
+        self.filter_shape = tuple(filter_shape)
+        self.conv_mode = conv_mode
+        self.activation_func = activation_func
+        self.batch_normalisation = batch_normalisation
+        self.gradnet_mode = gradnet_mode
+        self.mfp = mfp
+        self.strides = parent.shape.strides
+        self.mfp_offsets = parent.shape.mfp_offsets
+        self.axis = parent.shape.tag2index('f')
+        self.axis_order = None
+        self.invalidate_fov = invalidate_fov
+        if pool_shape is None:
+            pool_shape = tuple([1 for _ in filter_shape])
+        self.pool_shape = tuple(int(p) for p in pool_shape)
+        self.spatial_axes = self.parent.shape.spatial_axes
+        conv_dim = len(self.spatial_axes)
+        x_dim = len(self.parent.shape)
+        if len(self.spatial_axes) != len(filter_shape) or \
+                len(filter_shape) != len(self.pool_shape):
+            raise ValueError("The filter_shape dimensionality (%i), the number "
+                             "of spatial dimensions in the input (%i) and "
+                             "the dimensionality of pool_shape (%i) differ! "
+                             "Use filter size 1 on axes which should not be "
+                             "convolved." % (len(filter_shape), conv_dim,
+                                             len(self.pool_shape)))
+        n_in = parent.shape['f']
+        fail = False
+        w_sh = None
+        if conv_dim in (1, 2):
+            raise NotImplementedError("Only 3-D convolutions run on the HIP hot path "
+                                      "(1-D/2-D are CPU plumbing in the reference "
+                                      "configs, SURVEY.md §8d)")
+        elif conv_dim == 3:
+            if x_dim != 5:
+                fail = True
+            if self.spatial_axes == [2, 3, 4]:
+                self.axis_order = 'dnn'
+                w_sh = [n_f, n_in] + list(filter_shape)
+            else:
+                fail = True
+        else:
+            fail = True
+        if fail:
+            raise NotImplementedError("Cannot convolve non-standard shapes / axis orders. "
+                                      "Implement reshaping before conv and "
+                                      "re-reshaping after!")
+        if conv_mode != 'valid':
+            raise NotImplementedError("conv_mode=%r: only 'valid' is on the HIP hot path"
+                                      % (conv_mode,))
+        if activation_func not in _HIP_ACTS:
+            raise NotImplementedError("activation_func=%r: only %s are on the HIP hot path"
+                                      % (activation_func, _HIP_ACTS))
+        if mfp:
+            raise NotImplementedError("MFP is a 'next' row (SURVEY.md §8f-3)")
+        self.conv_dim = conv_dim
+        self.w_sh = w_sh
+        self._setup_params(w_sh, w, b, gamma, mean, std, dropout_rate, self.pool_shape,
+                           1.0 if gradnet_mode else None)
+
+    def _make_output(self):
+        self.output = Sym(self, floatX)
+        self.strides = np.multiply(self.pool_shape, self.strides)
+
+    def _calc_shape(self):
+        """neural.py:725-764."""
+        sh = self.parent.shape
+        for j, (i, f, p) in enumerate(zip(self.spatial_axes, self.filter_shape,
+                                          self.pool_shape)):
+            k = 1 - f
+            s = (sh[i] + k) // p
+            if (sh[i] + k) % p != 0:
+                raise ValueError("Cannot pool spatial axis '%s' of length %i "
+                                 "by factor %i after convolving with "
+                                 "kernel of size %i." % (sh.tags[i], sh[i], p, f))
+            if s <= 0:
+                raise ValueError("Spatial axis '%s' of length %i is too small for "
+                                 "kernel %i" % (sh.tags[i], sh[i], f))
+            sh = sh.updateshape(i, s)
+            if sh.fov[j] > 0 and not self.invalidate_fov:
+                fov = sh.fov[j] + (f + p - 2) * sh.strides[j]
+            else:
+                fov = -1
+            sh = sh.updatefov(j, fov)
+        sh = sh.updatestrides(self.strides)
+        sh = sh.updateshape('f', self.n_f)
+        self.shape = sh
+
+    def _calc_comp_cost(self):
+        sh = self.parent.shape
+        n_position = 1
+        for i, f, p in zip(self.spatial_axes, self.filter_shape, self.pool_shape):
+            n_position *= sh[i] + 1 - f
+        b = 1 if sh['b'] is None else sh['b']
+        self.computational_cost = int(np.prod(self.w_sh)) * n_position * b
+
+    def __repr__(self):
+        s = Node.__repr__(self) + "\n"
+        s += "  n_f=%i, " % (self.n_f,)
+        s += "%id conv, kernel=%s, pool=%s, " % (self.conv_dim, self.filter_shape,
+                                                  self.pool_shape)
+        s += "act='%s', " % (self.activation_func,)
+        return s
+
+    def make_dual(self, parent, share_w=False, mfp=False, **kwargs):
+        """neural.py:780-846 (weight sharing is not supported here)."""
+        if share_w or mfp:
+            raise NotImplementedError("make_dual(share_w / mfp) is outside the hot path")
+        defaults = dict(activation_func=self.activation_func, name=self.name + '.T',
+                        print_repr=self._print_repr)
+        defaults.update(kwargs)
+        if self.w_sh[0] != parent.shape['f']:
+            raise ValueError("Cannot make dual layer: input features mismatch")
+        return UpConv(parent, self.parent.shape['f'], self.pool_shape, **defaults)
+
+    # ---- device execution ------------------------------------------------------------
+    def _plan_alloc(self, plan):
+        N = plan.batch
+        psp = self.parent.shape.spatial_shape
+        k = self.filter_shape
+        osp = [psp[i] - k[i] + 1 for i in range(3)]
+        plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
+        plan.alloc_out(self)
+        cin = self.parent.shape['f']
+        nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
+        plan.scratch[self, 'wp_f'] = plan.empty_flat(nb // 4 + 64)
+        if plan.training:
+            pad = [kk - 1 for kk in k]
+            dyp = plan.zeros((N, self.n_f) + tuple(osp[i] + 2 * pad[i] for i in range(3)))
+            plan.scratch[self, 'dy_pad'] = dyp
+            plan.scratch[self, 'dy'] = dyp[:, :, pad[0]:pad[0] + osp[0],
+                                           pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]]
+            if plan.needs_grad(self.parent):
+                plan.scratch[self, 'wp_d'] = plan.empty_flat(nb // 4 + 64)
+
+    def _plan_fwd(self, plan):
+        ctx = plan.ctx
+        x = plan.out[self.parent]
+        y = plan.scratch[self, 'y']
+        wp = plan.scratch[self, 'wp_f']
+        ctx.conv3d_pack(plan.param(self.w), 0, wp)
+        ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y)
+        ctx.pool_bias_act_fwd(y, plan.param(self.b), self.pool_shape, self.activation_func,
+                              plan.out[self])
+
+    def _plan_bwd(self, plan):
+        ctx = plan.ctx
+        x = plan.out[self.parent]
+        y = plan.scratch[self, 'y']
+        dy = plan.scratch[self, 'dy']
+        ctx.pool_bias_act_bwd(plan.grad[self], y, plan.param(self.b), self.pool_shape,
+                              self.activation_func, dy, plan.pgrad(self.b))
+        ctx.conv3d_wgrad(x, dy, plan.pgrad(self.w))
+        if plan.needs_grad(self.parent):
+            wp = plan.scratch[self, 'wp_d']
+            ctx.conv3d_pack(plan.param(self.w), 1, wp)
+            cin = self.parent.shape['f']
+            dst, first = plan.grad_slot(self.parent)
+            if first:
+                ctx.conv3d_dgrad_packed(plan.scratch[self, 'dy_pad'], wp, cin,
+                                        self.filter_shape, dst)
+            else:
+                tmp = plan.tmp_like(dst)
+                ctx.conv3d_dgrad_packed(plan.scratch[self, 'dy_pad'], wp, cin,
+                                        self.filter_shape, tmp)
+                ctx.copy5(tmp, dst, accumulate=True)
+
+
+class UpConv(Conv):
+    """Upconvolution / transposed convolution with stride = kernel = pool_shape
+    (neural.py:907-1129).  F2: y[n,co,p*i+r] = sum_ci w[co,ci,r] x[n,ci,i]."""
+
+    def __init__(self, parent, n_f, pool_shape, activation_func='relu',
+                 identity_init=True, batch_normalisation=False, dropout_rate=0,
+                 name="upconv", print_repr=True, w=None, b=None, gamma=None,
+                 mean=None, std=None, gradnet_mode=None):
+        pool_shape = tuple(int(p) for p in pool_shape)
+        Conv.__init__(self, parent, n_f, pool_shape, pool_shape, 'valid', activation_func,
+                      mfp=False, batch_normalisation=batch_normalisation,
+                      dropout_rate=dropout_rate, name=name, print_repr=print_repr,
+                      w=w, b=b, gamma=gamma, mean=mean, std=std, gradnet_mode=gradnet_mode)
+        if identity_init:          # neural.py:977-986
+            w_val = self.w.get_value() * 0.1
+            s = np.arange(np.minimum(w_val.shape[0], w_val.shape[1]))
+            w_val[s, s] = 1.0
+            self.w.set_value(w_val)
+            self.b.set_value(self.b.get_value() * 0.0)
+
+    def _make_output(self):
+        self.output = Sym(self, floatX)
+
+    def _calc_shape(self):
+        """neural.py:1074-1097."""
+        self.strides = np.divide(self.strides, self.pool_shape)
+        sh = self.parent.shape
+        for j, (i, f, p) in enumerate(zip(self.spatial_axes, self.filter_shape,
+                                          self.pool_shape)):
+            s = (sh[i] * p) + p - 1 + (1 - f)
+            sh = sh.updateshape(i, s)
+            sh = sh.updatefov(j, -1)
+        sh = sh.updateshape('f', self.n_f)
+        sh = sh.updatestrides(self.strides)
+        self.shape = sh
+
+    def _calc_comp_cost(self):
+        sh = self.parent.shape
+        n_position = 1
+        for i, f, p in zip(self.spatial_axes, self.filter_shape, self.pool_shape):
+            n_position *= (sh[i] * p) + 1 - f
+        b = 1 if sh['b'] is None else sh['b']
+        self.computational_cost = int(np.prod(self.w_sh)) * n_position * b
+
+    def make_dual(self, *args, **kwargs):
+        raise NotImplementedError("Use Conv instead?")
+
+    def _plan_alloc(self, plan):
+        plan.alloc_out(self)
+        xs = plan.out_shape(self.parent)
+        nb = plan.ctx.upconv_ws_bytes(self.n_f, self.parent.shape['f'], self.pool_shape, xs)
+        plan.scratch[self, 'ws'] = plan.empty_flat(nb // 4 + 64)
+
+    def _plan_fwd(self, plan):
+        plan.ctx.upconv3d_fwd(plan.out[self.parent], plan.param(self.w), plan.param(self.b),
+                              self.pool_shape, self.activation_func, plan.out[self],
+                              plan.scratch[self, 'ws'])
+
+    def _plan_bwd(self, plan):
+        ctx = plan.ctx
+        dx = None
+        first = True
+        if plan.needs_grad(self.parent):
+            dst, first = plan.grad_slot(self.parent)
+            dx = dst if first else plan.tmp_like(dst)
+        ctx.upconv3d_bwd(plan.out[self.parent], plan.param(self.w), plan.out[self],
+                         plan.grad[self], self.pool_shape, self.activation_func, dx,
+                         plan.pgrad(self.w), plan.pgrad(self.b), plan.scratch[self, 'ws'])
+        if dx is not None and not first:
+            ctx.copy5(dx, dst, accumulate=True)
+
+
+class Crop(Node):
+    """Symmetric spatial crop (neural.py:1132-1190): a zero-copy view."""
+
+    def __init__(self, parent, crop, name="crop", print_repr=True):
+        super(Crop, self).__init__(parent, name, print_repr)
+        self.crop = [int(c) for c in crop]
+
+    def _calc_shape(self):
+        sh = self.parent.shape.copy()
+        k = 0
+        for i, s in enumerate(self.parent.shape):
+            if i in self.parent.shape.spatial_axes:
+                sh = sh.updateshape(i, s - 2 * self.crop[k])
+                k += 1
+        self.shape = sh
+
+    def _calc_comp_cost(self):
+        self.computational_cost = 0
+
+    def _slicer(self):
+        sl = []
+        k = 0
+        for i, s in enumerate(self.parent.shape):
+            if i in self.parent.shape.spatial_axes:
+                off = self.crop[k]
+                sl.append(slice(off, s - off))
+                k += 1
+            else:
+                sl.append(slice(None))
+        return tuple(sl)
+
+    def _plan_alloc(self, plan):
+        plan.out[self] = plan.out[self.parent][self._slicer()]
+        if plan.training and plan.needs_grad(self):
+            plan.alloc_grad(self)
+
+    def _plan_fwd(self, plan):
+        pass
+
+    def _plan_bwd(self, plan):
+        plan.add_grad_region(self.parent, self._slicer(), plan.grad[self])
+
+
+def AutoMerge(parent1, parent2, upconv_n_f=None, merge_mode='concat',
+              disable_upconv=False, upconv_kwargs=None, name='merge', print_repr=True):
+    """neural.py:1282-1405: align a low-res and a high-res branch by UpConv +
+    Crop, then Concat((lo_res, hi_res)) or Add."""
+    assert len(parent1.shape) == len(parent2.shape)
+    assert parent1.shape.spatial_axes == parent2.shape.spatial_axes
+    if any(np.array(parent2.shape.strides) // np.array(parent1.shape.strides) < 1):
+        lo_res, hi_res = parent1, parent2
+    else:
+        hi_res, lo_res = parent1, parent2
+    unpool = (np.array(lo_res.shape.strides) // np.array(hi_res.shape.strides)).astype(int)
+    if np.any(unpool > 1) and not disable_upconv:
+        if upconv_n_f is None:
+            raise ValueError('AutoMerge is trying to insert an UpConv node, but '
+                             'upconv_n_f is not defined. Please set it to the '
+                             'desired number of features to be used for UpConv.')
+        if upconv_kwargs is None:
+            upconv_kwargs = {}
+        lo_res = UpConv(lo_res, upconv_n_f, tuple(int(u) for u in unpool), **upconv_kwargs)
+    sh_hi = hi_res.shape.spatial_shape
+    sh_lo = lo_res.shape.spatial_shape
+    crop_lo, crop_hi = [], []
+    for i in range(len(sh_hi)):
+        diff = sh_hi[i] - sh_lo[i]
+        if diff % 2 != 0:
+            raise ValueError("hi_res and lo_res maps cannot be aligned with "
+                             "shapes:\n%s\n%s" % (sh_hi, sh_lo))
+        if diff > 0:
+            crop_hi.append(diff // 2)
+            crop_lo.append(0)
+        else:
+            crop_lo.append(-diff // 2)
+            crop_hi.append(0)
+    if np.any(crop_lo):
+        lo_res = Crop(lo_res, crop_lo, print_repr=print_repr)
+    if np.any(crop_hi):
+        hi_res = Crop(hi_res, crop_hi, print_repr=print_repr)
+    if merge_mode == 'concat':
+        return Concat((lo_res, hi_res), axis='f', name=name, print_repr=print_repr)
+    elif merge_mode == 'add':
+        return Add(lo_res, hi_res, name=name, print_repr=print_repr)
+    raise ValueError('Invalid "merge_mode". Should be "add" or "concat".')
+
+
+UpConvMerge = AutoMerge
+
+
+class Pool(Node):
+    """Max-pooling node (neural.py:1409-1559)."""
+
+    def __init__(self, parent, pool_shape, stride=None, mfp=False, mode='max',
+                 name="pool", print_repr=True):
+        super(Pool, self).__init__(parent, name, print_repr)
+        if mfp:
+            raise NotImplementedError("MFP is a 'next' row (SURVEY.md §8f-3)")
+        if stride is not None and tuple(stride) != tuple(pool_shape):
+            raise NotImplementedError("Stride!=Pool using 3d pooling")   # computations.py:612
+        if mode != 'max':
+            raise NotImplementedError("Pooling mode %r needs cuDNN in the reference; "
+                                      "only 'max' is on the hot path" % (mode,))
+        self.pool_shape = tuple(int(p) for p in pool_shape)
+        self.pool_stride = self.pool_shape
+        self.mfp = False
+        self.mode = mode
+        self.strides = parent.shape.strides
+        self.axis = parent.shape.tag2index('f')
+        spatial_axes = self.parent.shape.spatial_axes
+        if len(pool_shape) != 3 or len(self.parent.shape) != 5 or spatial_axes != [2, 3, 4]:
+            raise NotImplementedError("Cannot pool non-standard shapes / axis orders "
+                                      "on the HIP hot path.")
+        self.spatial_axes = spatial_axes
+        self.conv_dim = 3
+
+    def _make_output(self):
+        self.output = Sym(self, floatX)
+        self.strides = np.multiply(self.pool_stride, self.strides)
+
+    def _calc_shape(self):
+        sh = self.parent.shape
+        for j, (i, p, st) in enumerate(zip(self.spatial_axes, self.pool_shape,
+                                           self.pool_stride)):
+            tmp = sh[i] - p + st - 1
+            s = tmp // st + 1
+            if (tmp + 1) % st != 0:
+                raise ValueError("Cannot downsample spatial axis '%s' of length %i "
+                                 "by factor %i with pool %i." % (sh.tags[i], sh[i], st, p))
+            sh = sh.updateshape(i, s)
+            fov = sh.fov[j] + (p - 1) * sh.strides[j] if sh.fov[j] > 0 else -1
+            sh = sh.updatefov(j, fov)
+        self.shape = sh.updatestrides(self.strides)
+
+    def _plan_fwd(self, plan):
+        plan.ctx.maxpool3d_fwd(plan.out[self.parent], self.pool_shape, plan.out[self])
+
+    def _plan_bwd(self, plan):
+        if not plan.needs_grad(self.parent):
+            return
+        dst, first = plan.grad_slot(self.parent)
+        plan.ctx.maxpool3d_bwd(plan.grad[self], plan.out[self.parent], self.pool_shape, dst,
+                               accumulate=not first)

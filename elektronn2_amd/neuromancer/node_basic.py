@@ -1,0 +1,479 @@
+"""Node protocol, model registry and the structural nodes.
+
+Mirrors elektronn2/neuromancer/node_basic.py: ``ModelContainer`` /
+``model_manager`` (:52-156), ``choose_name`` (:160-196), automatic
+registration of every node in the current model (``MetaNode`` :200-302),
+``Node`` (:307-574 -- ``_make_output/_calc_shape/_calc_comp_cost``, ``params``,
+``shape``, callable on numpy arrays), ``Input`` (:1182-1243), ``Input_like``
+(:1246-1271), ``Concat`` (:1403-1451), ``Add`` (:1455-1483).
+
+There is no symbolic tensor engine here: ``node.output`` is a small ``Sym``
+handle (dtype + owner) and the numerics run through a static launch plan
+(``plan.py``) over libe2hip.so.  Each node contributes ``_plan_fwd`` /
+``_plan_bwd`` hooks instead of a Theano expression.
+"""
+from __future__ import annotations
+
+import inspect
+import logging
+import re
+import uuid
+from collections import OrderedDict
+from functools import reduce
+
+import numpy as np
+
+from . import graphutils
+from .graphutils import TaggedShape, floatX
+
+logger = logging.getLogger('elektronn2log')
+
+__all__ = ['Node', 'Input', 'Input_like', 'Concat', 'Add', 'model_manager',
+           'choose_name', 'Sym']
+
+
+class Sym(object):
+    """Stand-in for the Theano variable a node's ``output`` used to be."""
+
+    def __init__(self, owner, dtype=floatX):
+        self.owner = owner
+        self.dtype = dtype
+        self.ndim = None
+
+    def __repr__(self):
+        return "<Sym of %s (%s)>" % (getattr(self.owner, 'name', '?'), self.dtype)
+
+
+class ModelContainer(object):
+    """node_basic.py:52-153."""
+    _count = 0
+
+    def __init__(self):
+        if ModelContainer._count > 0:
+            raise RuntimeError("There may exist only one ModelContainer "
+                               "(which may contain several models)")
+        ModelContainer._count += 1
+        self._default_set = False
+        self.models = OrderedDict()
+        self.last = None
+        self.current = None
+
+    def __getitem__(self, item):
+        return self.models[item]
+
+    def __repr__(self):
+        return repr(list(self.models.keys()))
+
+    def setdefault(self):
+        if self._default_set:
+            raise RuntimeError("The default model has already been set.")
+        from .model import Model
+        self.models["default"] = Model(name="default")
+        self.current = self["default"]
+        self.last = self["default"]
+        self._default_set = True
+
+    def newmodel(self, name):
+        from .model import Model
+        if name in self.models:
+            raise ValueError("Model of the same name %s exists already." % (name,))
+        elif name is None:
+            name = str(uuid.uuid4())
+        self.models[name] = Model(name=name)
+        self.last = self.current
+        self.current = self[name]
+        return self[name]
+
+    def getmodel(self, *args):
+        if len(args) == 1:
+            current = self[args[0]]
+        elif len(args) == 0:
+            current = self["default"]
+        else:
+            raise ValueError("Either provide name or nothing!")
+        self.last = self.current
+        self.current = current
+        return current
+
+    def togglemodel(self):
+        self.last, self.current = self.current, self.last
+        return self.current
+
+    def reset(self):
+        """(new) forget all models -- lets tests build several graphs."""
+        self.models = OrderedDict()
+        self.last = self.current = None
+        self._default_set = False
+
+
+model_manager = ModelContainer()
+
+
+def choose_name(proposal, names):
+    """node_basic.py:160-196: "conv", "conv1", "conv2", ..."""
+    if proposal in names:
+        numbers = re.findall(r'(\d+)$', proposal)
+        if not len(numbers):
+            proposal = proposal + str(1)
+        while proposal in names:
+            proposal = re.sub(r'(\d+)$', lambda x: str(int(x.group(0)) + 1), proposal)
+    return proposal
+
+
+class MetaNode(type):
+    """Registers every node in ``model_manager.current`` under a unique name
+    BEFORE ``__init__`` runs, then finalises it (node_basic.py:230-300)."""
+
+    def __call__(cls, *args, **kwargs):
+        if model_manager.current is None:
+            model_manager.setdefault()
+        default_name = ''
+        try:
+            sig = inspect.signature(cls.__init__)
+            d = sig.parameters['name'].default
+            if isinstance(d, str):
+                default_name = d
+        except Exception:
+            pass
+        # positional ``name``?  find its index in the signature
+        try:
+            names = list(inspect.signature(cls.__init__).parameters)[1:]
+            if 'name' in names and len(args) > names.index('name'):
+                args = list(args)
+                kwargs['name'] = args.pop(names.index('name'))
+                args = tuple(args)
+        except Exception:
+            pass
+        name = kwargs.get('name', default_name)
+        name = choose_name(name, model_manager.current.node_descriptors.keys())
+        kwargs['name'] = name
+        node = cls.__new__(cls)
+        model_manager.current.register_node(node, name, args, kwargs)
+        node.__init__(*args, **kwargs)
+        node._finalize_init()
+        return node
+
+
+class Node(object, metaclass=MetaNode):
+    """Basic node (node_basic.py:307-574)."""
+
+    def __init__(self, parent, name="", print_repr=False):
+        self.parent = parent
+        self.children = OrderedDict()
+        self.name = name
+        self._features_names = None
+        self.params = OrderedDict()
+        self.computational_cost = 0
+        self.is_source = False
+        self.output = None
+        self.shape = None
+        self._output_func = None
+        self._debug_outputs = []
+        self._local_exec_time = None
+        self._total_exec_time = None
+        self._finalized = False
+        self._print_repr = print_repr
+
+    # ---- protocol ---------------------------------------------------------
+    def _make_output(self):
+        self.output = Sym(self, self._parents()[0].output.dtype if self._parents() else floatX)
+
+    def _calc_shape(self):
+        self.shape = self._parents()[0].shape.copy()
+
+    def _calc_comp_cost(self):
+        self.computational_cost = self._parents()[0].shape.stripnone_prod
+
+    def _parents(self):
+        if self.parent is None:
+            return []
+        if isinstance(self.parent, (list, tuple)):
+            return list(self.parent)
+        return [self.parent]
+
+    def _finalize_init(self):
+        if self._finalized:
+            return
+        self._make_output()
+        self._calc_shape()
+        self._calc_comp_cost()
+        for p in self._parents():
+            p._register_child(self)
+        self._output_func = graphutils.make_func(self.input_nodes, self, name=self.name)
+        if self._print_repr:
+            logger.info("-" * 87)
+            logger.info(self)
+        self._finalized = True
+
+    def _register_child(self, child):
+        self.children[child.name] = child
+
+    def __repr__(self):
+        if self.name == '':
+            s = "<%s-Node>\n" % (self.__class__.__name__,)
+        else:
+            s = "<%s-Node> '%s' \n" % (self.__class__.__name__, self.name)
+        s += '  '
+        if self.param_count > 0:
+            s += "#Params={0:,d} ".format(self.param_count)
+        if self.computational_cost > 0:
+            s += "Comp.Cost=%.3g, " % (float(self.computational_cost),)
+        s += "Out:%s" % (str(self.shape))
+        if len(self.input_nodes) > 1:
+            s += "\n  Order of sources=%s, " % (str([n.name for n in self.input_nodes]))
+        return s
+
+    def __call__(self, *args):
+        """Compute the node's output for numpy inputs (first call "compiles")."""
+        if len(args) != len(self.input_nodes):
+            raise TypeError("%s: %i inputs required, %i were given."
+                            % (self.name, len(self.input_nodes), len(args)))
+        try:
+            return self._output_func(*args)
+        except TypeError as e:
+            add_info = '\nShapes (required - given):\n'
+            for ni, ar in zip(self.input_nodes, args):
+                add_info += " %s %s\t%s %s\n" % (tuple(ni.shape.shape), ni.dtype,
+                                                 getattr(ar, 'shape', '?'),
+                                                 getattr(ar, 'dtype', '?'))
+            raise TypeError(str(e) + add_info)
+
+    # ---- parameters -------------------------------------------------------------
+    def get_param_values(self, skip_const=False):
+        p_dict = OrderedDict()
+        for k, v in self.params.items():
+            if v.constant and skip_const:
+                continue
+            p_dict[k] = v.get_value()
+        return p_dict
+
+    def set_param_values(self, value_dict, skip_const=False):
+        for k, v in value_dict.items():
+            if k not in self.params:
+                if k in ['gamma', 'std', 'mean']:
+                    continue
+                raise KeyError("Layer has no parameter %s" % (k,))
+            if self.params[k].constant:
+                if skip_const:
+                    continue
+                raise ValueError("Cannot set value of constant parameter %s in node %s"
+                                 % (k, self.name))
+            self.params[k].set_value(v)
+
+    # ---- graph queries --------------------------------------------------------------
+    @property
+    def all_parents(self):
+        parents = OrderedDict()
+        for node in self._parents():
+            parents.update(node.all_parents)
+        parents[self.name] = self
+        return parents
+
+    @property
+    def input_nodes(self):
+        return [n for n in self.all_parents.values() if n.is_source]
+
+    @property
+    def input_tensors(self):
+        return [s.output for s in self.input_nodes]
+
+    @property
+    def all_params(self):
+        p = OrderedDict()
+        for node in self.all_parents.values():
+            for k, v in node.params.items():
+                p[str(node.name) + '_' + k] = v
+        return p
+
+    @property
+    def all_trainable_params(self):
+        return OrderedDict((k, v) for k, v in self.all_params.items() if v.apply_train)
+
+    @property
+    def all_nontrainable_params(self):
+        return OrderedDict((k, v) for k, v in self.all_params.items() if not v.apply_train)
+
+    @property
+    def all_extra_updates(self):
+        return [p.updates for n in self.all_parents.values()
+                for p in n.params.values() if p.updates]
+
+    @property
+    def param_count(self):
+        return int(sum(int(np.prod(x.shape)) for x in self.params.values() if x.apply_train))
+
+    @property
+    def all_params_count(self):
+        return int(sum(int(np.prod(x.shape)) for x in self.all_trainable_params.values()))
+
+    @property
+    def all_computational_cost(self):
+        return reduce(lambda x, y: x + y.computational_cost, self.all_parents.values(), 0)
+
+    @property
+    def all_children(self):
+        children = OrderedDict()
+        for child in self.children.values():
+            children[child.name] = child
+            children.update(child.all_children)
+        return children
+
+    @property
+    def last_exec_time(self):
+        return self._output_func.last_exec_time
+
+    @property
+    def feature_names(self):
+        return self._features_names
+
+    @feature_names.setter
+    def feature_names(self, value):
+        if len(value) != self.shape['f']:
+            raise ValueError("Feature names must match feature count")
+        self._features_names = tuple(value)
+
+    # ---- self test (node_basic.py:1014-1063) -------------------------------------
+    def test_run(self, on_shape_mismatch='warn', debug_outputs=False, warmup=False):
+        """Random input, check computed vs declared shape, report MPix/s."""
+        import time
+        inp = []
+        for n in self.input_nodes:
+            sh = [1 if s is None else s for s in n.shape.shape]
+            inp.append(np.random.rand(*sh).astype(n.dtype) if 'float' in n.dtype
+                       else np.random.randint(0, 2, sh).astype(n.dtype))
+        if warmup:
+            self(*inp)
+        t0 = time.time()
+        y = self(*inp)
+        t = time.time() - t0
+        declared = [1 if s is None else s for s in self.shape.shape]
+        if list(y.shape) != list(declared):
+            msg = "Node %s: declared shape %s != computed %s" % (self.name, declared, y.shape)
+            if on_shape_mismatch == 'raise':
+                raise ValueError(msg)
+            logger.warning(msg)
+        n_out = float(np.prod(y.shape[-self.shape.ndim:])) if self.shape.ndim else 1.0
+        logger.info("Compute time %.4f s, %.3f MPix/s", t, n_out / max(t, 1e-9) / 1e6)
+        return y
+
+    # ---- plan hooks (device execution); overridden by compute nodes ----------------
+    def _plan_out_shape(self, batch):
+        return tuple(batch if s is None else s for s in self.shape.shape)
+
+    def _plan_alloc(self, plan):
+        plan.alloc_out(self)
+
+    def _plan_fwd(self, plan):
+        raise NotImplementedError("%s has no HIP forward" % self.__class__.__name__)
+
+    def _plan_bwd(self, plan):
+        raise NotImplementedError("%s has no HIP backward" % self.__class__.__name__)
+
+
+class Input(Node):
+    """Source node (node_basic.py:1182-1243)."""
+
+    def __init__(self, shape, tags, strides=None, fov=None, dtype=floatX,
+                 hardcoded_shape=False, name='input', print_repr=True):
+        super(Input, self).__init__(None, name, print_repr)
+        self.is_source = True
+        self._shape = TaggedShape(shape, tags, strides, fov=fov)
+        if not isinstance(dtype, str):
+            raise ValueError("dtype must be a string.")
+        self.dtype = dtype
+        self.hardcoded_shape = hardcoded_shape
+        self._local_exec_time = 0
+
+    def _make_output(self):
+        self.output = Sym(self, self.dtype)
+
+    def _calc_shape(self):
+        self.shape = self._shape
+
+    def _calc_comp_cost(self):
+        self.computational_cost = 0
+
+    def _plan_fwd(self, plan):
+        pass
+
+    def _plan_bwd(self, plan):
+        pass
+
+
+def Input_like(ref, dtype=None, name='input', print_repr=True, override_f=False,
+               hardcoded_shape=False):
+    """node_basic.py:1246-1271."""
+    if isinstance(ref, Node):
+        shape = list(ref.shape.shape)
+        tags = ref.shape.tags
+        strides = ref.shape.strides
+        fov = ref.shape.fov
+        if override_f:
+            shape[ref.shape.tag2index('f')] = override_f
+        if dtype is None:
+            dtype = ref.output.dtype
+    elif isinstance(ref, TaggedShape):
+        shape, tags, strides, fov = ref.shape, ref.tags, ref.strides, ref.fov
+        assert dtype is not None
+    else:
+        raise ValueError("ref must be Node or TaggedShape.")
+    return Input(shape, tags, strides, fov=fov, dtype=dtype, name=name,
+                 print_repr=print_repr, hardcoded_shape=hardcoded_shape)
+
+
+class Concat(Node):
+    """Channel concat (node_basic.py:1403-1451).  Device side: each parent's
+    output is copied into its channel slice of one buffer; the gradient of a
+    slice is a zero-copy view of the concat gradient."""
+
+    def __init__(self, parent_nodes, axis='f', name="concat", print_repr=True):
+        super(Concat, self).__init__(parent_nodes, name, print_repr)
+        if not isinstance(parent_nodes, (tuple, list)):
+            raise ValueError("Can only join list/tuple of nodes")
+        self.axis = (parent_nodes[0].shape.tag2index(axis) if isinstance(axis, str)
+                     else axis)
+
+    def _calc_shape(self):
+        joint = reduce(lambda x, y: x + y.shape[self.axis], self.parent, 0)
+        self.shape = self.parent[0].shape.updateshape(self.axis, joint)
+
+    def _calc_comp_cost(self):
+        self.computational_cost = 0
+
+    def _plan_fwd(self, plan):
+        if self.axis != 1:
+            raise NotImplementedError("HIP Concat only along the feature axis")
+        out = plan.out[self]
+        c0 = 0
+        for p in self.parent:
+            c = p.shape['f']
+            plan.ctx.copy5(plan.out[p], out[:, c0:c0 + c])
+            c0 += c
+
+    def _plan_bwd(self, plan):
+        g = plan.grad[self]
+        c0 = 0
+        for p in self.parent:
+            c = p.shape['f']
+            plan.add_grad(p, g[:, c0:c0 + c])
+            c0 += c
+
+
+class Add(Node):
+    """node_basic.py:1455-1483."""
+
+    def __init__(self, n1, n2, name="add", print_repr=True):
+        super(Add, self).__init__((n1, n2), name, print_repr)
+        assert list(n1.shape.shape) == list(n2.shape.shape)
+
+    def _calc_comp_cost(self):
+        self.computational_cost = 0
+
+    def _plan_fwd(self, plan):
+        out = plan.out[self]
+        plan.ctx.copy5(plan.out[self.parent[0]], out)
+        plan.ctx.copy5(plan.out[self.parent[1]], out, accumulate=True)
+
+    def _plan_bwd(self, plan):
+        for p in self.parent:
+            plan.add_grad(p, plan.grad[self])

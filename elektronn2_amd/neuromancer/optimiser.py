@@ -1,0 +1,184 @@
+"""SGD and Adam with the reference's update rules and globals
+(elektronn2/neuromancer/optimiser.py:19-129, 135-165, 273-334).
+
+``lr`` / ``mom`` / ``wd`` are CLASS-level parameters shared by all optimisers
+(optimiser.py:19-29); ``beta2`` belongs to Adam.  The update itself is one fused
+HIP launch over the model's flat parameter arena (``e2_adam_step`` /
+``e2_sgd_step``); the hyper-parameters live in a small device array that is
+refreshed from the host values before every step, so learning-rate schedules
+work under hipGraph replay.  Adam's step counter ``t`` and bias factor are kept
+on the device.  The 3-deep parameter rotation for ``repair()``
+(optimiser.py:103-118) is not kept (its only call site is commented out in the
+reference, trainer.py:207).  AdaGrad / AdaDelta: not used by any BASELINE config.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import graphutils
+from .variables import VariableParam
+
+__all__ = ['Optimiser', 'SGD', 'Adam']
+
+
+class Optimiser(object):
+    global_lr = VariableParam(value=1, name='lr', dtype=graphutils.floatX)
+    global_weight_decay = VariableParam(value=0, name='weight_decay', dtype=graphutils.floatX)
+    global_mom = VariableParam(value=0.9, name='mom', dtype=graphutils.floatX)
+
+    @classmethod
+    def setlr(cls, val):
+        cls.global_lr.set_value(graphutils.as_floatX(val))
+
+    @classmethod
+    def setwd(cls, val):
+        cls.global_weight_decay.set_value(graphutils.as_floatX(val))
+
+    @classmethod
+    def setmom(cls, val):
+        cls.global_mom.set_value(graphutils.as_floatX(val))
+
+    step_name = None
+
+    def __init__(self, inputs, loss, params, additional_outputs, model):
+        self.meta_params = dict(lr=self.global_lr, mom=self.global_mom,
+                                wd=self.global_weight_decay)
+        self.input = inputs
+        self.output = [loss] + list(additional_outputs or [])
+        self.loss = loss
+        self.params = params
+        self.model = model
+        self.last_exec_time = None
+        self._hyper = None
+        self._hyper_host = None
+        self.step = graphutils.make_func(self.input, self.output, name='%s step' % self.step_name,
+                                         model=model, step=self.step_name)
+
+    def set_opt_meta_params(self, value_dict):
+        for k, v in value_dict.items():
+            try:
+                self.meta_params[k].set_value(graphutils.as_floatX(v))
+            except KeyError:
+                raise AttributeError("optimiser has no meta parameter %r" % (k,))
+
+    def _beta2(self):
+        return 0.0
+
+    def _sync_hyper(self, plan):
+        """refresh {lr, mom, beta2, wd} on the device when the host values changed."""
+        import torch
+        vals = (float(self.global_lr.get_value()), float(self.global_mom.get_value()),
+                float(self._beta2()), float(self.global_weight_decay.get_value()))
+        if self._hyper is None:
+            self._hyper = torch.zeros(8, dtype=torch.float32, device=plan.ctx.device)
+        if vals != self._hyper_host:
+            self._hyper[:4].copy_(torch.tensor(vals, dtype=torch.float32))
+            self._hyper_host = vals
+
+    def __call__(self, *args):
+        """[data (,labels ...)] -> [loss (, additional outputs ...)]"""
+        if self.step.func is None:
+            self.step.compile()
+        plan = self.step.func
+        plan.set_inputs(args)           # builds the plan (and the arena) on first use
+        import torch
+        with torch.cuda.stream(plan.stream):
+            self._ensure_state(plan)
+            self._sync_hyper(plan)
+        plan.run()
+        ret = list(plan.fetch())
+        ret[0] = graphutils.as_floatX(ret[0])
+        self.last_exec_time = plan.last_device_time
+        self.step.last_exec_time = plan.last_device_time
+        return ret
+
+    # subclasses
+    def _ensure_state(self, plan):
+        raise NotImplementedError
+
+    def device_update(self, plan):
+        raise NotImplementedError
+
+    def state_dict(self):
+        return {}
+
+    def load_state_dict(self, d):
+        pass
+
+
+class SGD(Optimiser):
+    """d' = g + mom*d ; p' = p - lr*(d' + wd*p [*apply_reg])  (optimiser.py:146-160)."""
+    step_name = 'SGD'
+
+    def __init__(self, *a):
+        self.last_dir = None
+        super(SGD, self).__init__(*a)
+
+    def _ensure_state(self, plan):
+        if self.last_dir is None:
+            self.last_dir = plan.zeros_flat(max(self.model.n_train, 4))
+
+    def device_update(self, plan):
+        m = self.model
+        plan.ctx.sgd_step(m.P[:m.n_train] if m.n_train < m.P.numel() else m.P, m.G,
+                          self.last_dir, m.seg_off, m.seg_reg, self._hyper)
+
+    def clear_last_dir(self):
+        if self.last_dir is not None:
+            self.last_dir.zero_()
+
+    def state_dict(self):
+        if self.last_dir is None:
+            return {}
+        return {'last_dir': self.last_dir.cpu().numpy()}
+
+    def load_state_dict(self, d):
+        if 'last_dir' in d and self.last_dir is not None:
+            import torch
+            self.last_dir.copy_(torch.from_numpy(d['last_dir']))
+
+
+class Adam(Optimiser):
+    """optimiser.py:273-334: eps = 1e-5 INSIDE the sqrt, bias factor
+    sqrt(1-beta2^t)/(1-mom^t), L2 term outside the adaptive scaling."""
+    step_name = 'Adam'
+
+    def __init__(self, *a):
+        self.beta2 = VariableParam(value=0.999, name='beta2', dtype=graphutils.floatX)
+        self.squared_accum = None
+        self.momentum = None
+        super(Adam, self).__init__(*a)
+        self.meta_params['beta2'] = self.beta2
+
+    def _beta2(self):
+        return self.beta2.get_value()
+
+    def _ensure_state(self, plan):
+        if self.momentum is None:
+            n = max(self.model.n_train, 4)
+            self.momentum = plan.zeros_flat(n)
+            self.squared_accum = plan.zeros_flat(n)
+
+    def device_update(self, plan):
+        m = self.model
+        plan.ctx.adam_step(m.P[:m.n_train] if m.n_train < m.P.numel() else m.P, m.G,
+                           self.momentum, self.squared_accum, m.seg_off, m.seg_reg,
+                           self._hyper)
+
+    @property
+    def t(self):
+        return 0.0 if self._hyper is None else float(self._hyper[4].item())
+
+    def state_dict(self):
+        if self.momentum is None:
+            return {}
+        return {'m': self.momentum.cpu().numpy(), 's': self.squared_accum.cpu().numpy(),
+                't': np.array(self.t)}
+
+    def load_state_dict(self, d):
+        import torch
+        if self.momentum is not None and 'm' in d:
+            self.momentum.copy_(torch.from_numpy(d['m']))
+            self.squared_accum.copy_(torch.from_numpy(d['s']))
+        if self._hyper is not None and 't' in d:
+            self._hyper[4] = float(d['t'])

@@ -1,0 +1,181 @@
+"""Parameter objects with the reference's protocol
+(elektronn2/neuromancer/variables.py:25-155): ``get_value()`` (copy),
+``set_value(ndarray)`` with shape check and optional float downcast, ``name``,
+``apply_train``, ``apply_reg``, ``constant``, ``updates``; and ``initweights``
+(variables.py:205-266).
+
+Storage: a parameter starts as a host numpy array.  When a plan is built the
+model binds it to a slice of the flat device arena (``bind``); from then on the
+device copy is authoritative and ``get_value`` reads it back.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .graphutils import floatX, as_floatX
+
+__all__ = ['VariableParam', 'VariableWeight', 'ConstantParam', 'initweights']
+
+
+class VariableParam(object):
+    def __init__(self, value=None, name=None, apply_train=True, apply_reg=True,
+                 dtype=None, **unused):
+        self.apply_reg = apply_reg
+        self.apply_train = apply_train
+        self._updates = None
+        self.constant = False
+        if not apply_train:
+            name = (name or '') + "_noTrain"
+        self.name = name
+        if isinstance(value, (int, float)):
+            value = np.array(value, dtype=dtype)
+        value = np.array(value, copy=True)
+        if dtype is not None:
+            value = value.astype(dtype)
+        self._host = value
+        self._dev = None          # torch view into the model's arena
+
+    # -- device binding -----------------------------------------------------
+    def bind(self, dev_view):
+        import torch
+        dev_view.copy_(torch.from_numpy(
+            np.ascontiguousarray(self._host, np.float32)).reshape(dev_view.shape))
+        self._dev = dev_view
+
+    @property
+    def dtype(self):
+        return self._host.dtype
+
+    @property
+    def shape(self):
+        return self._host.shape
+
+    def get_value(self, borrow=False):
+        if self._dev is not None:
+            self._host = self._dev.detach().cpu().numpy().reshape(
+                self._host.shape).astype(self._host.dtype)
+        return self._host.copy()
+
+    def set_value(self, new_value, borrow=False):
+        new_value = np.asarray(new_value)
+        if new_value.dtype != self._host.dtype:
+            new_value = new_value.astype(self._host.dtype)   # allow_floatX_downcast
+        if new_value.shape != self._host.shape:
+            new_value = np.broadcast_to(new_value, self._host.shape)
+        self._host = np.array(new_value, copy=True)
+        if self._dev is not None:
+            import torch
+            self._dev.copy_(torch.from_numpy(
+                np.ascontiguousarray(self._host, np.float32)).reshape(self._dev.shape))
+
+    @property
+    def updates(self):
+        return self._updates
+
+    @updates.setter
+    def updates(self, up):
+        if self.apply_train or self.apply_reg:
+            raise ValueError("Cannot register extra updates for trainable "
+                             "parameter %s" % (repr(self),))
+        self._updates = up
+
+    def __repr__(self):
+        return "<%s %s %s>" % (self.__class__.__name__, self.name, self._host.shape)
+
+
+class VariableWeight(VariableParam):
+    def __init__(self, shape=None, init_kwargs=None, value=None, name=None,
+                 apply_train=True, apply_reg=True, dtype=None, **unused):
+        if value is None:
+            if (shape is None) or (init_kwargs is None):
+                raise ValueError("shape and init_kwargs are required if value is None")
+            value = initweights(shape, **init_kwargs)
+        elif shape is not None:
+            if np.array(value).ndim > 1:
+                raise ValueError("If value and shape are specified, value must be scalar.")
+            value = np.ones(shape) * value
+        super(VariableWeight, self).__init__(value, name, apply_train, apply_reg, dtype)
+
+    def set_value(self, new_value, borrow=False):
+        sh = self._host.shape
+        if isinstance(new_value, np.ndarray):
+            if not (sh == new_value.shape):
+                raise NotImplementedError(
+                    "given shape: %s, required shape: %s Crop value or extend "
+                    "with similar numbers" % (new_value.shape, sh))
+        elif isinstance(new_value, (float, int)):
+            pass
+        else:
+            raise ValueError("Value/type not understood")
+        super(VariableWeight, self).set_value(as_floatX(new_value), borrow)
+
+
+class ConstantParam(object):
+    def __init__(self, value, name=None, dtype=None, **unused):
+        self.name = (name or '') + "_const"
+        if isinstance(value, (int, float)):
+            value = np.array(value, dtype=dtype)
+        if dtype is not None:
+            value = value.astype(dtype)
+        self.value = value
+        self.apply_train = False
+        self.apply_reg = False
+        self.constant = True
+        self._dev = None
+
+    def set_value(self, new_value, borrow=False):
+        raise RuntimeError("Cannot set value for ConstantParam")
+
+    def get_value(self, borrow=False):
+        return self.value
+
+    @property
+    def updates(self):
+        return None
+
+
+def initweights(shape, dtype=floatX, scale='glorot', mode='normal', pool=None,
+                spatial_axes=None):
+    """variables.py:205-266 -- uses the global ``np.random`` like the reference
+    (F8: nothing is seeded; tests seed np.random or inject ``w=``/``b=``)."""
+    if mode == 'const':
+        W = np.ones(shape) * scale
+    elif mode == 'prelu':
+        W = np.ones(shape) * scale
+        W[:, 1] = 1.0
+    elif mode == 'fix-uni':
+        W = np.random.uniform(-scale, scale, shape)
+    elif scale == 'glorot':
+        if len(shape) == 2:
+            n_in, n_out = shape[0], shape[1]
+            s = n_in + n_out
+        else:
+            assert spatial_axes is not None
+            other, kernel = [], []
+            for i, s in enumerate(shape):
+                (kernel if i in spatial_axes else other).append(s)
+            assert len(other) == 2
+            n_out, n_in = other[0], other[1]
+            s = (n_in + float(n_out) / np.prod(pool)) * np.prod(kernel)
+        W_scale = np.sqrt(2.0 / s)
+        if mode == 'normal':
+            W = np.random.normal(0, W_scale, shape)
+        elif mode == 'uni':
+            W = np.random.uniform(-W_scale, W_scale, shape)
+        elif mode == 'ortho':
+            M = np.random.normal(0, W_scale, size=shape).reshape((n_out, -1))
+            strip_required = False
+            n_in = M.shape[1]
+            if n_out > n_in:
+                M = np.random.normal(0, W_scale, size=(n_out, n_out))
+                strip_required = True
+            U, S, V = np.linalg.svd(M, full_matrices=False)
+            W = V / V.std(1)[:, None] * W_scale
+            if strip_required:
+                W = W[:, :n_in]
+            W = W.reshape(shape)
+        else:
+            raise ValueError("Invalid weigh initialisation parameters")
+    else:
+        raise ValueError("Invalid weigh initialisation parameters")
+    return np.ascontiguousarray(W, dtype=dtype)
