@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- training throughput of the hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C-lite@183"): the
+neuro3d_lite net on synthetic (1,1,23,183,183) fp32 volumes -> (1,2,10,37,37),
+one sample per GPU (weak scaling).  One "step" = forward + backward + (N>1: one
+RCCL all-reduce of the flat gradient arena) + the reference's Adam update, all
+inside the timed region, inputs already resident in HBM.
+
+metric = training INPUT voxels per second (the reference's own definition,
+training/trainer.py:283-284), whole job.  roofline: fp32-MFMA; achieved =
+algorithmic fwd+bwd FLOPs per step (118.29 GF for this
+workload) / mean step time measured with HIP events on the plan's stream.
+cpu_baseline: the torch-CPU fp32 port of the same step (oracle/torch_step.py)
+on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (builder, input spatial, algorithmic fwd+bwd GFLOP/step  [SURVEY.md §8d])
+    "lite183": ("neuro3d_lite", (23, 183, 183), 118.29),
+    "full185": ("neuro3d", (23, 185, 185), 119.02),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
+
+
+def algorithmic_gflop(spec, sp):
+    """2*MAC; wgrad = dgrad = fwd; no dgrad for the first layer."""
+    cin, tot = 1, 0.0
+    for li, (nf, k, p, _) in enumerate(spec):
+        osp = [sp[i] - k[i] + 1 for i in range(3)]
+        f = 2.0 * nf * cin * np.prod(k) * np.prod(osp)
+        tot += f * (3 if li > 0 else 2)
+        sp = [osp[i] // p[i] for i in range(3)]
+        cin = nf
+    return tot / 1e9
+
+
+def host_cores():
+    """CPU cores this process may actually use: cgroup quota if set, else the
+    affinity mask, capped at the GPU box's per-GPU CPU share (16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("E2_CPU_BASELINE_CORES", "16"))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    from elektronn2_amd import parallel, nets
+    from elektronn2_amd import neuromancer as nm
+    from oracle import e2_oracle as O        # spec tables + cpu_baseline leg only
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        parallel.init_from_env("nccl")
+    assert world == args.gpus or world == 1, "launch with torchrun for --gpus > 1"
+
+    builder, sp, gf_table = WORKLOADS[args.workload]
+    spec = O.NEURO3D_LITE if builder == "neuro3d_lite" else O.NEURO3D
+    gflop = algorithmic_gflop(spec, sp)
+    osp = O.net_out_shape(spec, sp)
+
+    # identical initial weights on every rank (seed 1), independent data per rank
+    params = O.init_net(spec, 1, seed=1)
+    model = getattr(nets, builder)((None, 1) + sp, params=params)
+    model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    opt = model.optimisers['Adam']
+    opt.step.compile()
+    plan = opt.step.func
+    plan.use_graph = not args.no_graph
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    rng = np.random.RandomState(parallel.rank_seed(0, rank))
+    n_batches = 4
+    xs = [torch.tensor(rng.rand(1, 1, *sp).astype(np.float32), device=dev)
+          for _ in range(n_batches)]
+    ts = [torch.tensor(rng.randint(0, 2, (1, 1) + osp).astype(np.float32), device=dev)
+          for _ in range(n_batches)]
+    plan.set_inputs([xs[0], ts[0]])          # builds plan + arena
+    if world > 1:
+        model.enable_data_parallel()
+    x_buf, t_buf = plan.input_buffer(plan.inputs[0]), plan.input_buffer(plan.inputs[1])
+
+    def one_step(i):
+        with torch.cuda.stream(plan.stream):
+            x_buf.copy_(xs[i % n_batches], non_blocking=True)
+            t_buf.copy_(ts[i % n_batches], non_blocking=True)
+            opt._ensure_state(plan)
+            opt._sync_hyper(plan)
+        plan.run()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ctx = plan.ctx
+    e0, e1 = ctx.event(), ctx.event()
+    old = ctx.stream
+    t0 = time.perf_counter()
+    ctx.set_stream(plan.stream); ctx.record(e0); ctx.set_stream(old)
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    ctx.set_stream(plan.stream); ctx.record(e1); ctx.set_stream(old)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev_ms = ctx.elapsed_ms(e0, e1) / args.steps
+    loss = float(plan.scratch[model.loss_node.parent[0], 'loss'].item())
+    assert np.isfinite(loss), "non-finite loss"
+
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank != 0:
+        return
+    vox_per_step = float(np.prod((1, 1) + sp)) * world
+    value = vox_per_step * args.steps / dt
+    achieved = gflop / (dev_ms * 1e-3) / 1e3            # TFLOP/s per GPU
+    out = {
+        "metric": "training_input_voxels_per_sec",
+        "value": value,
+        "unit": "voxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%s (1,1,%d,%d,%d)->(1,2,%d,%d,%d) fwd+bwd+Adam, 1 sample/GPU"
+                               % ((builder,) + tuple(sp) + tuple(osp)),
+                   "parallelism": "dp%d" % world,
+                   "output_voxels_per_sec": float(np.prod(osp)) * world * args.steps / dt,
+                   "hipgraph": bool(plan.use_graph), "final_loss": loss},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": None,
+                     "kernel": "training step (hipGraph): conv3d igemm fwd/dgrad/wgrad on "
+                               "v_mfma_f32_16x16x4_f32 + pointwise + Adam",
+                     "algorithmic_gflop_per_step": gflop,
+                     "device_ms_per_step": dev_ms},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_step as TS
+        cores = host_cores()
+        x = xs[0].cpu().numpy()
+        t = ts[0].cpu().numpy()
+        med, all_t = TS.time_cpu_step(spec, params, x, t, cores, warmup=1, steps=3)
+        out["cpu_baseline"] = {
+            "value": float(np.prod((1, 1) + sp)) / med, "unit": "voxels/s", "cores": cores,
+            "kind": "port",
+            "sample": "3 full training steps (median) of the same workload, torch-CPU fp32 "
+                      "(oneDNN) port of the reference step; Theano itself is not "
+                      "installable offline (BASELINE.md §3)",
+            "s_per_step": med,
+        }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -44,20 +44,54 @@ struct IgemmP {
   long isN, isC, isZ, isY;
   long osN, osC, osZ, osY;
   int ciP, coP;
-  int CC, log2CC;
-  int Lpad, BMpad;
+  int Lpad, CC;
   int nPT, nMT, splitK, nChunkC;
   int atomic;
   int upz, upy, upx;
+  int bufFloats;          // floats per LDS buffer (x region + w region + slack)
 };
 
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+// async global -> LDS copies (no VGPR destination); LDS address is
+// wave-uniform base + lane*size, the global source is per lane.
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 4, 0, 0);
+}
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 16, 0, 0);
+}
+
+// Scheduling pipeline for one k-step: R LDS reads (operands of the NEXT step)
+// spread evenly between the M MFMAs of the current step (cdna guide T19).
+template <int I, int R, int M>
+struct SchedStep {
+  static __device__ __forceinline__ void run() {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
+    constexpr int n = (M * (I + 1)) / R - (M * I) / R;
+    if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x008, n, 0);   // n MFMA
+    if constexpr (I + 1 < R) SchedStep<I + 1, R, M>::run();
+  }
+};
+
+constexpr int igemm_bmpad(int MT) {          // row stride == 16 (mod 32)
+  return ((16 * MT) & 31) == 16 ? 16 * MT : 16 * MT + 16;
+}
+
+// Pipeline: two LDS buffers.  While the MFMAs of chunk k run out of buffer
+// k&1, the LDS-DMA of chunk k+1 lands in the other one; one barrier per chunk
+// (wait vmcnt(0) -> barrier -> issue next DMA -> compute).  Inside a chunk the
+// A/B fragments of tap t+1 are fetched from LDS while the MFMAs of tap t issue.
 template <int MT, int NT>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xl = smem;
-  float* wl = smem + p.CC * p.Lpad;
   constexpr int BM = 16 * MT, BN = 64 * NT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int CC = p.CC, CG = p.CC >> 2;
+  constexpr int BMpad = igemm_bmpad(MT);
+  constexpr int BMp4 = BMpad / 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, qd = lane >> 4;
 
   int bid = blockIdx.x;
@@ -75,13 +109,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   const int isY = (int)p.isY;
   const long span_lo = (long)r0 * p.isY + c0;
   const int L = (rl - r0) * isY + (cl - c0) + (p.kh - 1) * isY + p.kw;
+  const int nJ = (L + 63) >> 6;
+  const int Lpad = p.Lpad;
+  const int xFloats = CC * Lpad;
 
   int posoff[NT];
 #pragma unroll
   for (int nb = 0; nb < NT; ++nb) {
     int q = min(q0 + wave * (16 * NT) + nb * 16 + l15, p.Q - 1);
     int r = q / p.Wo, c = q - r * p.Wo;
-    posoff[nb] = (r - r0) * isY + (c - c0) + qd * p.Lpad;
+    posoff[nb] = (r - r0) * isY + (c - c0) + qd * Lpad;
   }
 
   f32x4 acc[MT][NT];
@@ -93,61 +130,90 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   const int nChunks = p.kd * p.nChunkC;
   const int per = (nChunks + p.splitK - 1) / p.splitK;
   const int cb = ks * per, ce = min(cb + per, nChunks);
-  const int CC = p.CC;
-  const int aBase = qd * p.BMpad + l15;
+  const int aBase = qd * BMpad + l15;
+  const int nRows = p.THW * CC;
+  const int nPieces = (nRows * BMp4 + 63) >> 6;
+  const float* in_n = p.in + (long)n * p.isN + (long)z * p.isZ + span_lo;
 
-  for (int ch = cb; ch < ce; ++ch) {
+  auto stage = [&](int ch, int buf) {
     const int dz = ch / p.nChunkC;
     const int cc0 = (ch - dz * p.nChunkC) * CC;
-    // ---- stage the input spans: CC rows of L floats, coalesced ----------
-    const float* xb = p.in + (long)n * p.isN + (long)(z + dz) * p.isZ + span_lo;
+    float* xl = smem + buf * p.bufFloats;
+    float* wl = xl + xFloats;
+    const float* xb = in_n + (long)dz * p.isZ;
     for (int cc = wave; cc < CC; cc += 4) {
-      const int ci = cc0 + cc;
+      const int ci = min(cc0 + cc, p.Cin - 1);      // padded channels carry zero weights
       const float* src = xb + (long)ci * p.isC;
-      float* dst = xl + cc * p.Lpad;
-      if (ci < p.Cin) {
-        for (int u = lane; u < L; u += 64) dst[u] = src[u];
-      } else {
-        for (int u = lane; u < L; u += 64) dst[u] = 0.f;
-      }
+      float* dst = xl + cc * Lpad;
+      for (int j = 0; j < nJ; ++j) glds4(src + min(64 * j + lane, L - 1), dst + 64 * j);
     }
-    // ---- stage the packed weights: THW*CC rows of BM floats (float4) -----
-    {
-      const int total4 = p.THW * CC * (4 * MT);
-      for (int i = tid; i < total4; i += 256) {
-        const int rr = i / (4 * MT);
-        const int c4 = i - rr * (4 * MT);
-        const int t = rr >> p.log2CC;
-        const int cc = rr & (CC - 1);
-        const float* src = p.wp +
-            (((long)(dz * p.THW + t) * p.ciP + (cc0 + cc)) * p.coP + m0 + 4 * c4);
-        const float4 v = *reinterpret_cast<const float4*>(src);
-        *reinterpret_cast<float4*>(wl + rr * p.BMpad + 4 * c4) = v;
-      }
+    const float* wb = p.wp + ((long)dz * p.THW * p.ciP + cc0) * p.coP + m0;
+    for (int pc = wave; pc < nPieces; pc += 4) {
+      const int s = pc * 64 + lane;
+      int row = s / BMp4;
+      int c4 = s - row * BMp4;
+      row = min(row, nRows - 1);
+      c4 = min(c4, BM / 4 - 1);
+      const int t = row / CC, cc = row - t * CC;
+      glds16(wb + ((long)t * p.ciP + cc) * p.coP + 4 * c4, wl + pc * 256);
     }
+  };
+
+  if (cb < ce) stage(cb, 0);
+  for (int ch = cb; ch < ce; ++ch) {
+    const int cur = (ch - cb) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- MFMA over the chunk: K = THW taps x CC channels ------------------
-    int ty = 0, tx = 0;
-    for (int t = 0; t < p.THW; ++t) {
-      const int tapoff = ty * isY + tx;
-      for (int cg = 0; cg < (CC >> 2); ++cg) {
-        const float* ap = wl + (t * CC + 4 * cg) * p.BMpad + aBase;
-        const float* bp = xl + 4 * cg * p.Lpad + tapoff;
-        float a[MT], b[NT];
-#pragma unroll
-        for (int mb = 0; mb < MT; ++mb) a[mb] = ap[mb * 16];
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) b[nb] = bp[posoff[nb]];
-#pragma unroll
-        for (int mb = 0; mb < MT; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < NT; ++nb)
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                a[mb], b[nb], acc[mb][nb], 0, 0, 0);
-      }
-      if (++tx == p.kw) { tx = 0; ++ty; }
+    if (ch + 1 < ce) stage(ch + 1, cur ^ 1);
+    const float* xl = smem + cur * p.bufFloats;
+    const float* wl = xl + xFloats + aBase;
+
+    // k-steps of the chunk in (tap, channel-group) order: the A row offset
+    // advances linearly.  Two register sets ping-pong: the LDS reads of step
+    // s+1 are issued (unconditionally -- past the end they hit the slack) before
+    // the MFMAs of step s, so the compiler can wait with a COUNTED lgkmcnt.
+    const int nSteps = p.THW * CG;
+    int ty = 0, tx = 0, cg = 0, tapoff = 0;
+    const float* ap = wl;
+#define E2_ADVANCE()                                         \
+    {                                                        \
+      ap += 4 * BMpad;                                       \
+      ++cg;                                                  \
+      const int wc = (cg == CG) ? 1 : 0;                     \
+      cg = wc ? 0 : cg;                                      \
+      tx += wc;                                              \
+      const int wx = (tx == p.kw) ? 1 : 0;                   \
+      tx = wx ? 0 : tx;                                      \
+      ty += wx;                                              \
+      tapoff = ty * isY + tx;                                \
     }
-    __syncthreads();
+#define E2_LOAD(A, B)                                                       \
+    {                                                                       \
+      const float* bp = xl + 4 * cg * Lpad + tapoff;                        \
+      _Pragma("unroll") for (int mb = 0; mb < MT; ++mb) A[mb] = ap[mb * 16]; \
+      _Pragma("unroll") for (int nb = 0; nb < NT; ++nb) B[nb] = bp[posoff[nb]]; \
+    }
+#define E2_MFMA(A, B)                                                       \
+    _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                       \
+    _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                       \
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mb], B[nb], acc[mb][nb], 0, 0, 0);
+    float a0[MT], b0[NT], a1[MT], b1[NT];
+    E2_LOAD(a0, b0)
+    int st = 0;
+    for (; st + 1 < nSteps; st += 2) {
+      E2_ADVANCE()
+      E2_LOAD(a1, b1)
+      E2_MFMA(a0, b0)
+      E2_ADVANCE()
+      E2_LOAD(a0, b0)
+      E2_MFMA(a1, b1)
+      SchedStep<0, MT + NT, MT * NT>::run();
+      SchedStep<0, MT + NT, MT * NT>::run();
+    }
+    if (st < nSteps) { E2_MFMA(a0, b0) }
+#undef E2_ADVANCE
+#undef E2_LOAD
+#undef E2_MFMA
   }
 
   // ---- epilogue: D col = position (lane&15), row = channel 4*qd+reg -------
@@ -232,8 +298,9 @@ static const int kMTs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13};
 static int dispatch(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int grid, size_t lds) {
 #define E2_CASE(M)                                                          \
   case M:                                                                   \
-    return NT == 1 ? launch_one<M, 1>(ctx, p, grid, lds)                    \
-                   : launch_one<M, 2>(ctx, p, grid, lds);
+    if (NT == 1) return launch_one<M, 1>(ctx, p, grid, lds);                \
+    if (NT == 2) return launch_one<M, 2>(ctx, p, grid, lds);                \
+    break;
   switch (MT) {
     E2_CASE(1) E2_CASE(2) E2_CASE(3) E2_CASE(4) E2_CASE(5) E2_CASE(6)
     E2_CASE(7) E2_CASE(8) E2_CASE(10) E2_CASE(13)
@@ -251,13 +318,27 @@ static int pad16mod32(int v) {          // smallest s >= v with s % 32 == 16
 
 static int span_rows(int BN, int Wo) { return (BN + Wo - 2) / Wo; }
 
-// Pick the tiling.  Cost model: work-groups run 2 per CU; a work-group's time
-// is its MFMA count per wave (32 cycles each) plus a staging term.
+static int span_lmax(const IgemmArgs& a, int BN) {
+  return (span_rows(BN, a.Wo) + a.kh - 1) * (int)a.isY + a.kw + a.Wo;
+}
+// LDS-DMA writes whole 64-float pieces: rows must hold a multiple of 64
+static int span_lpad(const IgemmArgs& a, int BN) {
+  return pad16mod32(((span_lmax(a, BN) + 63) / 64) * 64);
+}
+static size_t buf_floats(const IgemmArgs& a, int MT, int BN, int CC) {
+  const int THW = a.kh * a.kw;
+  return (size_t)CC * span_lpad(a, BN) + (size_t)THW * CC * igemm_bmpad(MT) + 256 +
+         8 * (size_t)igemm_bmpad(MT);   // DMA piece slack + prefetch-past-the-end slack
+}
+
+// Pick the tiling.  Cost model (cycles): work-groups run 1 or 2 per CU
+// (LDS-limited); a work-group's time is its MFMA count per wave at 32 cycles,
+// stretched when two share the SIMDs, plus prologue/epilogue; split-K pays
+// the chip-wide fp32 atomic rate (1.3 TB/s) and a memset.
 static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   const int mblocks = e2_cdiv(a.Cout, 16);
   const int THW = a.kh * a.kw;
   const long Q = (long)a.Ho * a.Wo;
-  const int slots = ctx->num_cu * 2;
   IgemmCfg best{0, 0, 0, 0};
   double bestCost = 1e300;
   const char* force = getenv("E2_IGEMM_FORCE");
@@ -265,33 +346,37 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
     IgemmCfg f{0, 0, 0, 0};
     if (sscanf(force, "%d,%d,%d,%d", &f.MT, &f.NT, &f.CC, &f.SK) == 4) { *ok = 1; return f; }
   }
+  const double out_bytes = 4.0 * a.N * a.Cout * a.Do * (double)Q;
   for (int MT : kMTs) {
     if (MT > mblocks && MT != 1) continue;
     const int nMT = e2_cdiv(mblocks, MT);
     for (int NT = 1; NT <= 2; ++NT) {
       const int BN = 64 * NT;
       const int nPT = (int)((Q + BN - 1) / BN);
-      for (int CC = 8; CC >= 4; CC -= 4) {
-        if (CC == 8 && a.Cin <= 4) continue;
-        const int Lmax = (span_rows(BN, a.Wo) + a.kh - 1) * (int)a.isY + a.kw + a.Wo;
-        const int Lpad = pad16mod32(Lmax);
-        const int BMpad = pad16mod32(16 * MT);
-        const size_t lds = ((size_t)CC * Lpad + (size_t)THW * CC * BMpad) * 4;
-        if (lds > 72 * 1024) continue;
+      const int cinP = ((a.Cin + 3) / 4) * 4;
+      for (int CC = 4; CC <= 32 && CC <= cinP; CC += 4) {
+        if (CC > 4 && e2_cdiv(a.Cin, CC) == e2_cdiv(a.Cin, CC - 4)) continue;  // no fewer chunks
+        const size_t lds = 2 * buf_floats(a, MT, BN, CC) * 4;
+        if (lds > 160 * 1024) break;
+        const int perCU = lds <= 80 * 1024 ? 2 : 1;
+        const int slots = ctx->num_cu * perCU;
         const int nChunkC = e2_cdiv(a.Cin, CC);
         const int nChunks = a.kd * nChunkC;
         const long wgs0 = (long)a.N * a.Do * nPT * nMT;
+        const double chunk_bytes = 4.0 * (CC * (double)span_lmax(a, BN) + THW * CC * 16.0 * MT);
         for (int SK = 1; SK <= 8; SK *= 2) {
           if (SK > nChunks) break;
           const long wgs = wgs0 * SK;
           const int per = e2_cdiv(nChunks, SK);
-          const double mfma = (double)MT * NT * THW * (CC / 4) * per * 32.0;
-          const double stage = per * (CC * (double)Lmax / 256.0 * 6.0 +
-                                      THW * CC * 4.0 * MT / 256.0 * 8.0 + 600.0);
-          const double wg_time = mfma + stage + 1500.0 + (SK > 1 ? 400.0 : 0.0);
+          const double mfma = (double)MT * NT * THW * (CC / 4) * 32.0;      // per chunk
+          const double issue = (MT + 2.0 * NT + 6) * THW * (CC / 4) * 5.0;  // non-MFMA issue
+          double chunk = std::max(mfma, issue) * perCU * 1.05;
+          // the next chunk's DMA must land while this one computes
+          chunk = std::max(chunk, std::max(3500.0, chunk_bytes / 48.0 * perCU));
+          const double wg_time = per * chunk + 4500.0 + MT * NT * 16 * 6.0;
           const double rounds = (double)((wgs + slots - 1) / slots);
-          // two co-resident work-groups share the 4 SIMDs
-          const double cost = rounds * wg_time * 2.0;
+          double cost = rounds * wg_time;
+          if (SK > 1) cost += out_bytes * SK / 1.3e12 * 2.4e9 + out_bytes / 4e12 * 2.4e9 + 4000.0;
           if (cost < bestCost) { bestCost = cost; best = IgemmCfg{MT, NT, CC, SK}; }
         }
       }
@@ -302,7 +387,7 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
 }
 
 void e2i_pack_dims(int cout, int cin, int* ciP, int* coP) {
-  *ciP = ((cin + 7) / 8) * 8;
+  *ciP = ((cin + 3) / 4) * 4 + 32;        // any channel-chunk size up to 32+
   *coP = ((cout + 15) / 16) * 16 + 16 * 13;   // room for any MT tiling
 }
 
@@ -320,10 +405,12 @@ int e2i_pack_weights(e2_ctx* ctx, const float* w, float* wp, int Cout, int Cin,
 int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   E2_REQUIRE(a.Do > 0 && a.Ho > 0 && a.Wo > 0 && a.Cin > 0 && a.Cout > 0,
              "igemm: empty problem");
+  E2_REQUIRE(a.isY < (1 << 20), "igemm: input row stride too large");
   int ok = 0;
   IgemmCfg c = choose_cfg(ctx, a, &ok);
   E2_REQUIRE(ok, "igemm: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d W=%d)", a.Cin,
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
+  E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0, "igemm: CC must be a multiple of 4");
   IgemmP p;
   p.in = a.in; p.wp = a.wp; p.out = a.out;
   p.Cin = a.Cin; p.Cout = a.Cout; p.kd = a.kd; p.kh = a.kh; p.kw = a.kw;
@@ -332,27 +419,24 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   p.isN = a.isN; p.isC = a.isC; p.isZ = a.isZ; p.isY = a.isY;
   p.osN = a.osN; p.osC = a.osC; p.osZ = a.osZ; p.osY = a.osY;
   p.ciP = a.ciP; p.coP = a.coP;
-  p.CC = c.CC; p.log2CC = (c.CC == 8) ? 3 : 2;
   const int BN = 64 * c.NT;
-  const int Lmax = (span_rows(BN, a.Wo) + a.kh - 1) * (int)a.isY + a.kw + a.Wo;
-  p.Lpad = pad16mod32(Lmax);
-  p.BMpad = pad16mod32(16 * c.MT);
+  p.Lpad = span_lpad(a, BN);
+  p.CC = c.CC;
   p.nPT = e2_cdiv(p.Q, BN);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), c.MT);
   p.splitK = c.SK;
   p.nChunkC = e2_cdiv(a.Cin, c.CC);
   p.atomic = (c.SK > 1) ? 1 : 0;
   p.upz = a.upz; p.upy = a.upy; p.upx = a.upx;
+  p.bufFloats = (int)buf_floats(a, c.MT, BN, c.CC);
   E2_REQUIRE(p.nMT * 16 * c.MT <= a.coP, "igemm: packed coP too small");
   E2_REQUIRE(p.nChunkC * c.CC <= a.ciP, "igemm: packed ciP too small");
-  E2_REQUIRE(a.isY < (1 << 20), "igemm: input row stride too large");
-  const size_t lds = ((size_t)p.CC * p.Lpad + (size_t)p.THW * p.CC * p.BMpad) * 4;
+  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  E2_REQUIRE(lds <= 160 * 1024, "igemm: forced tiling needs %zu B of LDS", lds);
   const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
   E2_REQUIRE(grid < (1L << 31), "igemm: grid too large");
   if (p.atomic) {
-    // split-K accumulates: the caller-visible result must start from zero.
-    // Output views of this library are dense in (d,h,w) per channel in the
-    // fwd/dgrad use; zero row by row to stay correct for strided views.
+    // split-K accumulates with atomics: start from zero
     const int R = a.upz * a.upy * a.upx;
     const int oc = a.Cout / (R > 1 ? R : 1);
     const int od = a.Do * a.upz, oh = a.Ho * a.upy, ow = a.Wo * a.upx;

@@ -1,0 +1,90 @@
+"""CPU, world_size 2, gloo: the data-parallel exchange step -- one all-reduce
+(mean) of the flat gradient arena, then identical Adam updates on every rank
+(SURVEY.md §8e).  The arithmetic of the step is the torch-CPU port of the oracle;
+what is under test is elektronn2_amd.parallel and the replica invariants."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from oracle import e2_oracle as O
+from oracle import torch_step as TS
+
+SPEC = [(6, (1, 3, 3), (1, 2, 2), 'relu'), (8, (2, 3, 3), (1, 1, 1), 'relu'),
+        (2, (1, 1, 1), (1, 1, 1), 'lin')]
+SP = (4, 16, 16)
+
+
+def _data(rank):
+    from elektronn2_amd import parallel
+    rng = np.random.RandomState(parallel.rank_seed(0, rank))
+    x = rng.rand(1, 1, *SP).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(SPEC, SP)).astype(np.float32)
+    return torch.tensor(x), torch.tensor(t)
+
+
+def _flat_grads(net):
+    return torch.cat([p.grad.reshape(-1) for p in net.w + net.b])
+
+
+def _set_flat_grads(net, flat):
+    o = 0
+    for p in net.w + net.b:
+        n = p.numel()
+        p.grad = flat[o:o + n].view_as(p).clone()
+        o += n
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from elektronn2_amd import parallel
+    assert parallel.init_from_env("gloo") == world
+    net = TS.TorchNet(SPEC, O.init_net(SPEC, 1, seed=1))
+    x, t = _data(rank)
+    for _ in range(3):
+        net.loss_and_grads(x, t)
+        flat = _flat_grads(net)
+        parallel.allreduce_mean_(flat)
+        _set_flat_grads(net, flat)
+        net.adam()
+    q.put((rank, torch.cat([p.detach().reshape(-1) for p in net.w + net.b]).numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_allreduce_mean_keeps_replicas_identical():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=240) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(res[0], res[1]), "replicas diverged"
+    # single-process reference: average the two per-rank gradients by hand
+    torch.set_num_threads(1)
+    nets = [TS.TorchNet(SPEC, O.init_net(SPEC, 1, seed=1)) for _ in range(2)]
+    data = [_data(r) for r in range(2)]
+    for _ in range(3):
+        fl = []
+        for n, (x, t) in zip(nets, data):
+            n.loss_and_grads(x, t)
+            fl.append(_flat_grads(n))
+        mean = (fl[0] + fl[1]) * 0.5
+        for n in nets:
+            _set_flat_grads(n, mean)
+            n.adam()
+    ref = torch.cat([p.detach().reshape(-1) for p in nets[0].w + nets[0].b]).numpy()
+    assert np.abs(res[0] - ref).max() < 1e-6
+
+
+def test_rank_seeds_are_distinct_and_single_process_is_identity():
+    from elektronn2_amd import parallel
+    assert len({parallel.rank_seed(0, r) for r in range(8)}) == 8
+    t = torch.arange(4.0)
+    assert parallel.allreduce_mean_(t) is t and t.tolist() == [0, 1, 2, 3]

@@ -1,0 +1,132 @@
+"""CPU: the neuromancer-shaped front end -- shape / stride / fov bookkeeping,
+naming, parameter protocol, error behaviour -- against the numbers and rules
+recorded from the reference (neural.py:725-764)."""
+import numpy as np
+import pytest
+
+from elektronn2_amd import nets, neuromancer as nm
+
+
+@pytest.fixture(autouse=True)
+def fresh():
+    nm.model_manager.reset()
+    yield
+    nm.model_manager.reset()
+
+
+def test_neuro3d_lite_at_183_shapes_and_counts():
+    m = nets.neuro3d_lite()
+    pn = m.prediction_node
+    assert pn.shape.shape == [None, 2, 10, 37, 37]
+    assert list(pn.shape.strides) == [2, 4, 4]
+    assert pn.shape.fov == [5, 39, 39] and pn.shape.offsets == [2, 19, 19]
+    assert m.loss_node.all_params_count == 885132
+    assert list(m.nodes.keys())[:9] == ['raw', 'conv', 'conv1', 'conv2', 'conv3', 'conv4',
+                                       'conv5', 'conv6', 'softmax']
+    assert m.target_node.shape.shape == [None, 1, 10, 37, 37]
+    assert m.target_node.output.dtype == 'float32'       # cnndata.py:140 reads this
+    assert m.batch_size is None and m.ndim == 3
+    # comp cost = prod(w_sh) * n_positions * b  (neural.py:767-778)
+    assert m.nodes['conv1'].computational_cost == 40 * 20 * 27 * 21 * 88 * 88
+
+
+def test_neuro3d_needs_185_and_rejects_183():
+    m = nets.neuro3d()
+    assert m.prediction_node.shape.shape == [None, 2, 5, 21, 21]
+    assert m.prediction_node.shape.fov == [15, 105, 105]
+    assert m.loss_node.all_params_count == 2756042
+    nm.model_manager.reset()
+    with pytest.raises(ValueError, match="Cannot pool spatial axis"):
+        nets.neuro3d((None, 1, 23, 183, 183))
+
+
+def test_param_init_formulas_and_protocol():
+    np.random.seed(0)
+    inp = nm.Input((1, 4, 9, 20, 20), 'b,f,z,x,y')
+    c = nm.Conv(inp, 200, (2, 3, 3), (2, 1, 1))
+    w = c.w.get_value()
+    # glorot normal: std = sqrt(2 / ((n_in + n_out/prod(pool)) * prod(kernel)))
+    assert abs(w.std() - np.sqrt(2.0 / ((4 + 200 / 2.0) * 18))) / w.std() < 0.05
+    assert np.allclose(c.b.get_value(), 1.0 / 18)          # relu bias = 1/prod(kernel)
+    assert c.w.apply_reg is True and c.b.apply_reg is False and c.w.apply_train
+    lin = nm.Conv(c, 2, (1, 1, 1), activation_func='lin')
+    assert np.abs(lin.b.get_value()).max() <= 1e-6
+    with pytest.raises(NotImplementedError):
+        c.w.set_value(np.zeros((3, 3)))                    # variables.py:137-146
+    c.w.set_value(np.ones(w.shape))                        # float64 -> downcast
+    assert c.w.get_value().dtype == np.float32
+    wi = np.random.rand(7, 200, 1, 1, 1).astype(np.float32)
+    c2 = nm.Conv(c, 7, (1, 1, 1), w=wi, b=np.zeros(7, np.float32))
+    assert np.array_equal(c2.w.get_value(), wi)
+    with pytest.raises(ValueError, match="Shape mismatch"):
+        nm.Conv(c, 7, (1, 1, 1), w=np.zeros((7, 3, 1, 1, 1), np.float32))
+
+
+def test_error_behaviour_matches_reference():
+    inp = nm.Input((1, 1, 8, 20, 20), 'b,f,z,x,y')
+    with pytest.raises(ValueError, match="dimensionality"):
+        nm.Conv(inp, 4, (3, 3))
+    with pytest.raises(ValueError, match="Cannot pool"):
+        nm.Conv(inp, 4, (1, 3, 3), (1, 4, 4))
+    c = nm.Conv(inp, 4, (1, 3, 3))
+    with pytest.raises(ValueError, match="linear activation"):
+        nm.Softmax(c)
+    with pytest.raises(NotImplementedError):
+        nm.Pool(c, (1, 2, 2), stride=(1, 1, 1))
+    with pytest.raises(ValueError, match="Cannot downsample"):
+        nm.Pool(c, (1, 4, 4))
+    with pytest.raises(NotImplementedError):
+        nm.Conv(inp, 4, (1, 3, 3), batch_normalisation='train')
+    inp2 = nm.Input((1, 1, 20, 20), 'b,f,x,y')
+    with pytest.raises(NotImplementedError):
+        nm.Conv(inp2, 4, (3, 3))
+
+
+def test_upconvmerge_unet_bookkeeping():
+    """examples/unet3d_lite.py pattern: UpConv inserted for stride ratio > 1,
+    symmetric Crop of the high-res branch, Concat((lo_res upconv, hi_res))."""
+    inp = nm.Input((1, 1, 12, 36, 36), 'b,f,z,x,y', name='raw')
+    c1 = nm.Conv(nm.Conv(inp, 8, (1, 3, 3)), 8, (1, 3, 3))
+    p1 = nm.Pool(c1, (1, 2, 2))
+    c3 = nm.Conv(nm.Conv(p1, 16, (3, 3, 3)), 16, (3, 3, 3))
+    assert list(c3.shape.strides) == [1, 2, 2]
+    mrg = nm.UpConvMerge(c1, c3, 24)
+    assert isinstance(mrg, nm.Concat)
+    lo, hi = mrg.parent
+    assert isinstance(lo, nm.UpConv) and isinstance(hi, nm.Crop)
+    assert lo.pool_shape == (1, 2, 2) and lo.shape['f'] == 24
+    assert lo.shape.spatial_shape == hi.shape.spatial_shape == [8, 24, 24]
+    assert hi.crop == [2, 4, 4]
+    assert mrg.shape['f'] == 24 + 8
+    assert lo.shape.fov == [-1, -1, -1]
+    # identity_init (neural.py:977-986)
+    w = lo.w.get_value()
+    assert np.all(w[np.arange(16), np.arange(16)] == 1.0) and np.all(lo.b.get_value() == 0)
+    # designate_nodes repairs the fov of UpConv nets (model.py:141-152)
+    out = nm.Conv(nm.Conv(mrg, 8, (1, 3, 3)), 2, (1, 1, 1), activation_func='lin')
+    probs = nm.Softmax(out)
+    target = nm.Input_like(probs, override_f=1, name='target')
+    loss = nm.AggregateLoss(nm.MultinoulliNLL(probs, target, target_is_sparse=True))
+    model = nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, target_node=target, loss_node=loss,
+                          prediction_node=probs)
+    assert probs.shape.fov == [4, 14, 14] and target.shape.fov == [4, 14, 14]
+    assert set(model.optimisers) == {'SGD', 'Adam'}
+
+
+def test_optimiser_globals_are_shared():
+    m = nets.neuro3d_lite((None, 1, 7, 47, 47))
+    m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    assert abs(m.lr - 5e-4) < 1e-10 and abs(m.wd - 0.5e-4) < 1e-12
+    m.lr = 1e-3
+    assert abs(m.optimisers['SGD'].global_lr.get_value() - 1e-3) < 1e-10   # optimiser.py:19-29
+    with pytest.raises(AttributeError):
+        m.set_opt_meta_params('SGD', dict(beta2=0.5))
+
+
+def test_choose_name_and_call_arity():
+    assert nm.choose_name('conv', ['conv']) == 'conv1'
+    assert nm.choose_name('conv', ['conv', 'conv1', 'conv2']) == 'conv3'
+    m = nets.neuro3d_lite((None, 1, 7, 47, 47))
+    with pytest.raises(TypeError, match="inputs required"):
+        m.prediction_node()
