@@ -32,6 +32,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <algorithm>
+#include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -44,7 +45,8 @@ struct IgemmP {
   long isN, isC, isZ, isY;
   long osN, osC, osZ, osY;
   int ciP, coP;
-  int Lpad, CC;
+  int Lpad, CC, Din, N;
+  int dbg;                // timing ablations only (E2_IGEMM_DBG): 1 = stage once, 2 = no MFMA, 4 = no barrier
   int nPT, nMT, splitK, nChunkC;
   int atomic;
   int upz, upy, upx;
@@ -63,15 +65,39 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 16, 0, 0);
 }
 
-// Scheduling pipeline for one k-step: R LDS reads (operands of the NEXT step)
-// spread evenly between the M MFMAs of the current step (cdna guide T19).
-template <int I, int R, int M>
-struct SchedStep {
-  static __device__ __forceinline__ void run() {
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // 1 DS read
-    constexpr int n = (M * (I + 1)) / R - (M * I) / R;
-    if constexpr (n > 0) __builtin_amdgcn_sched_group_barrier(0x008, n, 0);   // n MFMA
-    if constexpr (I + 1 < R) SchedStep<I + 1, R, M>::run();
+// ds_read_b32 with an immediate offset, invisible to hipcc's waitcnt
+// bookkeeping: the kernel waits with its own "s_waitcnt lgkmcnt(0)" AFTER the
+// MFMAs of the previous group have been issued (cdna guide §5.7 form iii).
+template <int OFF>
+__device__ __forceinline__ float lds_ld(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(lds_vp)p;
+}
+// operands of one (cg,ty) group: KW taps x (MT weight blocks + NT position blocks)
+template <int MT, int NT, int KW, int ASTRIDE>
+struct GroupRegs {
+  float a[KW][MT];
+  float b[KW][NT];
+  template <int... I>
+  __device__ __forceinline__ void load_a(unsigned addr, std::integer_sequence<int, I...>) {
+    ((a[I / MT][I % MT] = lds_ld<(I / MT) * ASTRIDE + (I % MT) * 64>(addr)), ...);
+  }
+  template <int NB, int... I>
+  __device__ __forceinline__ void load_b1(unsigned addr, std::integer_sequence<int, I...>) {
+    ((b[I][NB] = lds_ld<I * 4>(addr)), ...);
+  }
+  template <int... NB>
+  __device__ __forceinline__ void load_b(const unsigned (&addr)[NT],
+                                         std::integer_sequence<int, NB...>) {
+    (load_b1<NB>(addr[NB], std::make_integer_sequence<int, KW>{}), ...);
+  }
+  __device__ __forceinline__ void load(unsigned addrA, const unsigned (&addrB)[NT]) {
+    load_a(addrA, std::make_integer_sequence<int, KW * MT>{});
+    load_b(addrB, std::make_integer_sequence<int, NT>{});
   }
 };
 
@@ -81,15 +107,24 @@ constexpr int igemm_bmpad(int MT) {          // row stride == 16 (mod 32)
 
 // Pipeline: two LDS buffers.  While the MFMAs of chunk k run out of buffer
 // k&1, the LDS-DMA of chunk k+1 lands in the other one; one barrier per chunk
-// (wait vmcnt(0) -> barrier -> issue next DMA -> compute).  Inside a chunk the
-// A/B fragments of tap t+1 are fetched from LDS while the MFMAs of tap t issue.
-template <int MT, int NT>
+// (wait vmcnt(0) -> barrier -> issue next DMA -> compute).
+//
+// K order inside a chunk: channel group cg (4 channels = the 4 lane quarters),
+// then tap row ty, then tap column tx.  The packed weight image and the LDS A
+// tile use the same order, so (a) the weight staging is a linear copy, (b) the
+// A rows of one (cg,ty) group are contiguous, and (c) with the kernel width KW
+// a template parameter the tx loop is fully unrolled: every LDS address of a
+// group is "loop-invariant VGPR + immediate", which keeps the scalar / vector
+// overhead per MFMA small (the matrix pipe, not instruction issue, must be the
+// limiter: rocprof showed 6 SALU + 4 VALU per MFMA in the first version).
+template <int MT, int NT, int KW>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = 16 * MT, BN = 64 * NT;
-  const int CC = p.CC, CG = p.CC >> 2;
   constexpr int BMpad = igemm_bmpad(MT);
   constexpr int BMp4 = BMpad / 4;
+  const int kw = KW > 0 ? KW : p.kw;
+  const int CC = p.CC, CG = p.CC >> 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, qd = lane >> 4;
@@ -110,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   const long span_lo = (long)r0 * p.isY + c0;
   const int L = (rl - r0) * isY + (cl - c0) + (p.kh - 1) * isY + p.kw;
   const int nJ = (L + 63) >> 6;
+  const int nJ16 = (L + 255) >> 8;
   const int Lpad = p.Lpad;
   const int xFloats = CC * Lpad;
 
@@ -137,25 +173,36 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
 
   auto stage = [&](int ch, int buf) {
     const int dz = ch / p.nChunkC;
-    const int cc0 = (ch - dz * p.nChunkC) * CC;
+    const int cgi0 = (ch - dz * p.nChunkC) * CG;
     float* xl = smem + buf * p.bufFloats;
     float* wl = xl + xFloats;
     const float* xb = in_n + (long)dz * p.isZ;
     for (int cc = wave; cc < CC; cc += 4) {
-      const int ci = min(cc0 + cc, p.Cin - 1);      // padded channels carry zero weights
+      const int ci = min(cgi0 * 4 + cc, p.Cin - 1);   // padded channels carry zero weights
       const float* src = xb + (long)ci * p.isC;
       float* dst = xl + cc * Lpad;
-      for (int j = 0; j < nJ; ++j) glds4(src + min(64 * j + lane, L - 1), dst + 64 * j);
+      // 16-byte pieces (256 floats per wave instruction); lanes past the span
+      // are masked off, the straddling lane over-reads <= 12 bytes, which stays
+      // inside the tensor except on its very last row: that row goes by dwords.
+      const bool tail_row = (ci == p.Cin - 1) && (z + dz == p.Din - 1) && (n == p.N - 1);
+      if (!tail_row) {
+        for (int j = 0; j < nJ16; ++j) {
+          const int u = 256 * j + 4 * lane;
+          if (u < L) glds16(src + u, dst + 256 * j);
+        }
+      } else {
+        for (int j = 0; j < nJ; ++j) glds4(src + min(64 * j + lane, L - 1), dst + 64 * j);
+      }
     }
-    const float* wb = p.wp + ((long)dz * p.THW * p.ciP + cc0) * p.coP + m0;
+    // weights: rows [cg][ty][tx][qd] are contiguous in the packed image
+    const float* wb = p.wp + ((long)(dz * (p.ciP >> 2) + cgi0) * p.THW * 4) * p.coP + m0;
     for (int pc = wave; pc < nPieces; pc += 4) {
       const int s = pc * 64 + lane;
       int row = s / BMp4;
       int c4 = s - row * BMp4;
       row = min(row, nRows - 1);
       c4 = min(c4, BM / 4 - 1);
-      const int t = row / CC, cc = row - t * CC;
-      glds16(wb + ((long)t * p.ciP + cc) * p.coP + 4 * c4, wl + pc * 256);
+      glds16(wb + (long)row * p.coP + 4 * c4, wl + pc * 256);
     }
   };
 
@@ -163,57 +210,87 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
   for (int ch = cb; ch < ce; ++ch) {
     const int cur = (ch - cb) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ch + 1 < ce) stage(ch + 1, cur ^ 1);
+    if (!(p.dbg & 4)) __syncthreads();
+    if (ch + 1 < ce && !(p.dbg & 1)) stage(ch + 1, cur ^ 1);
     const float* xl = smem + cur * p.bufFloats;
     const float* wl = xl + xFloats + aBase;
 
-    // k-steps of the chunk in (tap, channel-group) order: the A row offset
-    // advances linearly.  Two register sets ping-pong: the LDS reads of step
-    // s+1 are issued (unconditionally -- past the end they hit the slack) before
-    // the MFMAs of step s, so the compiler can wait with a COUNTED lgkmcnt.
-    const int nSteps = p.THW * CG;
-    int ty = 0, tx = 0, cg = 0, tapoff = 0;
-    const float* ap = wl;
-#define E2_ADVANCE()                                         \
-    {                                                        \
-      ap += 4 * BMpad;                                       \
-      ++cg;                                                  \
-      const int wc = (cg == CG) ? 1 : 0;                     \
-      cg = wc ? 0 : cg;                                      \
-      tx += wc;                                              \
-      const int wx = (tx == p.kw) ? 1 : 0;                   \
-      tx = wx ? 0 : tx;                                      \
-      ty += wx;                                              \
-      tapoff = ty * isY + tx;                                \
-    }
-#define E2_LOAD(A, B)                                                       \
-    {                                                                       \
-      const float* bp = xl + 4 * cg * Lpad + tapoff;                        \
-      _Pragma("unroll") for (int mb = 0; mb < MT; ++mb) A[mb] = ap[mb * 16]; \
-      _Pragma("unroll") for (int nb = 0; nb < NT; ++nb) B[nb] = bp[posoff[nb]]; \
-    }
-#define E2_MFMA(A, B)                                                       \
-    _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                       \
-    _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                       \
-      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mb], B[nb], acc[mb][nb], 0, 0, 0);
-    float a0[MT], b0[NT], a1[MT], b1[NT];
-    E2_LOAD(a0, b0)
-    int st = 0;
-    for (; st + 1 < nSteps; st += 2) {
-      E2_ADVANCE()
-      E2_LOAD(a1, b1)
-      E2_MFMA(a0, b0)
-      E2_ADVANCE()
-      E2_LOAD(a0, b0)
-      E2_MFMA(a1, b1)
-      SchedStep<0, MT + NT, MT * NT>::run();
-      SchedStep<0, MT + NT, MT * NT>::run();
-    }
-    if (st < nSteps) { E2_MFMA(a0, b0) }
-#undef E2_ADVANCE
-#undef E2_LOAD
+    if (p.dbg & 2) continue;
+    if constexpr (KW > 0) {
+      // groups g = (cg, ty) flattened; A rows of consecutive groups are
+      // contiguous, the B base moves by isY per ty and wraps per cg.
+      const int nG = CG * p.kh;
+      constexpr int ASTR = 4 * BMpad * 4;                  // bytes per tap of A rows
+      GroupRegs<MT, NT, KW, ASTR> g0, g1;
+      unsigned addrA = lds_addr(wl);
+      unsigned addrB[NT];
+      const unsigned xbase = lds_addr(xl);
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) addrB[nb] = xbase + 4u * (unsigned)posoff[nb];
+      const unsigned stepY = 4u * (unsigned)isY;
+      const unsigned wrapCg = 4u * (unsigned)(4 * Lpad) - (unsigned)p.kh * stepY;
+      int ty = 0;
+#define E2_NEXT()                                                        \
+      {                                                                  \
+        addrA += KW * ASTR;                                              \
+        ++ty;                                                            \
+        const unsigned d = (ty == p.kh) ? (stepY + wrapCg) : stepY;      \
+        ty = (ty == p.kh) ? 0 : ty;                                      \
+        _Pragma("unroll") for (int nb = 0; nb < NT; ++nb) addrB[nb] += d; \
+      }
+#define E2_MFMA(G)                                                       \
+      _Pragma("unroll") for (int tx = 0; tx < KW; ++tx)                  \
+      _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                  \
+      _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                  \
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[tx][mb], G.b[tx][nb], acc[mb][nb], 0, 0, 0);
+#define E2_WAIT()                                                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+      __builtin_amdgcn_sched_barrier(0);
+      g0.load(addrA, addrB);
+      E2_WAIT()
+      int g = 0;
+      for (; g + 1 < nG; g += 2) {
+        E2_NEXT()
+        g1.load(addrA, addrB);            // group g+1 in flight ...
+        __builtin_amdgcn_sched_barrier(0);
+        E2_MFMA(g0)                       // ... while group g computes
+        __builtin_amdgcn_sched_barrier(0);
+        E2_WAIT()
+        E2_NEXT()
+        g0.load(addrA, addrB);            // group g+2 (past the end: reads slack)
+        __builtin_amdgcn_sched_barrier(0);
+        E2_MFMA(g1)
+        __builtin_amdgcn_sched_barrier(0);
+        E2_WAIT()
+      }
+      if (g < nG) { E2_MFMA(g0) }
+#undef E2_NEXT
 #undef E2_MFMA
+#undef E2_WAIT
+    } else {
+    for (int cg = 0; cg < CG; ++cg) {
+      for (int ty = 0; ty < p.kh; ++ty) {
+        const float* ap = wl + ((cg * p.kh + ty) * kw) * (4 * BMpad);
+        const float* bq = xl + 4 * cg * Lpad + ty * isY;
+        const float* bp[NT];
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) bp[nb] = bq + posoff[nb];
+        for (int tx = 0; tx < kw; ++tx) {
+          float a0[MT], b0[NT];
+#pragma unroll
+          for (int mb = 0; mb < MT; ++mb) a0[mb] = ap[tx * (4 * BMpad) + mb * 16];
+#pragma unroll
+          for (int nb = 0; nb < NT; ++nb) b0[nb] = bp[nb][tx];
+#pragma unroll
+          for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mb], b0[nb],
+                                                                 acc[mb][nb], 0, 0, 0);
+        }
+      }
+    }
+    }
   }
 
   // ---- epilogue: D col = position (lane&15), row = channel 4*qd+reg -------
@@ -251,22 +328,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
 }
 
 // ---- weight packing ---------------------------------------------------------
-// Wp[dz][t][ic(ciP)][oc(coP)], zero padded.  One thread per packed element.
+// Wp[dz][cg = ic/4][t = ty*kw+tx][qd = ic%4][oc (coP)], zero padded: the K order
+// the kernel consumes, so staging a chunk is a linear copy of rows.
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                     int Cout, int Cin, int kd, int THW, long wsO,
                                     long wsI, int flip, int ciP, int coP, int Rout,
                                     int Rin) {
   const long total = (long)kd * THW * ciP * coP;
   const int T = kd * THW;
+  const int nCG = ciP >> 2;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
     const int oc = (int)(i % coP);
     long r = i / coP;
-    const int ic = (int)(r % ciP);
-    r /= ciP;                       // r = dz*THW + t
+    const int qd = (int)(r & 3); r >>= 2;
+    const int t = (int)(r % THW); r /= THW;
+    const int cg = (int)(r % nCG);
+    const int dz = (int)(r / nCG);
+    const int ic = cg * 4 + qd;
     float v = 0.f;
     if (oc < Cout && ic < Cin) {
-      const int tap = flip ? (T - 1 - (int)r) : (int)r;
+      const int tl = dz * THW + t;
+      const int tap = flip ? (T - 1 - tl) : tl;
       // Rout/Rin > 1: UpConv sub-position folded into the channel index
       v = w[(long)(oc / Rout) * wsO + (long)(ic / Rin) * wsI + tap + (oc % Rout) +
             (ic % Rin)];
@@ -278,28 +361,39 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 // ---- host side ----------------------------------------------------------------
 struct IgemmCfg { int MT, NT, CC, SK; };
 
-template <int MT, int NT>
+template <int MT, int NT, int KW>
 static int launch_one(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<MT, NT>),
+        reinterpret_cast<const void*>(&igemm_kernel<MT, NT, KW>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<MT, NT>), dim3(grid), dim3(256), lds, ctx->stream, p);
+  hipLaunchKernelGGL((igemm_kernel<MT, NT, KW>), dim3(grid), dim3(256), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 static const int kMTs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13};
 
+template <int MT, int NT>
+static int dispatch_kw(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
+  switch (p.kw) {
+    case 1: return launch_one<MT, NT, 1>(ctx, p, grid, lds);
+    case 3: return launch_one<MT, NT, 3>(ctx, p, grid, lds);
+    case 4: return launch_one<MT, NT, 4>(ctx, p, grid, lds);
+    case 5: return launch_one<MT, NT, 5>(ctx, p, grid, lds);
+    default: return launch_one<MT, NT, 0>(ctx, p, grid, lds);   // runtime tx loop
+  }
+}
+
 static int dispatch(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int grid, size_t lds) {
 #define E2_CASE(M)                                                          \
   case M:                                                                   \
-    if (NT == 1) return launch_one<M, 1>(ctx, p, grid, lds);                \
-    if (NT == 2) return launch_one<M, 2>(ctx, p, grid, lds);                \
+    if (NT == 1) return dispatch_kw<M, 1>(ctx, p, grid, lds);               \
+    if (NT == 2) return dispatch_kw<M, 2>(ctx, p, grid, lds);               \
     break;
   switch (MT) {
     E2_CASE(1) E2_CASE(2) E2_CASE(3) E2_CASE(4) E2_CASE(5) E2_CASE(6)
@@ -321,14 +415,15 @@ static int span_rows(int BN, int Wo) { return (BN + Wo - 2) / Wo; }
 static int span_lmax(const IgemmArgs& a, int BN) {
   return (span_rows(BN, a.Wo) + a.kh - 1) * (int)a.isY + a.kw + a.Wo;
 }
-// LDS-DMA writes whole 64-float pieces: rows must hold a multiple of 64
+// LDS-DMA writes whole 256-float pieces (16 B per lane): rows hold a multiple of 256
 static int span_lpad(const IgemmArgs& a, int BN) {
-  return pad16mod32(((span_lmax(a, BN) + 63) / 64) * 64);
+  return pad16mod32(((span_lmax(a, BN) + 255) / 256) * 256);
 }
 static size_t buf_floats(const IgemmArgs& a, int MT, int BN, int CC) {
   const int THW = a.kh * a.kw;
   return (size_t)CC * span_lpad(a, BN) + (size_t)THW * CC * igemm_bmpad(MT) + 256 +
-         8 * (size_t)igemm_bmpad(MT);   // DMA piece slack + prefetch-past-the-end slack
+         (size_t)(8 + 4 * 6) * igemm_bmpad(MT) + 4 * (size_t)span_lpad(a, BN) + 64;
+  // DMA piece slack + one group of A/B prefetch past the end
 }
 
 // Pick the tiling.  Cost model (cycles): work-groups run 1 or 2 per CU
@@ -422,6 +517,9 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   const int BN = 64 * c.NT;
   p.Lpad = span_lpad(a, BN);
   p.CC = c.CC;
+  p.Din = a.Do + a.kd - 1;
+  p.dbg = getenv("E2_IGEMM_DBG") ? atoi(getenv("E2_IGEMM_DBG")) : 0;
+  p.N = a.N;
   p.nPT = e2_cdiv(p.Q, BN);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), c.MT);
   p.splitK = c.SK;

@@ -10,22 +10,66 @@
 // the tap index FLATTENED into N (so Cin = 1 or odd Cin waste nothing), K =
 // output positions.  A work-group owns an (M-tile, N-tile) and a range of
 // position tiles; it keeps the partial G tile in MFMA accumulators across all
-// its position tiles and flushes once with fp32 atomics into the zeroed dw.
+// its position tiles and flushes once with fp32 atomics into the zeroed dw
+// (the host keeps the number of position splits small: the chip-wide fp32
+// atomic rate is ~1.3 TB/s).
 //
 // Position tile = BP consecutive positions of one z-plane.  As in the forward
 // kernel the input the tile touches is one contiguous span per (ci, dz); the
-// spans of every (ci, dz) the N-tile needs are staged in LDS.  The B operand of
-// lane (j = n-index, qd = pos & 3) is x_l[lanebase(j) + inoff[pos]] where
-// lanebase = slot(ci,dz)*Lpad + ty*sY + tx is loop invariant and inoff[pos]
-// (the position's offset inside the span) comes from a small LDS table.
+// spans of every (ci, dz) the N-tile needs and the dy rows are brought in by
+// LDS-DMA into one of two buffers while the other one is being consumed.
+// B operand of lane (j = n-index, qd = pos & 3): x_l[lanebase(j) + inoff[pos]],
+// lanebase = slot(ci,dz)*Lpad + ty*sY + tx (loop invariant), inoff[pos] = the
+// position's offset inside the span (small LDS table, read 4 k-steps at a
+// time with one ds_read_b128).
 //
-// LDS row strides are == 2 (mod 4) so that 16 channel rows x 2 position
-// quarters of a 32-lane ds_read_b32 group fall on 32 distinct banks.
+// Inner loop: "quads" of 4 k-steps.  All LDS reads of quad q+1 are issued (asm,
+// invisible to hipcc's waitcnt pass) before the MFMAs of quad q; one
+// s_waitcnt lgkmcnt(0) after the MFMAs.  Two register sets ping-pong.
 #include "common.hpp"
 #include <stdlib.h>
 #include <algorithm>
+#include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+__device__ __forceinline__ void w_glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 4, 0, 0);
+}
+__device__ __forceinline__ void w_glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ float w_lds_ld(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ i32x4 w_lds_ld128(unsigned addr) {
+  i32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ unsigned w_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(lds_vp)p;
+}
+
+struct FastDivW { unsigned d, m, sh; };
+static inline FastDivW mk_divw(unsigned d) {
+  FastDivW f; f.d = d;
+  if (d <= 1) { f.m = 0; f.sh = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  f.sh = l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdivw(unsigned n, const FastDivW& f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.m) >> f.sh);
+}
 
 struct WgradP {
   const float* x;
@@ -37,23 +81,53 @@ struct WgradP {
   long dsN, dsC, dsZ, dsY;
   int flip, upR;
   int NTOT;
-  int BP, log2BP;
-  int DLpad, Lpad;
+  int Lpad;
   int nMT, nNT, nPS;
   int nPT, tilesTotal;
   int maxSpans;
+  int bufFloats;
+  int Din, N;
+  int dbg;
+  FastDivW divWo;
 };
 
-template <int MT, int NT, int WN, int WK>
+// one quad = 4 k-steps: A[4][MT], B[4][NT] fragments + the span offsets of the
+// NEXT quad (4 ints per lane)
+template <int MT, int NT, int DLPAD>
+struct QuadRegs {
+  float a[4][MT];
+  float b[4][NT];
+  i32x4 io;
+  template <int... I>
+  __device__ __forceinline__ void load_a(unsigned addr, std::integer_sequence<int, I...>) {
+    ((a[I / MT][I % MT] = w_lds_ld<((I % MT) * 16 * DLPAD + (I / MT) * 4) * 4>(addr)), ...);
+  }
+  __device__ __forceinline__ void load(unsigned addrA, unsigned addrT, unsigned xbase,
+                                       const int (&lanebase)[NT], const i32x4& cur_io) {
+    load_a(addrA, std::make_integer_sequence<int, 4 * MT>{});
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+        b[j][nb] = w_lds_ld<0>(xbase + 4u * (unsigned)(lanebase[nb] + cur_io[j]));
+    io = w_lds_ld128(addrT);
+  }
+};
+
+template <int MT, int NT, int BP, int WK>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int WN = 4 / WK;
   constexpr int BM = 16 * MT;
   constexpr int BNn = 16 * NT * WN;
-  float* dyl = smem;                                  // BM * DLpad
-  float* xl = dyl + BM * p.DLpad;                     // maxSpans * Lpad
-  int* inoff = reinterpret_cast<int*>(xl + p.maxSpans * p.Lpad);   // BP
+  constexpr int DLPAD = BP + 2;          // == 2 (mod 4): conflict-free A reads
+  constexpr int NQ = BP / 16;            // quads per tile
+  // buffer layout: [dy: BM*DLPAD][pad to 16B][table: BP ints + 16][x: maxSpans*Lpad]
+  constexpr int DYF = ((BM * DLPAD + 3) / 4) * 4;
+  constexpr int TBF = BP + 16;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, qd = lane >> 4;
   const int wn = wave % WN, wk = wave / WN;
 
@@ -69,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   const int ciB = nEnd / p.T;
   const int nSpans = (ciB - ciA + 1) * p.kd;
   const int xsY = (int)p.xsY;
+  const int Lpad = p.Lpad;
 
   int lanebase[NT];
 #pragma unroll
@@ -79,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     const int dz = tap / p.THW;
     const int t2 = tap - dz * p.THW;
     const int ty = t2 / p.kw, tx = t2 - ty * p.kw;
-    lanebase[nb] = ((ci - ciA) * p.kd + dz) * p.Lpad + ty * xsY + tx;
+    lanebase[nb] = ((ci - ciA) * p.kd + dz) * Lpad + ty * xsY + tx;
   }
 
   f32x4 acc[MT][NT];
@@ -90,67 +165,110 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 
   const int per = (p.tilesTotal + p.nPS - 1) / p.nPS;
   const int tb = ps * per, te = min(tb + per, p.tilesTotal);
-  const int BP = p.BP;
-  const int pl = tid & (BP - 1);          // this thread's position in the tile
-  const int coStep = 256 >> p.log2BP;
-  const int co0 = tid >> p.log2BP;
 
-  for (int tt = tb; tt < te; ++tt) {
+  // ---- stage one position tile into buffer `buf` (async LDS-DMA) ----------
+  auto stage = [&](int tt, int buf) {
+    float* dyl = smem + buf * p.bufFloats;
+    int* tbl = reinterpret_cast<int*>(dyl + DYF);
+    float* xl = dyl + DYF + TBF;
     const int pt = tt % p.nPT;
     const int zz = tt / p.nPT;
     const int z = zz % p.Do;
     const int n = zz / p.Do;
     const int q0 = pt * BP;
     const int qlast = min(q0 + BP, p.Q) - 1;
-    const int r0 = q0 / p.Wo, c0 = q0 - r0 * p.Wo;
-    const int rl = qlast / p.Wo, cl = qlast - rl * p.Wo;
+    const int r0 = (int)fdivw(q0, p.divWo), c0 = q0 - r0 * p.Wo;
+    const int rl = (int)fdivw(qlast, p.divWo), cl = qlast - rl * p.Wo;
     const long span_lo = (long)r0 * p.xsY + c0;
     const int L = (rl - r0) * xsY + (cl - c0) + (p.kh - 1) * xsY + p.kw;
-
-    // ---- position table + dy tile (thread <-> fixed position) ------------
-    {
+    const bool partial = (qlast - q0 + 1) < BP;
+    // dy rows: lane <-> position (64 positions per DMA instruction)
+    const float* dyb = p.dy + (long)n * p.dsN + (long)z * p.dsZ;
+#pragma unroll
+    for (int j = 0; j < BP / 64; ++j) {
+      const int pl = 64 * j + lane;
       const int q = q0 + pl;
       const bool valid = q <= qlast;
       const int qc = valid ? q : qlast;
-      const int r = qc / p.Wo, c = qc - r * p.Wo;
-      if (tid < BP) inoff[pl] = (r - r0) * xsY + (c - c0);
-      const float* src = p.dy + (long)n * p.dsN + (long)z * p.dsZ + (long)r * p.dsY + c;
-      for (int co = co0; co < BM; co += coStep) {
-        float v = 0.f;
-        if (valid && (m0 + co) < p.Cout) v = src[(long)(m0 + co) * p.dsC];
-        dyl[co * p.DLpad + pl] = v;
+      const int r = (int)fdivw(qc, p.divWo), c = qc - r * p.Wo;
+      // span-offset table, [qd][BP/4] so a lane reads 4 consecutive k-steps at once
+      if (wave == 0) tbl[(pl & 3) * (BP / 4) + (pl >> 2)] = (r - r0) * xsY + (c - c0);
+      const float* src = dyb + (long)r * p.dsY + c;
+      for (int co = wave; co < BM; co += 4) {
+        float* dst = dyl + co * DLPAD + 64 * j;
+        if (partial) {                       // invalid positions must contribute 0
+          dst[lane] = 0.f;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        const int cg = min(m0 + co, p.Cout - 1);
+        if (valid) w_glds4(src + (long)cg * p.dsC, dst);
       }
     }
-    // ---- input spans --------------------------------------------------------
-    {
-      const float* xb = p.x + (long)n * p.xsN + (long)z * p.xsZ + span_lo;
-      for (int slot = wave; slot < nSpans; slot += 4) {
-        const int ci = ciA + slot / p.kd;
-        const int dz = slot - (slot / p.kd) * p.kd;
-        const float* src = xb + (long)ci * p.xsC + (long)dz * p.xsZ;
-        float* dst = xl + slot * p.Lpad;
-        for (int u = lane; u < L; u += 64) dst[u] = src[u];
-      }
+    // input spans, 16 B per lane; the tensor's very last row goes by dwords
+    const float* xb = p.x + (long)n * p.xsN + (long)z * p.xsZ + span_lo;
+    const int nJ = (L + 63) >> 6;
+    for (int slot = wave; slot < nSpans; slot += 4) {
+      const int cs = slot / p.kd;
+      const int dz = slot - cs * p.kd;
+      const int ci = ciA + cs;
+      const float* src = xb + (long)ci * p.xsC + (long)dz * p.xsZ;
+      float* dst = xl + slot * Lpad;
+      for (int j = 0; j < nJ; ++j) w_glds4(src + min(64 * j + lane, L - 1), dst + 64 * j);
     }
+  };
+
+  // the quad pipeline reads one quad of offsets past the table: keep them in range
+  if (tid < 32) {
+    int* t = reinterpret_cast<int*>(smem + (tid >> 4) * p.bufFloats + DYF);
+    t[BP + (tid & 15)] = 0;
+  }
+  if (tb < te) stage(tb, 0);
+  for (int tt = tb; tt < te; ++tt) {
+    const int cur = (tt - tb) & 1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- MFMA: K = positions, 4 per step ----------------------------------
-    const int nsteps = (qlast - q0 + 4) >> 2;
-    for (int s = wk; s < nsteps; s += WK) {
-      const int pk = 4 * s + qd;
-      const int io = inoff[pk];
-      float a[MT], b[NT];
-#pragma unroll
-      for (int mb = 0; mb < MT; ++mb) a[mb] = dyl[(mb * 16 + l15) * p.DLpad + pk];
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) b[nb] = xl[lanebase[nb] + io];
-#pragma unroll
-      for (int mb = 0; mb < MT; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b[nb],
-                                                             acc[mb][nb], 0, 0, 0);
+    if (tt + 1 < te && !(p.dbg & 1)) stage(tt + 1, cur ^ 1);
+    if (p.dbg & 2) continue;
+    const float* dyl = smem + cur * p.bufFloats;
+    const unsigned xbase = w_lds_addr(dyl + DYF + TBF);
+    // A: row (mb*16 + l15), column 4*s + qd ; table: [qd][BP/4]
+    unsigned addrA = w_lds_addr(dyl + l15 * DLPAD + qd) + 64u * (unsigned)wk;
+    unsigned addrT = w_lds_addr(dyl + DYF + qd * (BP / 4)) + 16u * (unsigned)wk;
+
+    QuadRegs<MT, NT, DLPAD> g0, g1;
+#define E2_MFMA(G)                                                       \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                        \
+    _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                    \
+    _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                    \
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[j][mb], G.b[j][nb], acc[mb][nb], 0, 0, 0);
+#define E2_WAIT()                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+    __builtin_amdgcn_sched_barrier(0);
+    // first quad of this wave: its offsets, then its operands
+    i32x4 io0 = w_lds_ld128(addrT);
+    E2_WAIT()
+    addrT += 16u * WK;
+    g0.load(addrA, addrT, xbase, lanebase, io0);   // also fetches the offsets of the next quad
+    E2_WAIT()
+    constexpr int NQW = NQ / WK;                   // quads per wave
+    int q = 0;
+    for (; q + 1 < NQW; q += 2) {
+      addrA += 64u * WK; addrT += 16u * WK;
+      g1.load(addrA, addrT, xbase, lanebase, g0.io);
+      __builtin_amdgcn_sched_barrier(0);
+      E2_MFMA(g0)
+      __builtin_amdgcn_sched_barrier(0);
+      E2_WAIT()
+      addrA += 64u * WK; addrT += 16u * WK;
+      g0.load(addrA, addrT, xbase, lanebase, g1.io);   // past the end: reads slack
+      __builtin_amdgcn_sched_barrier(0);
+      E2_MFMA(g1)
+      __builtin_amdgcn_sched_barrier(0);
+      E2_WAIT()
     }
-    __syncthreads();
+    if (q < NQW) { E2_MFMA(g0) }
+#undef E2_MFMA
+#undef E2_WAIT
   }
 
   // ---- flush: row = co (4*qd+reg), col = n-index (lane&15) -----------------
@@ -185,54 +303,89 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 }
 
 // ---- host side ----------------------------------------------------------------
-template <int MT, int NT, int WN, int WK>
+template <int MT, int NT, int BP, int WK>
 static int launch_w(e2_ctx* ctx, const WgradP& p, int grid, size_t lds) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_kernel<MT, NT, WN, WK>),
+        reinterpret_cast<const void*>(&wgrad_kernel<MT, NT, BP, WK>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<MT, NT, WN, WK>), dim3(grid), dim3(256), lds,
-                     ctx->stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<MT, NT, BP, WK>), dim3(grid), dim3(256), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 static const int kWMTs[] = {1, 2, 3, 4, 5, 7};
 
-static int dispatch_w(e2_ctx* ctx, const WgradP& p, int MT, int NT, int WK, int grid,
-                      size_t lds) {
-#define E2_W(M)                                                                  \
-  case M:                                                                        \
-    if (WK == 4) return launch_w<M, 1, 1, 4>(ctx, p, grid, lds);                 \
-    if (NT == 1) return launch_w<M, 1, 4, 1>(ctx, p, grid, lds);                 \
-    if (NT == 2) return launch_w<M, 2, 4, 1>(ctx, p, grid, lds);                 \
-    if (NT == 4) return launch_w<M, 4, 4, 1>(ctx, p, grid, lds);                 \
-    break;
-  switch (MT) { E2_W(1) E2_W(2) E2_W(3) E2_W(4) E2_W(5) E2_W(7) }
-#undef E2_W
-  e2_set_error("wgrad: no instance MT=%d NT=%d WK=%d", MT, NT, WK);
+template <int MT>
+static int dispatch_w2(e2_ctx* ctx, const WgradP& p, int NT, int BP, int WK, int grid,
+                       size_t lds) {
+  if (WK == 4) {
+    if (BP == 64) return launch_w<MT, 1, 64, 4>(ctx, p, grid, lds);
+    return launch_w<MT, 1, 128, 4>(ctx, p, grid, lds);
+  }
+  if (BP == 64) {
+    if (NT == 1) return launch_w<MT, 1, 64, 1>(ctx, p, grid, lds);
+    if (NT == 2) return launch_w<MT, 2, 64, 1>(ctx, p, grid, lds);
+    if (NT == 4) return launch_w<MT, 4, 64, 1>(ctx, p, grid, lds);
+  } else {
+    if (NT == 1) return launch_w<MT, 1, 128, 1>(ctx, p, grid, lds);
+    if (NT == 2) return launch_w<MT, 2, 128, 1>(ctx, p, grid, lds);
+    if (NT == 4) return launch_w<MT, 4, 128, 1>(ctx, p, grid, lds);
+  }
+  e2_set_error("wgrad: no instance NT=%d BP=%d WK=%d", NT, BP, WK);
   return 2;
 }
 
-static int pad2mod4(int v) {             // smallest s >= v with s % 4 == 2
-  int s = v;
-  while ((s & 3) != 2) ++s;
-  return s;
+static int dispatch_w(e2_ctx* ctx, const WgradP& p, int MT, int NT, int BP, int WK, int grid,
+                      size_t lds) {
+  switch (MT) {
+    case 1: return dispatch_w2<1>(ctx, p, NT, BP, WK, grid, lds);
+    case 2: return dispatch_w2<2>(ctx, p, NT, BP, WK, grid, lds);
+    case 3: return dispatch_w2<3>(ctx, p, NT, BP, WK, grid, lds);
+    case 4: return dispatch_w2<4>(ctx, p, NT, BP, WK, grid, lds);
+    case 5: return dispatch_w2<5>(ctx, p, NT, BP, WK, grid, lds);
+    case 7: return dispatch_w2<7>(ctx, p, NT, BP, WK, grid, lds);
+  }
+  e2_set_error("wgrad: no instance MT=%d", MT);
+  return 2;
+}
+
+// x-span row stride: whole 64-float (dword) DMA pieces, == 2 (mod 4) so rows of
+// consecutive channels fall on different banks
+static int w_lpad(int Lmax) {
+  return ((Lmax + 63) / 64) * 64 + 2;    // whole 64-float DMA pieces, == 2 (mod 4)
+}
+static int w_lmax(const WgradArgs& a, int BP) {
+  const int rows = (BP + a.Wo - 2) / a.Wo;
+  return (rows + a.kh - 1) * (int)a.xsY + a.kw + a.Wo;
+}
+static int w_maxspans(const WgradArgs& a, int BNn) {
+  const int T = a.kd * a.kh * a.kw;
+  int cis = (BNn - 1) / T + 2;
+  if (cis > a.Cin) cis = a.Cin;
+  return cis * a.kd;
+}
+static size_t w_buf_floats(const WgradArgs& a, int MT, int BNn, int BP) {
+  const size_t dyf = (((size_t)16 * MT * (BP + 2) + 3) / 4) * 4;
+  // + slack: the quad pipeline prefetches one quad past the end of the tile
+  return dyf + (BP + 16) + (size_t)w_maxspans(a, BNn) * w_lpad(w_lmax(a, BP)) + 64;
 }
 
 struct WCfg { int MT, NT, WK, BP, PS; };
 
+// Cost model (cycles): MFMA time of a work-group's waves (they run 1-2 per
+// SIMD), DMA bytes at ~20 B/clk/CU, and the flush atomics against the chip-wide
+// 1.3 TB/s rate; position splits only as needed to fill the CUs.
 static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
   const int mblocks = e2_cdiv(a.Cout, 16);
   const int T = a.kd * a.kh * a.kw;
   const long NTOT = (long)a.Cin * T;
   const int nblocks = (int)((NTOT + 15) / 16);
   const long Q = (long)a.Ho * a.Wo;
-  const int slots = ctx->num_cu * 2;
   WCfg best{0, 0, 0, 0, 0};
   double bestCost = 1e300;
   const char* force = getenv("E2_WGRAD_FORCE");
@@ -240,45 +393,45 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
     WCfg f{0, 0, 0, 0, 0};
     if (sscanf(force, "%d,%d,%d,%d,%d", &f.MT, &f.NT, &f.WK, &f.BP, &f.PS) == 5) { *ok = 1; return f; }
   }
+  const double dw_bytes = 4.0 * a.Cout * (double)NTOT;
   for (int MT : kWMTs) {
     if (MT > mblocks && MT != 1) continue;
     const int nMT = e2_cdiv(mblocks, MT);
     for (int v = 0; v < 4; ++v) {
       const int NT = (v == 3) ? 1 : (1 << v);       // 1,2,4 | WK variant
       const int WK = (v == 3) ? 4 : 1;
-      const int WN = (v == 3) ? 1 : 4;
+      const int WN = 4 / WK;
       const int BNn = 16 * NT * WN;
-      if (BNn > 16 * nblocks && !(NT == 1)) continue;
+      if (16 * NT * WN > 16 * nblocks && NT > 1) continue;
+      if (WK == 4 && nblocks > 2) continue;        // K-split waves only for tiny N
       const int nNT = e2_cdiv(nblocks, NT * WN);
-      for (int BP = 64; BP <= 256; BP *= 2) {
-        if (BP > 64 && Q <= BP / 2) continue;
-        const int rows = (BP + a.Wo - 2) / a.Wo;
-        const int Lmax = (rows + a.kh - 1) * (int)a.xsY + a.kw + a.Wo;
-        const int Lpad = pad2mod4(Lmax);
-        const int DLpad = pad2mod4(BP);
-        const int maxSpans = ((BNn - 1) / T + 2) * a.kd;
-        const int spansEff = std::min<long>(maxSpans, (long)a.Cin * a.kd);
-        const size_t lds = ((size_t)16 * MT * DLpad + (size_t)maxSpans * Lpad + BP) * 4;
-        if (lds > 72 * 1024) continue;
+      for (int BP = 64; BP <= 128; BP *= 2) {
+        if (BP == 128 && Q <= 64) continue;
+        const size_t bufF = w_buf_floats(a, MT, BNn, BP);
+        const size_t lds = 2 * bufF * 4;
+        if (lds > 160 * 1024) continue;
+        const int perCU = lds <= 80 * 1024 ? 2 : 1;
+        const int slots = ctx->num_cu * perCU;
         const int nPT = (int)((Q + BP - 1) / BP);
         const long tiles = (long)a.N * a.Do * nPT;
         const long base = (long)nMT * nNT;
-        // position splits: fill the machine, but bound the atomic volume
-        long PS = std::max<long>(1, (slots + base - 1) / base);
-        PS = std::min(PS, tiles);
-        const int per = (int)((tiles + PS - 1) / PS);
-        const double steps = BP / 4.0 / WK;
-        const double mfma = per * steps * MT * NT * 32.0;
-        const double reads = per * steps * (MT + NT + 1) * 6.0;
-        const double stage = per * ((16.0 * MT * BP + (double)spansEff * Lmax) / 256.0 * 6.0 + 700.0);
-        const double flush = 16.0 * MT * 16.0 * NT * 4 * 0.5 * WK;
-        const double wg_time = std::max(mfma, reads) + stage + flush + 1500.0;
-        const long wgs = base * PS;
-        const double rounds = (double)((wgs + slots - 1) / slots);
-        // chip-wide atomic floor: bytes / 1.3 TB/s in cycles @2.4GHz
-        const double atom = (double)wgs * 16 * MT * BNn * 4.0 * WK / 1.3e12 * 2.4e9;
-        const double cost = std::max(rounds * wg_time * 2.0, atom);
-        if (cost < bestCost) { bestCost = cost; best = WCfg{MT, NT, WK, BP, (int)PS}; }
+        for (int fill = 1; fill <= 2; ++fill) {
+          long PS = std::max<long>(1, ((long)slots * fill + base - 1) / base);
+          PS = std::min(PS, tiles);
+          const int per = (int)((tiles + PS - 1) / PS);
+          const double mfma = (BP / 4.0 / WK) * MT * NT * 32.0;              // per tile
+          const double bytes = 4.0 * (16.0 * MT * BP + (double)w_maxspans(a, BNn) * w_lmax(a, BP));
+          const double issue = (BP / 4.0 / WK) * (MT + 2.0 * NT + 1) * 5.0;
+          double tile = std::max(mfma, issue) * perCU * 1.08 + 400.0;
+          tile = std::max(tile, bytes / 20.0 * perCU);
+          const double flush = 16.0 * MT * 16.0 * NT * 4 * WK * 0.6;
+          const double wg_time = per * tile + flush + 5000.0;
+          const long wgs = base * PS;
+          const double rounds = (double)((wgs + slots - 1) / slots);
+          const double atom = (double)PS * dw_bytes * WK / 1.3e12 * 2.4e9 + dw_bytes / 4e12 * 2.4e9;
+          const double cost = rounds * wg_time + atom;
+          if (cost < bestCost) { bestCost = cost; best = WCfg{MT, NT, WK, BP, (int)PS}; }
+        }
       }
     }
   }
@@ -289,10 +442,13 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
 int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   E2_REQUIRE(a.Do > 0 && a.Ho > 0 && a.Wo > 0 && a.Cin > 0 && a.Cout > 0,
              "wgrad: empty problem");
+  E2_REQUIRE(a.xsY < (1 << 20), "wgrad: input row stride too large");
   int ok = 0;
   WCfg c = choose_wcfg(ctx, a, &ok);
   E2_REQUIRE(ok, "wgrad: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d)", a.Cin, a.Cout,
              a.kd, a.kh, a.kw);
+  E2_REQUIRE(c.BP == 64 || c.BP == 128, "wgrad: BP must be 64 or 128");
+  E2_REQUIRE(c.WK == 1 || (c.WK == 4 && c.NT == 1), "wgrad: WK=4 needs NT=1");
   WgradP p;
   p.x = a.x; p.dy = a.dy; p.dw = a.dw;
   p.Cin = a.Cin; p.Cout = a.Cout; p.kd = a.kd; p.kh = a.kh; p.kw = a.kw;
@@ -305,28 +461,27 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   const long NTOT = (long)a.Cin * p.T;
   E2_REQUIRE(NTOT < (1L << 30), "wgrad: Cin*T too large");
   p.NTOT = (int)NTOT;
-  p.BP = c.BP;
-  p.log2BP = (c.BP == 64) ? 6 : (c.BP == 128 ? 7 : (c.BP == 256 ? 8 : 5));
-  E2_REQUIRE((1 << p.log2BP) == c.BP, "wgrad: BP must be 32..256 pow2");
-  const int WN = (c.WK == 4) ? 1 : 4;
+  const int WN = 4 / c.WK;
   const int BNn = 16 * c.NT * WN;
-  const int rows = (c.BP + a.Wo - 2) / a.Wo;
-  const int Lmax = (rows + a.kh - 1) * (int)a.xsY + a.kw + a.Wo;
-  p.Lpad = pad2mod4(Lmax);
-  p.DLpad = pad2mod4(c.BP);
-  p.maxSpans = ((BNn - 1) / p.T + 2) * a.kd;
+  p.Lpad = w_lpad(w_lmax(a, c.BP));
+  p.maxSpans = w_maxspans(a, BNn);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), c.MT);
   p.nNT = e2_cdiv(e2_cdiv(p.NTOT, 16), c.NT * WN);
   p.nPT = e2_cdiv(p.Q, c.BP);
   p.tilesTotal = a.N * a.Do * p.nPT;
-  p.nPS = std::min(c.PS, p.tilesTotal);
-  E2_REQUIRE(a.xsY < (1 << 20), "wgrad: input row stride too large");
-  const size_t lds = ((size_t)16 * c.MT * p.DLpad + (size_t)p.maxSpans * p.Lpad + c.BP) * 4;
+  p.nPS = std::max(1, std::min(c.PS, p.tilesTotal));
+  p.bufFloats = (int)w_buf_floats(a, c.MT, BNn, c.BP);
+  p.Din = a.Do + a.kd - 1;
+  p.N = a.N;
+  p.divWo = mk_divw((unsigned)a.Wo);
+  p.dbg = getenv("E2_WGRAD_DBG") ? atoi(getenv("E2_WGRAD_DBG")) : 0;
+  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  E2_REQUIRE(lds <= 160 * 1024, "wgrad: tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
   E2_CHECK_HIP(hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.Cout * p.NTOT, ctx->stream));
   if (getenv("E2_VERBOSE"))
     fprintf(stderr, "[e2] wgrad Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d WK=%d BP=%d PS=%d grid=%ld lds=%zu\n",
             a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.WK, c.BP, p.nPS, grid, lds);
-  return dispatch_w(ctx, p, c.MT, c.NT, c.WK, (int)grid, lds);
+  return dispatch_w(ctx, p, c.MT, c.NT, c.BP, c.WK, (int)grid, lds);
 }

@@ -23,6 +23,26 @@ __device__ __forceinline__ long vidx(const View5& v, int n, int c, int z, int y,
   return (long)n * v.sn + (long)c * v.sc + (long)z * v.sd + (long)y * v.sh + x;
 }
 
+// exact unsigned division of n < 2^31 by a runtime constant (host-made magic):
+// l = ceil(log2 d), m = ceil(2^(31+l) / d);  n / d == umulhi(n, m) >> (l - 1)
+struct FastDiv {
+  unsigned d, m, sh;
+};
+static inline FastDiv mk_div(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.m = 0; f.sh = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  const unsigned long long num = 1ull << (31 + l);
+  f.m = (unsigned)((num + d - 1) / d);
+  f.sh = l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.m) >> f.sh);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -74,57 +94,77 @@ __global__ void copy_view_kernel(View5 src, View5 dst, int accumulate) {
 
 // ---------------------------------------------------------------------------
 // max-pool (+bias +act) forward:  out = act(max_window(y) + b[c])
+// grid: (chunks of the (z,y,x) output range, c, n); 32-bit index math with
+// magic-number division; each thread walks its chunk with stride 256.
 // ---------------------------------------------------------------------------
-template <bool HAS_BIAS>
-__global__ void pool_fwd_kernel(View5 y, const float* __restrict__ bias, int pz, int py,
-                                int px, int act, View5 out) {
-  const long S = (long)out.d * out.h * out.w;
-  const long s = blockIdx.x * 256L + threadIdx.x;
-  if (s >= S) return;
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int xo = (int)(s % out.w);
-  const long t = s / out.w;
-  const int yo = (int)(t % out.h), zo = (int)(t / out.h);
-  const float* src = y.p + vidx(y, n, c, zo * pz, yo * py, xo * px);
-  float m = src[0];
-  for (int a = 0; a < pz; ++a)
-    for (int b = 0; b < py; ++b) {
-      const float* row = src + a * y.sd + b * y.sh;
-      for (int e = 0; e < px; ++e) m = fmaxf(m, row[e]);
-    }
-  float v = m;
-  if (HAS_BIAS) v += bias[c];
-  if (act == E2_ACT_RELU) v = fmaxf(v, 0.f);
-  out.p[vidx(out, n, c, zo, yo, xo)] = v;
-}
 
-// backward: dy[window] = (y == max) ? dout * act'(max + b) : 0 ; dbias += sum
 template <bool HAS_BIAS>
-__global__ void pool_bwd_kernel(View5 dout, View5 y, const float* __restrict__ bias,
-                                int pz, int py, int px, int act, View5 dy,
-                                float* __restrict__ dbias, int accumulate) {
-  __shared__ float red[4];
-  const long S = (long)dout.d * dout.h * dout.w;
-  const long s = blockIdx.x * 256L + threadIdx.x;
+__global__ __launch_bounds__(256) void pool_fwd_kernel(View5 y, const float* __restrict__ bias,
+                                                       int pz, int py, int px, int act,
+                                                       View5 out, FastDiv dw, FastDiv dh,
+                                                       unsigned chunk) {
+  const unsigned S = (unsigned)out.d * out.h * out.w;
+  const unsigned s0 = blockIdx.x * chunk;
+  const unsigned s1 = min(s0 + chunk, S);
   const int c = blockIdx.y, n = blockIdx.z;
-  float g = 0.f;
-  if (s < S) {
-    const int xo = (int)(s % dout.w);
-    const long t = s / dout.w;
-    const int yo = (int)(t % dout.h), zo = (int)(t / dout.h);
-    const float* src = y.p + vidx(y, n, c, zo * pz, yo * py, xo * px);
+  const float bv = HAS_BIAS ? bias[c] : 0.f;
+  const float* ybase = y.p + (long)n * y.sn + (long)c * y.sc;
+  float* obase = out.p + (long)n * out.sn + (long)c * out.sc;
+  for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
+    const unsigned t = fdiv(s, dw);
+    const unsigned xo = s - t * out.w;
+    const unsigned zo = fdiv(t, dh);
+    const unsigned yo = t - zo * out.h;
+    const float* src = ybase + (long)(zo * pz) * y.sd + (long)(yo * py) * y.sh + xo * px;
     float m = src[0];
     for (int a = 0; a < pz; ++a)
       for (int b = 0; b < py; ++b) {
         const float* row = src + a * y.sd + b * y.sh;
         for (int e = 0; e < px; ++e) m = fmaxf(m, row[e]);
       }
-    g = dout.p[vidx(dout, n, c, zo, yo, xo)];
+    float v = m + bv;
+    if (act == E2_ACT_RELU) v = fmaxf(v, 0.f);
+    obase[(long)zo * out.sd + (long)yo * out.sh + xo] = v;
+  }
+}
+
+// backward: dy[window] = (y == max) ? dout * act'(max + b) : 0 ; dbias += sum
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(View5 dout, View5 y,
+                                                       const float* __restrict__ bias, int pz,
+                                                       int py, int px, int act, View5 dy,
+                                                       float* __restrict__ dbias,
+                                                       int accumulate, FastDiv dw,
+                                                       FastDiv dh, unsigned chunk) {
+  __shared__ float red[4];
+  const unsigned S = (unsigned)dout.d * dout.h * dout.w;
+  const unsigned s0 = blockIdx.x * chunk;
+  const unsigned s1 = min(s0 + chunk, S);
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float bv = HAS_BIAS ? bias[c] : 0.f;
+  const float* ybase = y.p + (long)n * y.sn + (long)c * y.sc;
+  const float* gbase = dout.p + (long)n * dout.sn + (long)c * dout.sc;
+  float* dbase = dy.p + (long)n * dy.sn + (long)c * dy.sc;
+  float gsum = 0.f;
+  for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
+    const unsigned t = fdiv(s, dw);
+    const unsigned xo = s - t * dout.w;
+    const unsigned zo = fdiv(t, dh);
+    const unsigned yo = t - zo * dout.h;
+    const float* src = ybase + (long)(zo * pz) * y.sd + (long)(yo * py) * y.sh + xo * px;
+    float m = src[0];
+    for (int a = 0; a < pz; ++a)
+      for (int b = 0; b < py; ++b) {
+        const float* row = src + a * y.sd + b * y.sh;
+        for (int e = 0; e < px; ++e) m = fmaxf(m, row[e]);
+      }
+    float g = gbase[(long)zo * dout.sd + (long)yo * dout.sh + xo];
     if (act == E2_ACT_RELU) {
-      const float pre = HAS_BIAS ? (m + bias[c]) : m;
+      const float pre = m + bv;
       g *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
     }
-    float* dst = dy.p + vidx(dy, n, c, zo * pz, yo * py, xo * px);
+    gsum += g;
+    float* dst = dbase + (long)(zo * pz) * dy.sd + (long)(yo * py) * dy.sh + xo * px;
     for (int a = 0; a < pz; ++a)
       for (int b = 0; b < py; ++b) {
         const float* row = src + a * y.sd + b * y.sh;
@@ -136,7 +176,7 @@ __global__ void pool_bwd_kernel(View5 dout, View5 y, const float* __restrict__ b
       }
   }
   if (dbias != nullptr) {
-    const float tot = block_sum256(g, red);
+    const float tot = block_sum256(gsum, red);
     if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(dbias + c, tot);
   }
 }
@@ -367,6 +407,20 @@ static dim3 grid_for(const View5& v) {
   const long S = (long)v.d * v.h * v.w;
   return dim3((unsigned)((S + 255) / 256), (unsigned)v.c, (unsigned)v.n);
 }
+// outputs per work-group: enough groups to fill the chip (>= ~2048), at most
+// 4096 per group so that per-channel reductions need few atomics
+static unsigned pw_chunk(const View5& v) {
+  const long S = (long)v.d * v.h * v.w;
+  long per = (S * v.c * v.n) / 2048;
+  per = ((per + 255) / 256) * 256;
+  if (per < 256) per = 256;
+  if (per > 4096) per = 4096;
+  return (unsigned)per;
+}
+static dim3 grid_chunked(const View5& v, unsigned chunk) {
+  const long S = (long)v.d * v.h * v.w;
+  return dim3((unsigned)((S + chunk - 1) / chunk), (unsigned)v.c, (unsigned)v.n);
+}
 
 int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
   if (int rc = check_view(t, "fill_view")) return rc;
@@ -423,12 +477,15 @@ extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const floa
   if (int rc = pool_shapes_ok(y, out, pz, py, px, "pool_bias_act_fwd")) return rc;
   E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "pool_bias_act_fwd: bad act %d", act);
   View5 vy = mk(y), vo = mk(out);
+  E2_REQUIRE((long)vo.d * vo.h * vo.w < (1L << 31), "pool_bias_act_fwd: channel too large");
+  const FastDiv dw = mk_div(vo.w), dh = mk_div(vo.h);
+  const unsigned chunk = pw_chunk(vo);
   if (bias)
-    hipLaunchKernelGGL((pool_fwd_kernel<true>), grid_for(vo), dim3(256), 0, ctx->stream, vy,
-                       bias, pz, py, px, act, vo);
+    hipLaunchKernelGGL((pool_fwd_kernel<true>), grid_chunked(vo, chunk), dim3(256), 0,
+                       ctx->stream, vy, bias, pz, py, px, act, vo, dw, dh, chunk);
   else
-    hipLaunchKernelGGL((pool_fwd_kernel<false>), grid_for(vo), dim3(256), 0, ctx->stream,
-                       vy, bias, pz, py, px, act, vo);
+    hipLaunchKernelGGL((pool_fwd_kernel<false>), grid_chunked(vo, chunk), dim3(256), 0,
+                       ctx->stream, vy, bias, pz, py, px, act, vo, dw, dh, chunk);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -447,12 +504,17 @@ static int pool_bwd_common(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5
     if (int rc = e2i_fill_view(ctx, dy, 0.f)) return rc;
   }
   View5 vd = mk(dout), vy = mk(y), vdy = mk(dy);
+  E2_REQUIRE((long)vd.d * vd.h * vd.w < (1L << 31), "pool_bwd: channel too large");
+  const FastDiv dw = mk_div(vd.w), dh = mk_div(vd.h);
+  const unsigned chunk = pw_chunk(vd);
   if (bias)
-    hipLaunchKernelGGL((pool_bwd_kernel<true>), grid_for(vd), dim3(256), 0, ctx->stream, vd,
-                       vy, bias, pz, py, px, act, vdy, dbias, accumulate);
+    hipLaunchKernelGGL((pool_bwd_kernel<true>), grid_chunked(vd, chunk), dim3(256), 0,
+                       ctx->stream, vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate, dw,
+                       dh, chunk);
   else
-    hipLaunchKernelGGL((pool_bwd_kernel<false>), grid_for(vd), dim3(256), 0, ctx->stream,
-                       vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate);
+    hipLaunchKernelGGL((pool_bwd_kernel<false>), grid_chunked(vd, chunk), dim3(256), 0,
+                       ctx->stream, vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate, dw,
+                       dh, chunk);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

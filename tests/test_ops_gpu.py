@@ -93,7 +93,7 @@ def test_conv3d_fwd_forced_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
-@pytest.mark.parametrize("force", ["1,1,1,64,3", "2,2,1,128,5", "3,4,1,64,2", "4,1,4,256,7",
+@pytest.mark.parametrize("force", ["1,1,1,64,3", "2,2,1,128,5", "3,4,1,64,2", "4,1,4,128,7",
                                    "5,2,1,64,1", "7,4,1,128,3", "1,1,4,64,2", "7,1,1,64,4"])
 def test_conv3d_wgrad_forced_tilings(ctx, force):
     rng = np.random.RandomState(8)
