@@ -1,0 +1,168 @@
+"""Empirical tiling selection for the conv kernels.
+
+The analytic cost models inside libe2hip.so pick a valid tiling; this module
+refines the choice per problem by timing a short list of candidates on the GPU
+(HIP events on the context's stream) the first time a problem is seen -- the
+moral equivalent of the seconds Theano spent in ``theano.function`` compile
+(graphutils.py:376-387), here it is ~20 ms per layer.  Results are cached in
+the process and in ``$E2HIP_TUNE_CACHE`` (default ~/.cache/e2hip_tune.json);
+``elektronn2_amd/tuned.json`` ships the choices for the BASELINE workloads.
+
+Tilings are passed to the library through the E2_IGEMM_FORCE / E2_WGRAD_FORCE
+environment overrides, which the library reads at every launch; a launch
+captured into a hipGraph keeps whatever tiling was active at capture time.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+from .backend import E2Error
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SHIPPED = os.path.join(_HERE, "tuned.json")
+_cache = None
+_dirty = False
+IGEMM_MTS = [1, 2, 3, 4, 5, 6, 7, 8, 10, 13]
+WGRAD_MTS = [1, 2, 3, 4, 5, 7]
+
+
+def _cache_path():
+    return os.environ.get("E2HIP_TUNE_CACHE",
+                          os.path.join(os.path.expanduser("~"), ".cache", "e2hip_tune.json"))
+
+
+def _load():
+    global _cache
+    if _cache is None:
+        _cache = {}
+        for path in (_SHIPPED, _cache_path()):
+            try:
+                with open(path) as f:
+                    _cache.update(json.load(f))
+            except Exception:
+                pass
+    return _cache
+
+
+def save():
+    global _dirty
+    if not _dirty:
+        return
+    try:
+        os.makedirs(os.path.dirname(_cache_path()), exist_ok=True)
+        with open(_cache_path(), "w") as f:
+            json.dump(_cache, f, indent=0, sort_keys=True)
+        _dirty = False
+    except Exception:
+        pass
+
+
+def enabled():
+    return os.environ.get("E2HIP_AUTOTUNE", "1") != "0"
+
+
+def _best_mts(mblocks, options, keep=3):
+    """tile heights with the least padding, larger first on ties"""
+    scored = []
+    for mt in options:
+        if mt > mblocks and mt != 1:
+            continue
+        n = -(-mblocks // mt)
+        scored.append((n * mt, -mt, mt))
+    scored.sort()
+    return [s[2] for s in scored[:keep]]
+
+
+def igemm_candidates(cout, cin, k, out_sp):
+    mblocks = -(-cout // 16)
+    q = out_sp[1] * out_sp[2]
+    cands = []
+    cinp = -(-cin // 4) * 4
+    ccs = sorted(set(c for c in (4, 8, 16, 32, cinp) if c <= max(cinp, 4) and c <= 32))
+    for mt in _best_mts(mblocks, IGEMM_MTS, keep=4):
+        nmt = -(-mblocks // mt)
+        for nt in (1, 2):
+            base = out_sp[0] * (-(-q // (64 * nt))) * nmt
+            sks = (1,) if base >= 200 else (1, 2, 4)
+            for cc in ccs:
+                for sk in sks:
+                    cands.append("%d,%d,%d,%d" % (mt, nt, cc, sk))
+    return cands
+
+
+def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
+    mblocks = -(-cout // 16)
+    T = k[0] * k[1] * k[2]
+    nblocks = -(-(cin * T) // 16)
+    q = out_sp[1] * out_sp[2]
+    cands = []
+    for mt in _best_mts(mblocks, WGRAD_MTS, keep=3):
+        nmt = -(-mblocks // mt)
+        variants = [(1, 1), (2, 1), (4, 1)]
+        if nblocks <= 2:
+            variants = [(1, 4), (1, 1)]
+        for nt, wk in variants:
+            wn = 4 // wk
+            if nt > 1 and 16 * nt * wn > 16 * nblocks:
+                continue
+            nnt = -(-nblocks // (nt * wn))
+            for bp in (64, 128):
+                tiles = out_sp[0] * (-(-q // bp))
+                for fill in (1, 2, 4):
+                    ps = max(1, min(tiles, (n_cu * fill) // max(1, nmt * nnt)))
+                    cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, ps))
+    return sorted(set(cands))
+
+
+def _time(ctx, fn, iters=4):
+    fn()
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0)
+    for _ in range(iters):
+        fn()
+    ctx.record(e1)
+    return ctx.elapsed_ms(e0, e1) / iters
+
+
+def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True):
+    """Run ``fn`` with the best known tiling for (kind, sig); tune on first sight.
+    kind: 'igemm' | 'wgrad'.  Returns the tiling string used (or None)."""
+    global _dirty
+    env = "E2_IGEMM_FORCE" if kind == "igemm" else "E2_WGRAD_FORCE"
+    key = "%s|%s" % (kind, ",".join(str(int(v)) for v in sig))
+    cache = _load()
+    best = cache.get(key)
+    if best is None and enabled() and allow_tune:
+        old = os.environ.pop(env, None)
+        try:
+            results = []
+            try:
+                t = _time(ctx, fn)
+                results.append((t, ""))
+            except E2Error:
+                pass
+            for c in cands:
+                os.environ[env] = c
+                try:
+                    results.append((_time(ctx, fn), c))
+                except E2Error:
+                    continue
+            os.environ.pop(env, None)
+            if results:
+                results.sort()
+                best = results[0][1]
+                cache[key] = best
+                _dirty = True
+        finally:
+            if old is not None:
+                os.environ[env] = old
+    if best:
+        os.environ[env] = best
+        try:
+            fn()
+        finally:
+            os.environ.pop(env, None)
+    else:
+        fn()
+    return best

@@ -31,11 +31,18 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->stream = nullptr;
   c->num_cu = prop.multiProcessorCount;
   c->capturing = false;
+  c->zeros = nullptr;
+  if (hipMalloc(&c->zeros, 1024) != hipSuccess || hipMemset(c->zeros, 0, 1024) != hipSuccess) {
+    delete c;
+    e2_set_error("e2_ctx_create: cannot allocate the zero page");
+    return 1;
+  }
   *out = c;
   return 0;
 }
 
 extern "C" int e2_ctx_destroy(e2_ctx* ctx) {
+  if (ctx && ctx->zeros) (void)hipFree(ctx->zeros);
   delete ctx;
   return 0;
 }

@@ -11,6 +11,7 @@ struct e2_ctx {
   hipStream_t stream;
   int num_cu;
   bool capturing;
+  float* zeros;        // 1 KiB of zeros in device memory (masked-lane DMA source)
 };
 
 void e2_set_error(const char* fmt, ...);

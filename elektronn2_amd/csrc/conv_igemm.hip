@@ -99,6 +99,18 @@ struct GroupRegs {
     load_a(addrA, std::make_integer_sequence<int, KW * MT>{});
     load_b(addrB, std::make_integer_sequence<int, NT>{});
   }
+  // keep every asm-load destination allocated until the s_waitcnt that retires
+  // the loads: a destination that is never read again (prefetch past the end of
+  // a chunk) could otherwise be reused while its LDS data is still in flight.
+  __device__ __forceinline__ void touch() {
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb) asm volatile("" : "+v"(a[t][mb]));
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) asm volatile("" : "+v"(b[t][nb]));
+    }
+  }
 };
 
 constexpr int igemm_bmpad(int MT) {          // row stride == 16 (mod 32)
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       g0.load(addrA, addrB);
       E2_WAIT()
+      g0.touch();
       int g = 0;
       for (; g + 1 < nG; g += 2) {
         E2_NEXT()
@@ -256,12 +269,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
         E2_MFMA(g0)                       // ... while group g computes
         __builtin_amdgcn_sched_barrier(0);
         E2_WAIT()
+        g1.touch();
         E2_NEXT()
         g0.load(addrA, addrB);            // group g+2 (past the end: reads slack)
         __builtin_amdgcn_sched_barrier(0);
         E2_MFMA(g1)
         __builtin_amdgcn_sched_barrier(0);
         E2_WAIT()
+        g0.touch();
       }
       if (g < nG) { E2_MFMA(g0) }
 #undef E2_NEXT
@@ -412,8 +427,10 @@ static int pad16mod32(int v) {          // smallest s >= v with s % 32 == 16
 
 static int span_rows(int BN, int Wo) { return (BN + Wo - 2) / Wo; }
 
+// exact upper bound of the span length of a BN-position tile:
+// L = (q_last - q_first) + rows_crossed*(isY - Wo) + (kh-1)*isY + kw
 static int span_lmax(const IgemmArgs& a, int BN) {
-  return (span_rows(BN, a.Wo) + a.kh - 1) * (int)a.isY + a.kw + a.Wo;
+  return (BN - 1) + span_rows(BN, a.Wo) * ((int)a.isY - a.Wo) + (a.kh - 1) * (int)a.isY + a.kw;
 }
 // LDS-DMA writes whole 256-float pieces (16 B per lane): rows hold a multiple of 256
 static int span_lpad(const IgemmArgs& a, int BN) {

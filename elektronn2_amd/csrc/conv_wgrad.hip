@@ -74,6 +74,7 @@ __device__ __forceinline__ unsigned fdivw(unsigned n, const FastDivW& f) {
 struct WgradP {
   const float* x;
   const float* dy;
+  const float* zeros;     // >= 64 zero floats in global memory
   float* dw;
   int Cin, Cout, kd, kh, kw, T, THW;
   int Do, Ho, Wo, Q;
@@ -101,6 +102,21 @@ struct QuadRegs {
   template <int... I>
   __device__ __forceinline__ void load_a(unsigned addr, std::integer_sequence<int, I...>) {
     ((a[I / MT][I % MT] = w_lds_ld<((I % MT) * 16 * DLPAD + (I / MT) * 4) * 4>(addr)), ...);
+  }
+  // The asm loads are invisible to the register allocator's liveness of IN-FLIGHT
+  // data: a destination that is never read again (the prefetch past the end of a
+  // tile) could be handed to another value while the LDS data is still on its
+  // way.  touch() after the s_waitcnt keeps every destination allocated until
+  // the data has landed (cdna guide 5.7: "may reuse it before the data lands").
+  __device__ __forceinline__ void touch() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb) asm volatile("" : "+v"(a[j][mb]));
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) asm volatile("" : "+v"(b[j][nb]));
+    }
+    asm volatile("" : "+v"(io));
   }
   __device__ __forceinline__ void load(unsigned addrA, unsigned addrT, unsigned xbase,
                                        const int (&lanebase)[NT], const i32x4& cur_io) {
@@ -181,7 +197,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     const int rl = (int)fdivw(qlast, p.divWo), cl = qlast - rl * p.Wo;
     const long span_lo = (long)r0 * p.xsY + c0;
     const int L = (rl - r0) * xsY + (cl - c0) + (p.kh - 1) * xsY + p.kw;
-    const bool partial = (qlast - q0 + 1) < BP;
     // dy rows: lane <-> position (64 positions per DMA instruction)
     const float* dyb = p.dy + (long)n * p.dsN + (long)z * p.dsZ;
 #pragma unroll
@@ -196,12 +211,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
       const float* src = dyb + (long)r * p.dsY + c;
       for (int co = wave; co < BM; co += 4) {
         float* dst = dyl + co * DLPAD + 64 * j;
-        if (partial) {                       // invalid positions must contribute 0
-          dst[lane] = 0.f;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
         const int cg = min(m0 + co, p.Cout - 1);
-        if (valid) w_glds4(src + (long)cg * p.dsC, dst);
+        // invalid positions must contribute 0
+        if (p.dbg & 32) w_glds4(valid ? src + (long)cg * p.dsC : p.zeros, dst);
+        else dst[lane] = valid ? src[(long)cg * p.dsC] : 0.f;
       }
     }
     // input spans, 16 B per lane; the tensor's very last row goes by dwords
@@ -247,9 +260,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     // first quad of this wave: its offsets, then its operands
     i32x4 io0 = w_lds_ld128(addrT);
     E2_WAIT()
+    asm volatile("" : "+v"(io0));
     addrT += 16u * WK;
     g0.load(addrA, addrT, xbase, lanebase, io0);   // also fetches the offsets of the next quad
     E2_WAIT()
+    g0.touch();
     constexpr int NQW = NQ / WK;                   // quads per wave
     int q = 0;
     for (; q + 1 < NQW; q += 2) {
@@ -259,12 +274,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
       E2_MFMA(g0)
       __builtin_amdgcn_sched_barrier(0);
       E2_WAIT()
+      g1.touch();
       addrA += 64u * WK; addrT += 16u * WK;
       g0.load(addrA, addrT, xbase, lanebase, g1.io);   // past the end: reads slack
       __builtin_amdgcn_sched_barrier(0);
       E2_MFMA(g1)
       __builtin_amdgcn_sched_barrier(0);
       E2_WAIT()
+      g0.touch();
     }
     if (q < NQW) { E2_MFMA(g0) }
 #undef E2_MFMA
@@ -360,8 +377,8 @@ static int w_lpad(int Lmax) {
   return ((Lmax + 63) / 64) * 64 + 2;    // whole 64-float DMA pieces, == 2 (mod 4)
 }
 static int w_lmax(const WgradArgs& a, int BP) {
-  const int rows = (BP + a.Wo - 2) / a.Wo;
-  return (rows + a.kh - 1) * (int)a.xsY + a.kw + a.Wo;
+  const int rows = (BP + a.Wo - 2) / a.Wo;      // rows crossed by BP consecutive positions
+  return (BP - 1) + rows * ((int)a.xsY - a.Wo) + (a.kh - 1) * (int)a.xsY + a.kw;
 }
 static int w_maxspans(const WgradArgs& a, int BNn) {
   const int T = a.kd * a.kh * a.kw;
@@ -451,6 +468,7 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   E2_REQUIRE(c.WK == 1 || (c.WK == 4 && c.NT == 1), "wgrad: WK=4 needs NT=1");
   WgradP p;
   p.x = a.x; p.dy = a.dy; p.dw = a.dw;
+  p.zeros = ctx->zeros;
   p.Cin = a.Cin; p.Cout = a.Cout; p.kd = a.kd; p.kh = a.kh; p.kw = a.kw;
   p.THW = a.kh * a.kw; p.T = a.kd * p.THW;
   p.Do = a.Do; p.Ho = a.Ho; p.Wo = a.Wo; p.Q = a.Ho * a.Wo;
@@ -475,7 +493,8 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   p.N = a.N;
   p.divWo = mk_divw((unsigned)a.Wo);
   p.dbg = getenv("E2_WGRAD_DBG") ? atoi(getenv("E2_WGRAD_DBG")) : 0;
-  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  size_t lds = 2 * (size_t)p.bufFloats * 4;
+  if (getenv("E2_WGRAD_LDSPAD")) lds += (size_t)atoi(getenv("E2_WGRAD_LDSPAD"));
   E2_REQUIRE(lds <= 160 * 1024, "wgrad: tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");

@@ -19,6 +19,7 @@ import logging
 import numpy as np
 
 from .graphutils import floatX
+from .. import autotune
 from .node_basic import Node, Concat, Add, Sym
 from .variables import VariableWeight, ConstantParam, VariableParam
 
@@ -272,7 +273,12 @@ class Conv(NeuralLayer):
         y = plan.scratch[self, 'y']
         wp = plan.scratch[self, 'wp_f']
         ctx.conv3d_pack(plan.param(self.w), 0, wp)
-        ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y)
+        cin = self.parent.shape['f']
+        sig = (0, self.n_f, cin) + tuple(self.filter_shape) + tuple(y.shape[2:]) + \
+            (x.stride(3),)
+        plan.tuned('igemm', sig,
+                   autotune.igemm_candidates(self.n_f, cin, self.filter_shape, y.shape[2:]),
+                   lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y))
         ctx.pool_bias_act_fwd(y, plan.param(self.b), self.pool_shape, self.activation_func,
                               plan.out[self])
 
@@ -283,20 +289,27 @@ class Conv(NeuralLayer):
         dy = plan.scratch[self, 'dy']
         ctx.pool_bias_act_bwd(plan.grad[self], y, plan.param(self.b), self.pool_shape,
                               self.activation_func, dy, plan.pgrad(self.b))
-        ctx.conv3d_wgrad(x, dy, plan.pgrad(self.w))
+        cin = self.parent.shape['f']
+        dw = plan.pgrad(self.w)
+        sigw = (self.n_f, cin) + tuple(self.filter_shape) + tuple(dy.shape[2:]) + \
+            (x.stride(3), dy.stride(3))
+        plan.tuned('wgrad', sigw,
+                   autotune.wgrad_candidates(self.n_f, cin, self.filter_shape, dy.shape[2:]),
+                   lambda: ctx.conv3d_wgrad(x, dy, dw))
         if plan.needs_grad(self.parent):
             wp = plan.scratch[self, 'wp_d']
             ctx.conv3d_pack(plan.param(self.w), 1, wp)
-            cin = self.parent.shape['f']
+            dyp = plan.scratch[self, 'dy_pad']
             dst, first = plan.grad_slot(self.parent)
-            if first:
-                ctx.conv3d_dgrad_packed(plan.scratch[self, 'dy_pad'], wp, cin,
-                                        self.filter_shape, dst)
-            else:
-                tmp = plan.tmp_like(dst)
-                ctx.conv3d_dgrad_packed(plan.scratch[self, 'dy_pad'], wp, cin,
-                                        self.filter_shape, tmp)
-                ctx.copy5(tmp, dst, accumulate=True)
+            out = dst if first else plan.tmp_like(dst)
+            sig = (1, cin, self.n_f) + tuple(self.filter_shape) + tuple(out.shape[2:]) + \
+                (dyp.stride(3),)
+            plan.tuned('igemm', sig,
+                       autotune.igemm_candidates(cin, self.n_f, self.filter_shape,
+                                                 out.shape[2:]),
+                       lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self.filter_shape, out))
+            if not first:
+                ctx.copy5(out, dst, accumulate=True)
 
 
 class UpConv(Conv):

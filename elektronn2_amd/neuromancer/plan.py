@@ -118,6 +118,12 @@ class Plan(object):
     def pgrad(self, p):
         return self.model.device_grad(p)
 
+    def tuned(self, kind, sig, cands, fn):
+        """launch a conv kernel with its autotuned tiling (tunes on first sight,
+        never while a hipGraph capture is in progress)."""
+        from .. import autotune
+        autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing)
+
     # ---- gradient routing ----------------------------------------------------------
     def grad_slot(self, node):
         """(buffer, first): first == True -> the caller must OVERWRITE it."""
@@ -150,6 +156,7 @@ class Plan(object):
             for n in self.nodes:
                 n._plan_alloc(self)
         self._graphs = None
+        self._capturing = False
         self._calls = 0
         self._grad_written = set()
         self._ev0, self._ev1 = self.ctx.event(), self.ctx.event()
@@ -178,6 +185,7 @@ class Plan(object):
         capture = self.use_graph and self._calls >= 1
         if capture and self._graphs is None:
             graphs = []
+            self._capturing = True
             ctx.graph_begin()
             self._emit_forward()
             if self.training:
@@ -189,7 +197,10 @@ class Plan(object):
                 ctx.graph_begin()
                 self._emit_update()
                 graphs.append(ctx.graph_end())
+            self._capturing = False
             self._graphs = graphs
+            from .. import autotune
+            autotune.save()
         ctx.record(self._ev0)
         if capture:
             ctx.graph_launch(self._graphs[0])

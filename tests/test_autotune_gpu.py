@@ -1,0 +1,82 @@
+"""GPU: every tiling the autotuner may pick must be numerically right -- each
+candidate of every op is run on small problems and compared with the oracle
+(a wrong-but-fast tiling would otherwise be SELECTED by the tuner)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import e2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PROBLEMS = [  # cin, cout, kernel, input spatial
+    (20, 40, (3, 3, 3), (7, 22, 22)),
+    (150, 200, (1, 3, 3), (2, 11, 12)),
+    (1, 20, (1, 4, 4), (3, 21, 23)),
+    (200, 2, (1, 1, 1), (2, 9, 10)),
+    (40, 150, (2, 4, 4), (3, 12, 13)),
+    (30, 40, (1, 5, 5), (1, 20, 21)),
+]
+
+
+def rel(a, b):
+    return float(np.abs(a.detach().cpu().numpy() - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize("prob", PROBLEMS, ids=lambda p: "%d-%d_k%s" % (p[0], p[1], "".join(map(str, p[2]))))
+def test_every_candidate_tiling_is_correct(ctx, prob):
+    from elektronn2_amd import autotune, backend
+    cin, cout, k, sp = prob
+    rng = np.random.RandomState(0)
+    x = rng.rand(1, cin, *sp).astype(np.float32)
+    w = (rng.randn(cout, cin, *k) / 10).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dw_ref = O.conv3d_wgrad(dy, x, w.shape)
+    dx_ref = O.conv3d_dgrad(dy, w, x.shape)
+    xd, wd = torch.tensor(x).cuda(), torch.tensor(w).cuda()
+    pad = [kk - 1 for kk in k]
+    osp = y_ref.shape[2:]
+    dyp = torch.zeros(1, cout, *[osp[i] + 2 * pad[i] for i in range(3)], device="cuda")
+    inner = dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]]
+    inner.copy_(torch.tensor(dy).cuda())
+    bad, ran = [], 0
+    try:
+        for c in autotune.wgrad_candidates(cout, cin, k, osp):
+            os.environ["E2_WGRAD_FORCE"] = c
+            dw = torch.full(w.shape, float("nan"), device="cuda")
+            try:
+                ctx.conv3d_wgrad(xd, inner, dw)
+            except backend.E2Error:
+                continue
+            ran += 1
+            if not rel(dw, dw_ref) < 2e-5:
+                bad.append(("wgrad", c))
+        os.environ.pop("E2_WGRAD_FORCE", None)
+        for c in autotune.igemm_candidates(cout, cin, k, osp):
+            os.environ["E2_IGEMM_FORCE"] = c
+            y = torch.full(y_ref.shape, float("nan"), device="cuda")
+            try:
+                ctx.conv3d_fwd(xd, wd, y)
+            except backend.E2Error:
+                continue
+            ran += 1
+            if not rel(y, y_ref) < 2e-5:
+                bad.append(("fwd", c))
+        for c in autotune.igemm_candidates(cin, cout, k, sp):
+            os.environ["E2_IGEMM_FORCE"] = c
+            dx = torch.full(x.shape, float("nan"), device="cuda")
+            try:
+                ctx.conv3d_dgrad(dyp, wd, dx)
+            except backend.E2Error:
+                continue
+            ran += 1
+            if not rel(dx, dx_ref) < 2e-5:
+                bad.append(("dgrad", c))
+    finally:
+        os.environ.pop("E2_WGRAD_FORCE", None)
+        os.environ.pop("E2_IGEMM_FORCE", None)
+    assert ran > 20
+    assert not bad, bad
