@@ -56,6 +56,9 @@ def _load():
         "e2_conv3d_fwd_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_dgrad_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_wgrad": (C.c_int, [vp, P5, P5, fp, i, i, i]),
+        "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
+        "e2_conv1_pool_act_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5]),
+        "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp]),
         "e2_pool_bias_act_fwd": (C.c_int, [vp, P5, fp, i, i, i, i, P5]),
         "e2_pool_bias_act_bwd": (C.c_int, [vp, P5, P5, fp, i, i, i, i, P5, fp]),
         "e2_maxpool3d_fwd": (C.c_int, [vp, P5, i, i, i, P5]),
@@ -196,6 +199,22 @@ class Context:
         kd, kh, kw = dw.shape[2:]
         _chk(_lib.e2_conv3d_wgrad(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw),
                                   kd, kh, kw), "e2_conv3d_wgrad")
+
+    # ---- fused first layer ----------------------------------------------------
+    @staticmethod
+    def conv1_supported(cin, k, pool):
+        return bool(_lib.e2_conv1_supported(cin, k[0], k[1], k[2], pool[0], pool[1], pool[2]))
+
+    def conv1_pool_act_fwd(self, x, w, bias, pool, act, out):
+        _chk(_lib.e2_conv1_pool_act_fwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias), w.shape[0],
+                                        w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
+                                        C.byref(t5(out))), "e2_conv1_pool_act_fwd")
+
+    def conv1_pool_act_bwd(self, x, w, bias, dout, pool, act, dw, dbias):
+        _chk(_lib.e2_conv1_pool_act_bwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias),
+                                        C.byref(t5(dout)), w.shape[3], w.shape[4], pool[1],
+                                        pool[2], ACT[act], _fp(dw), _fp(dbias)),
+             "e2_conv1_pool_act_bwd")
 
     # ---- pool / bias / act ---------------------------------------------------
     def pool_bias_act_fwd(self, y, bias, pool, act, out):

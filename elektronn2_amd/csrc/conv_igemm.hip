@@ -30,6 +30,9 @@
 // LDS rows are padded so that rows qd and qd+1 sit 16 banks apart
 // (stride == 16 mod 32): ds_read_b32 of a 32-lane half is conflict free.
 #include "common.hpp"
+#ifndef E2_INTERLEAVE
+#define E2_INTERLEAVE 1
+#endif
 #include <stdlib.h>
 #include <algorithm>
 #include <utility>
@@ -112,6 +115,49 @@ struct GroupRegs {
     }
   }
 };
+
+// One group step, hand-scheduled: MFMA i of the CURRENT group, then LDS reads
+// [R0, R1) of the NEXT group.  The reads are spread over the first ~3/4 of the
+// MFMAs: a wave may have at most 15 LDS operations outstanding (lgkmcnt is 4
+// bits), so a burst of KW*(MT+NT) reads stalls the wave -- and the matrix pipe
+// behind it -- while 1-2 reads per 32-cycle MFMA slot are free.
+template <int MT, int NT, int KW, int ASTRIDE, int R>
+__device__ __forceinline__ void group_read(GroupRegs<MT, NT, KW, ASTRIDE>& g, unsigned addrA,
+                                           const unsigned (&addrB)[NT]) {
+  constexpr int tx = R / (MT + NT), k = R % (MT + NT);
+  if constexpr (k < MT) g.a[tx][k] = lds_ld<tx * ASTRIDE + k * 64>(addrA);
+  else g.b[tx][k - MT] = lds_ld<tx * 4>(addrB[k - MT]);
+}
+template <int MT, int NT, int KW, int ASTRIDE, int R0, int R1>
+__device__ __forceinline__ void group_reads(GroupRegs<MT, NT, KW, ASTRIDE>& g, unsigned addrA,
+                                            const unsigned (&addrB)[NT]) {
+  if constexpr (R0 < R1) {
+    group_read<MT, NT, KW, ASTRIDE, R0>(g, addrA, addrB);
+    group_reads<MT, NT, KW, ASTRIDE, R0 + 1, R1>(g, addrA, addrB);
+  }
+}
+template <int MT, int NT, int KW, int ASTRIDE, int I>
+__device__ __forceinline__ void group_steps(const GroupRegs<MT, NT, KW, ASTRIDE>& cur,
+                                            GroupRegs<MT, NT, KW, ASTRIDE>& nxt, f32x4 (&acc)[MT][NT],
+                                            unsigned addrA, const unsigned (&addrB)[NT]) {
+  constexpr int M = KW * MT * NT, R = KW * (MT + NT);
+  constexpr int tx = I / (MT * NT), mb = (I / NT) % MT, nb = I % NT;
+  acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[tx][mb], cur.b[tx][nb], acc[mb][nb],
+                                                     0, 0, 0);
+  constexpr int r0 = (I * R * 4) / (3 * M) < R ? (I * R * 4) / (3 * M) : R;
+  constexpr int r1 = ((I + 1) * R * 4) / (3 * M) < R ? ((I + 1) * R * 4) / (3 * M) : R;
+  group_reads<MT, NT, KW, ASTRIDE, r0, r1>(nxt, addrA, addrB);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (I + 1 < M) group_steps<MT, NT, KW, ASTRIDE, I + 1>(cur, nxt, acc, addrA, addrB);
+}
+template <int MT, int NT, int KW, int ASTRIDE, int I>
+__device__ __forceinline__ void group_mfma_only(const GroupRegs<MT, NT, KW, ASTRIDE>& cur,
+                                                f32x4 (&acc)[MT][NT]) {
+  constexpr int tx = I / (MT * NT), mb = (I / NT) % MT, nb = I % NT;
+  acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[tx][mb], cur.b[tx][nb], acc[mb][nb],
+                                                     0, 0, 0);
+  if constexpr (I + 1 < KW * MT * NT) group_mfma_only<MT, NT, KW, ASTRIDE, I + 1>(cur, acc);
+}
 
 constexpr int igemm_bmpad(int MT) {          // row stride == 16 (mod 32)
   return ((16 * MT) & 31) == 16 ? 16 * MT : 16 * MT + 16;
@@ -264,6 +310,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
       int g = 0;
       for (; g + 1 < nG; g += 2) {
         E2_NEXT()
+#if E2_INTERLEAVE
+        __builtin_amdgcn_sched_barrier(0);
+        group_steps<MT, NT, KW, ASTR, 0>(g0, g1, acc, addrA, addrB);   // compute g, fetch g+1
+        E2_WAIT()
+        g1.touch();
+        E2_NEXT()
+        __builtin_amdgcn_sched_barrier(0);
+        group_steps<MT, NT, KW, ASTR, 0>(g1, g0, acc, addrA, addrB);   // past the end: slack
+        E2_WAIT()
+        g0.touch();
+#else
         g1.load(addrA, addrB);            // group g+1 in flight ...
         __builtin_amdgcn_sched_barrier(0);
         E2_MFMA(g0)                       // ... while group g computes
@@ -277,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmP p) {
         __builtin_amdgcn_sched_barrier(0);
         E2_WAIT()
         g0.touch();
+#endif
       }
       if (g < nG) { E2_MFMA(g0) }
 #undef E2_NEXT

@@ -248,10 +248,20 @@ class Conv(NeuralLayer):
         return UpConv(parent, self.parent.shape['f'], self.pool_shape, **defaults)
 
     # ---- device execution ------------------------------------------------------------
+    def _fused_first(self, plan):
+        """Cin = 1 first layer with a supported kernel/pool: fused conv+pool+bias+act
+        kernels that never materialise the conv output (csrc/conv_first.hip)."""
+        return (self.parent.is_source and self.parent.shape['f'] == 1 and
+                plan.ctx.conv1_supported(1, self.filter_shape, self.pool_shape) and
+                not plan.needs_grad(self.parent))
+
     def _plan_alloc(self, plan):
         N = plan.batch
         psp = self.parent.shape.spatial_shape
         k = self.filter_shape
+        if self._fused_first(plan):
+            plan.alloc_out(self)
+            return
         osp = [psp[i] - k[i] + 1 for i in range(3)]
         plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
         plan.alloc_out(self)
@@ -270,6 +280,10 @@ class Conv(NeuralLayer):
     def _plan_fwd(self, plan):
         ctx = plan.ctx
         x = plan.out[self.parent]
+        if self._fused_first(plan):
+            ctx.conv1_pool_act_fwd(x, plan.param(self.w), plan.param(self.b), self.pool_shape,
+                                   self.activation_func, plan.out[self])
+            return
         y = plan.scratch[self, 'y']
         wp = plan.scratch[self, 'wp_f']
         ctx.conv3d_pack(plan.param(self.w), 0, wp)
@@ -285,6 +299,11 @@ class Conv(NeuralLayer):
     def _plan_bwd(self, plan):
         ctx = plan.ctx
         x = plan.out[self.parent]
+        if self._fused_first(plan):
+            ctx.conv1_pool_act_bwd(x, plan.param(self.w), plan.param(self.b), plan.grad[self],
+                                   self.pool_shape, self.activation_func, plan.pgrad(self.w),
+                                   plan.pgrad(self.b))
+            return
         y = plan.scratch[self, 'y']
         dy = plan.scratch[self, 'dy']
         ctx.pool_bias_act_bwd(plan.grad[self], y, plan.param(self.b), self.pool_shape,

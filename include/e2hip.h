@@ -89,6 +89,20 @@ int e2_conv3d_dgrad_packed(e2_ctx*, const e2_tensor5* dy_pad, const void* wp,
 int e2_conv3d_wgrad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy,
                     float* dw, int kd, int kh, int kw);
 
+/* ---- first layer, fused (Conv node on a 1-channel input: conv -> pool -> +b ->
+ *      act in one pass; neural.py:662-712).  Supported: kd = 1, pool z = 1 and
+ *      (kh,kw,py,px) in {(4,4,2,2), (6,6,2,2)} -- the neuro3d nets' first layers;
+ *      e2_conv1_supported() tells.  The backward RECOMPUTES the conv values
+ *      instead of reading a stored conv output; dw / dbias are accumulated
+ *      (zero them first). ---------------------------------------------------- */
+int e2_conv1_supported(int cin, int kd, int kh, int kw, int pz, int py, int px);
+int e2_conv1_pool_act_fwd(e2_ctx*, const e2_tensor5* x, const float* w,
+                          const float* bias, int cout, int kh, int kw, int py,
+                          int px, int act, const e2_tensor5* out);
+int e2_conv1_pool_act_bwd(e2_ctx*, const e2_tensor5* x, const float* w,
+                          const float* bias, const e2_tensor5* dout, int kh,
+                          int kw, int py, int px, int act, float* dw, float* dbias);
+
 /* ---- pool + bias + activation  (computations.py:538-631 pooling();
  *      neural.py:705-712; computations.py:57-134 apply_activation) -------- */
 /* out = act(maxpool(y, pool) + bias[c]) ; pool == stride, floor semantics. */

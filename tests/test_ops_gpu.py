@@ -304,3 +304,24 @@ def test_graph_capture_replay(ctx):
         ctx.graph_destroy(g)
     finally:
         ctx.set_stream(old)
+
+
+@pytest.mark.parametrize("k,sp", [((1, 4, 4), (3, 23, 71)), ((1, 6, 6), (2, 25, 77)), ((1, 4, 4), (1, 19, 11))])
+def test_fused_first_layer(ctx, k, sp):
+    """csrc/conv_first.hip: conv(1 ch) -> pool(1,2,2) -> +b -> relu, fwd and bwd (recompute)."""
+    rng = np.random.RandomState(21)
+    x = rng.rand(2, 1, *sp).astype(np.float32)
+    w = (rng.randn(20, 1, *k) / 3).astype(np.float32)
+    b = (rng.randn(20) / 4).astype(np.float32)
+    pool = (1, 2, 2)
+    assert ctx.conv1_supported(1, k, pool) and not ctx.conv1_supported(2, k, pool)
+    out_ref, cache = O.conv_node_fwd(x, w, b, pool, 'relu')
+    out = torch.full(out_ref.shape, float("nan"), device="cuda")
+    ctx.conv1_pool_act_fwd(dev(x), dev(w), dev(b), pool, 'relu', out)
+    assert relerr(out, out_ref) < TOL
+    dout = rng.randn(*out_ref.shape).astype(np.float32)
+    _, dw_ref, db_ref = O.conv_node_bwd(dout, x, w, b, cache, pool, 'relu', need_dx=False)
+    dw = torch.zeros(w.shape, device="cuda"); db = torch.zeros(20, device="cuda")
+    ctx.conv1_pool_act_bwd(dev(x), dev(w), dev(b), dev(dout), pool, 'relu', dw, db)
+    assert relerr(dw, dw_ref) < TOL
+    assert relerr(db, db_ref) < TOL
