@@ -82,7 +82,9 @@ def igemm_candidates(cout, cin, k, out_sp):
     ccs = sorted(set(c for c in (4, 8, 16, 32, cinp) if c <= max(cinp, 4) and c <= 32))
     for mt in _best_mts(mblocks, IGEMM_MTS, keep=4):
         nmt = -(-mblocks // mt)
-        for nt in (1, 2):
+        for nt in (1, 2, 4):
+            if nt == 4 and mt > 5:
+                continue
             base = out_sp[0] * (-(-q // (64 * nt))) * nmt
             sks = (1,) if base >= 200 else (1, 2, 4)
             for cc in ccs:

@@ -468,11 +468,18 @@ static int dispatch(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int grid, size
     if (NT == 1) return dispatch_kw<M, 1>(ctx, p, grid, lds);               \
     if (NT == 2) return dispatch_kw<M, 2>(ctx, p, grid, lds);               \
     break;
+#define E2_CASE4(M)                                                         \
+  case M:                                                                   \
+    if (NT == 1) return dispatch_kw<M, 1>(ctx, p, grid, lds);               \
+    if (NT == 2) return dispatch_kw<M, 2>(ctx, p, grid, lds);               \
+    if (NT == 4) return dispatch_kw<M, 4>(ctx, p, grid, lds);               \
+    break;
   switch (MT) {
-    E2_CASE(1) E2_CASE(2) E2_CASE(3) E2_CASE(4) E2_CASE(5) E2_CASE(6)
+    E2_CASE4(1) E2_CASE4(2) E2_CASE4(3) E2_CASE4(4) E2_CASE4(5) E2_CASE(6)
     E2_CASE(7) E2_CASE(8) E2_CASE(10) E2_CASE(13)
   }
 #undef E2_CASE
+#undef E2_CASE4
   e2_set_error("igemm: no instance MT=%d NT=%d", MT, NT);
   return 2;
 }
@@ -520,7 +527,8 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   for (int MT : kMTs) {
     if (MT > mblocks && MT != 1) continue;
     const int nMT = e2_cdiv(mblocks, MT);
-    for (int NT = 1; NT <= 2; ++NT) {
+    for (int NT = 1; NT <= 4; NT *= 2) {
+      if (NT == 4 && MT > 5) continue;
       const int BN = 64 * NT;
       const int nPT = (int)((Q + BN - 1) / BN);
       const int cinP = ((a.Cin + 3) / 4) * 4;
