@@ -127,27 +127,33 @@ def _time(ctx, fn, iters=4):
     return ctx.elapsed_ms(e0, e1) / iters
 
 
-def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True):
+def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None):
     """Run ``fn`` with the best known tiling for (kind, sig); tune on first sight.
-    kind: 'igemm' | 'wgrad'.  Returns the tiling string used (or None)."""
+    kind: 'igemm' | 'wgrad'.  ``fn_tune`` (default ``fn``) is the IDEMPOTENT form of
+    the launch used for the timing runs (e.g. wgrad that overwrites instead of
+    accumulating); when tuning ran, the result is produced by one final
+    ``fn_tune`` call instead of ``fn``.  Returns the tiling string used."""
     global _dirty
     env = "E2_IGEMM_FORCE" if kind == "igemm" else "E2_WGRAD_FORCE"
     key = "%s|%s" % (kind, ",".join(str(int(v)) for v in sig))
     cache = _load()
     best = cache.get(key)
+    tuned_now = False
+    ft = fn_tune if fn_tune is not None else fn
     if best is None and enabled() and allow_tune:
         old = os.environ.pop(env, None)
+        tuned_now = True
         try:
             results = []
             try:
-                t = _time(ctx, fn)
+                t = _time(ctx, ft)
                 results.append((t, ""))
             except E2Error:
                 pass
             for c in cands:
                 os.environ[env] = c
                 try:
-                    results.append((_time(ctx, fn), c))
+                    results.append((_time(ctx, ft), c))
                 except E2Error:
                     continue
             os.environ.pop(env, None)
@@ -159,12 +165,13 @@ def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True):
         finally:
             if old is not None:
                 os.environ[env] = old
+    final = ft if tuned_now else fn
     if best:
         os.environ[env] = best
         try:
-            fn()
+            final()
         finally:
             os.environ.pop(env, None)
     else:
-        fn()
+        final()
     return best

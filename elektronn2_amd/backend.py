@@ -56,6 +56,10 @@ def _load():
         "e2_conv3d_fwd_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_dgrad_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_wgrad": (C.c_int, [vp, P5, P5, fp, i, i, i]),
+        "e2_conv3d_wgrad_acc": (C.c_int, [vp, P5, P5, fp, i, i, i]),
+        "e2_pack_job_bytes": (sz, []),
+        "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
+        "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5]),
         "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp]),
@@ -195,10 +199,27 @@ class Context:
                                          C.c_void_p(wp.data_ptr()), cin, k[0], k[1], k[2],
                                          C.byref(t5(dx))), "e2_conv3d_dgrad_packed")
 
-    def conv3d_wgrad(self, x, dy, dw):
+    def conv3d_wgrad(self, x, dy, dw, accumulate=False):
         kd, kh, kw = dw.shape[2:]
-        _chk(_lib.e2_conv3d_wgrad(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw),
-                                  kd, kh, kw), "e2_conv3d_wgrad")
+        fn = _lib.e2_conv3d_wgrad_acc if accumulate else _lib.e2_conv3d_wgrad
+        _chk(fn(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw), kd, kh, kw),
+             "e2_conv3d_wgrad")
+
+    def make_pack_jobs(self, jobs):
+        """jobs: list of (w tensor, wp tensor, mode).  Returns a device byte tensor
+        of job records for conv3d_pack_multi."""
+        rec = int(_lib.e2_pack_job_bytes())
+        buf = (C.c_char * (rec * len(jobs)))()
+        for n, (w, wp, mode) in enumerate(jobs):
+            cout, cin, kd, kh, kw = w.shape
+            _chk(_lib.e2_pack_job_fill(C.byref(buf, n * rec), _fp(w), C.c_void_p(wp.data_ptr()),
+                                       cout, cin, kd, kh, kw, mode), "e2_pack_job_fill")
+        host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+        return host.to(self.device), len(jobs)
+
+    def conv3d_pack_multi(self, jobs_dev, njobs):
+        _chk(_lib.e2_conv3d_pack_multi(self.h, C.c_void_p(jobs_dev.data_ptr()), njobs),
+             "e2_conv3d_pack_multi")
 
     # ---- fused first layer ----------------------------------------------------
     @staticmethod

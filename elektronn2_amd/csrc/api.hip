@@ -156,8 +156,18 @@ extern "C" int e2_conv3d_dgrad(e2_ctx* ctx, const e2_tensor5* dy_pad, const floa
   return e2_conv3d_dgrad_packed(ctx, dy_pad, ws, cin, kd, kh, kw, dx);
 }
 
+static int wgrad_impl(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy, float* dw,
+                      int kd, int kh, int kw, int accumulate);
 extern "C" int e2_conv3d_wgrad(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy,
                                float* dw, int kd, int kh, int kw) {
+  return wgrad_impl(ctx, x, dy, dw, kd, kh, kw, 0);
+}
+extern "C" int e2_conv3d_wgrad_acc(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy,
+                                   float* dw, int kd, int kh, int kw) {
+  return wgrad_impl(ctx, x, dy, dw, kd, kh, kw, 1);
+}
+static int wgrad_impl(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy, float* dw,
+                      int kd, int kh, int kw, int accumulate) {
   E2_REQUIRE(ctx && dw, "conv3d_wgrad: null argument");
   if (int rc = view_ok(x, "conv3d_wgrad x")) return rc;
   if (int rc = view_ok(dy, "conv3d_wgrad dy")) return rc;
@@ -174,6 +184,7 @@ extern "C" int e2_conv3d_wgrad(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor
   a.dsN = dy->sn; a.dsC = dy->sc; a.dsZ = dy->sd; a.dsY = dy->sh;
   a.flip = 1;
   a.upR = 1;
+  a.accumulate = accumulate;
   return e2i_wgrad_conv(ctx, a);
 }
 
@@ -276,6 +287,7 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
     g.dsN = (long)cout * R * S; g.dsC = S; g.dsZ = (long)x->h * x->w; g.dsY = x->w;
     g.flip = 0;
     g.upR = R;
+    g.accumulate = 0;
     if (int rc = e2i_wgrad_conv(ctx, g)) return rc;
   }
   return 0;

@@ -78,6 +78,7 @@ struct WgradArgs {
   int64_t dsN, dsC, dsZ, dsY;
   int flip;           // store tap index reversed
   int upR;            // >1: rows are (co*R + r); store dw[co][col][r] (UpConv)
+  int accumulate;     // 1: dw += grad (caller zeroed it); 0: dw = grad
 };
 int e2i_upconv_dpre_s2d(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* yout, int pz,
                         int py, int px, int act, float* s2d, float* dbias);

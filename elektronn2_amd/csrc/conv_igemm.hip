@@ -431,6 +431,66 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// all layers' images in one launch (blockIdx.y = job): the repack of every conv
+// weight tensor after an optimiser step costs one kernel instead of 2 per layer
+struct PackJobDev {
+  const float* w;
+  float* wp;
+  int Cout, Cin, kd, THW;
+  long wsO, wsI;
+  int flip, ciP, coP;
+  long total;
+};
+__global__ void pack_multi_kernel(const PackJobDev* __restrict__ jobs) {
+  const PackJobDev j = jobs[blockIdx.y];
+  const int T = j.kd * j.THW;
+  const int nCG = j.ciP >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < j.total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int oc = (int)(i % j.coP);
+    long r = i / j.coP;
+    const int qd = (int)(r & 3); r >>= 2;
+    const int t = (int)(r % j.THW); r /= j.THW;
+    const int cg = (int)(r % nCG);
+    const int dz = (int)(r / nCG);
+    const int ic = cg * 4 + qd;
+    float v = 0.f;
+    if (oc < j.Cout && ic < j.Cin) {
+      const int tl = dz * j.THW + t;
+      v = j.w[(long)oc * j.wsO + (long)ic * j.wsI + (j.flip ? (T - 1 - tl) : tl)];
+    }
+    j.wp[i] = v;
+  }
+}
+
+extern "C" size_t e2_pack_job_bytes(void) { return sizeof(PackJobDev); }
+
+/* fill one host-side job record (to be copied into a device array) */
+extern "C" int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin, int kd,
+                                int kh, int kw, int mode) {
+  E2_REQUIRE(rec && w && wp, "pack_job_fill: null argument");
+  PackJobDev* j = (PackJobDev*)rec;
+  const int T = kd * kh * kw;
+  j->w = w; j->wp = (float*)wp; j->kd = kd; j->THW = kh * kw;
+  if (mode == 0) {
+    j->Cout = cout; j->Cin = cin; j->wsO = (long)cin * T; j->wsI = T; j->flip = 1;
+    e2i_pack_dims(cout, cin, &j->ciP, &j->coP);
+  } else {
+    j->Cout = cin; j->Cin = cout; j->wsO = T; j->wsI = (long)cin * T; j->flip = 0;
+    e2i_pack_dims(cin, cout, &j->ciP, &j->coP);
+  }
+  j->total = (long)kd * kh * kw * j->ciP * j->coP;
+  return 0;
+}
+
+extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs) {
+  E2_REQUIRE(ctx && jobs_dev && njobs > 0 && njobs < 65536, "pack_multi: bad argument");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(256, njobs), dim3(256), 0, ctx->stream,
+                     (const PackJobDev*)jobs_dev);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- host side ----------------------------------------------------------------
 struct IgemmCfg { int MT, NT, CC, SK; };
 

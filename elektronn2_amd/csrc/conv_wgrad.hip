@@ -498,7 +498,8 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   E2_REQUIRE(lds <= 160 * 1024, "wgrad: tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
-  E2_CHECK_HIP(hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.Cout * p.NTOT, ctx->stream));
+  if (!a.accumulate)
+    E2_CHECK_HIP(hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.Cout * p.NTOT, ctx->stream));
   if (getenv("E2_VERBOSE"))
     fprintf(stderr, "[e2] wgrad Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d WK=%d BP=%d PS=%d grid=%ld lds=%zu\n",
             a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.WK, c.BP, p.nPS, grid, lds);

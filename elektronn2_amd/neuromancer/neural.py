@@ -268,6 +268,7 @@ class Conv(NeuralLayer):
         cin = self.parent.shape['f']
         nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
         plan.scratch[self, 'wp_f'] = plan.empty_flat(nb // 4 + 64)
+        plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 0))
         if plan.training:
             pad = [kk - 1 for kk in k]
             dyp = plan.zeros((N, self.n_f) + tuple(osp[i] + 2 * pad[i] for i in range(3)))
@@ -276,6 +277,7 @@ class Conv(NeuralLayer):
                                            pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]]
             if plan.needs_grad(self.parent):
                 plan.scratch[self, 'wp_d'] = plan.empty_flat(nb // 4 + 64)
+                plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_d'], 1))
 
     def _plan_fwd(self, plan):
         ctx = plan.ctx
@@ -285,8 +287,7 @@ class Conv(NeuralLayer):
                                    self.activation_func, plan.out[self])
             return
         y = plan.scratch[self, 'y']
-        wp = plan.scratch[self, 'wp_f']
-        ctx.conv3d_pack(plan.param(self.w), 0, wp)
+        wp = plan.scratch[self, 'wp_f']       # packed by the plan's multi-pack launch
         cin = self.parent.shape['f']
         sig = (0, self.n_f, cin) + tuple(self.filter_shape) + tuple(y.shape[2:]) + \
             (x.stride(3),)
@@ -314,10 +315,10 @@ class Conv(NeuralLayer):
             (x.stride(3), dy.stride(3))
         plan.tuned('wgrad', sigw,
                    autotune.wgrad_candidates(self.n_f, cin, self.filter_shape, dy.shape[2:]),
-                   lambda: ctx.conv3d_wgrad(x, dy, dw))
+                   lambda: ctx.conv3d_wgrad(x, dy, dw, accumulate=True),
+                   fn_tune=lambda: ctx.conv3d_wgrad(x, dy, dw, accumulate=False))
         if plan.needs_grad(self.parent):
             wp = plan.scratch[self, 'wp_d']
-            ctx.conv3d_pack(plan.param(self.w), 1, wp)
             dyp = plan.scratch[self, 'dy_pad']
             dst, first = plan.grad_slot(self.parent)
             out = dst if first else plan.tmp_like(dst)

@@ -118,11 +118,12 @@ class Plan(object):
     def pgrad(self, p):
         return self.model.device_grad(p)
 
-    def tuned(self, kind, sig, cands, fn):
+    def tuned(self, kind, sig, cands, fn, fn_tune=None):
         """launch a conv kernel with its autotuned tiling (tunes on first sight,
         never while a hipGraph capture is in progress)."""
         from .. import autotune
-        autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing)
+        autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing,
+                            fn_tune=fn_tune)
 
     # ---- gradient routing ----------------------------------------------------------
     def grad_slot(self, node):
@@ -151,10 +152,15 @@ class Plan(object):
         self.batch = int(batch)
         self.stream = torch.cuda.Stream(device=self.ctx.device)
         self.out, self.grad, self.scratch = {}, {}, {}
+        self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
         with torch.cuda.stream(self.stream):
             for n in self.nodes:
                 n._plan_alloc(self)
+            self._pack_dev = None
+            if self.pack_jobs:
+                jobs = [(self.param(w), wp, mode) for (w, wp, mode) in self.pack_jobs]
+                self._pack_dev = self.ctx.make_pack_jobs(jobs)
         self._graphs = None
         self._capturing = False
         self._calls = 0
@@ -164,6 +170,8 @@ class Plan(object):
 
     # ---- kernel sequences ----------------------------------------------------------------
     def _emit_forward(self):
+        if self._pack_dev is not None:       # all packed weight images, one launch
+            self.ctx.conv3d_pack_multi(*self._pack_dev)
         for n in self.nodes:
             n._plan_fwd(self)
 

@@ -88,6 +88,18 @@ int e2_conv3d_dgrad_packed(e2_ctx*, const e2_tensor5* dy_pad, const void* wp,
  * of a padded buffer).  dw is overwritten. */
 int e2_conv3d_wgrad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy,
                     float* dw, int kd, int kh, int kw);
+/* same, but dw += gradient (no internal memset): for callers that zero one
+ * flat gradient arena per step. */
+int e2_conv3d_wgrad_acc(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy,
+                        float* dw, int kd, int kh, int kw);
+
+/* Repack MANY weight tensors in one launch (after an optimiser step): fill one
+ * record per (tensor, mode) with e2_pack_job_fill on the host, copy the records
+ * (e2_pack_job_bytes() each) to the device, then call e2_conv3d_pack_multi. */
+size_t e2_pack_job_bytes(void);
+int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin,
+                     int kd, int kh, int kw, int mode);
+int e2_conv3d_pack_multi(e2_ctx*, const void* jobs_dev, int njobs);
 
 /* ---- first layer, fused (Conv node on a 1-channel input: conv -> pool -> +b ->
  *      act in one pass; neural.py:662-712).  Supported: kd = 1, pool z = 1 and
