@@ -92,17 +92,29 @@ struct WgradP {
   FastDivW divWo;
 };
 
-// one quad = 4 k-steps: A[4][MT], B[4][NT] fragments + the span offsets of the
-// NEXT quad (4 ints per lane)
+__device__ __forceinline__ f32x4 w_lds_ld128f(unsigned addr, int off_dummy = 0) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 w_lds_ld128o(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
+// one quad = 16 positions = 4 k-steps.  K is permuted so that lane quarter qd
+// owns positions 16q + 4qd + j (j = k-step): its A operands of the 4 steps are 4
+// CONTIGUOUS floats of the dy row -> one ds_read_b128 per row block (4x fewer
+// LDS instructions than b32; the matrix pipe does not care about the K order as
+// long as A and B agree).  B: x_l[lanebase + inoff[16q + 4qd + j]], the 4
+// offsets again one b128 of the (natural order) table.
 template <int MT, int NT, int DLPAD>
 struct QuadRegs {
-  float a[4][MT];
+  f32x4 a[MT];          // a[mb][j]
   float b[4][NT];
   i32x4 io;
-  template <int... I>
-  __device__ __forceinline__ void load_a(unsigned addr, std::integer_sequence<int, I...>) {
-    ((a[I / MT][I % MT] = w_lds_ld<((I % MT) * 16 * DLPAD + (I / MT) * 4) * 4>(addr)), ...);
-  }
   // The asm loads are invisible to the register allocator's liveness of IN-FLIGHT
   // data: a destination that is never read again (the prefetch past the end of a
   // tile) could be handed to another value while the LDS data is still on its
@@ -110,17 +122,20 @@ struct QuadRegs {
   // the data has landed (cdna guide 5.7: "may reuse it before the data lands").
   __device__ __forceinline__ void touch() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int mb = 0; mb < MT; ++mb) asm volatile("" : "+v"(a[mb]));
 #pragma unroll
-      for (int mb = 0; mb < MT; ++mb) asm volatile("" : "+v"(a[j][mb]));
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int nb = 0; nb < NT; ++nb) asm volatile("" : "+v"(b[j][nb]));
-    }
     asm volatile("" : "+v"(io));
+  }
+  template <int... I>
+  __device__ __forceinline__ void load_a(unsigned addr, std::integer_sequence<int, I...>) {
+    ((a[I] = w_lds_ld128o<I * 16 * DLPAD * 4>(addr)), ...);
   }
   __device__ __forceinline__ void load(unsigned addrA, unsigned addrT, unsigned xbase,
                                        const int (&lanebase)[NT], const i32x4& cur_io) {
-    load_a(addrA, std::make_integer_sequence<int, 4 * MT>{});
+    load_a(addrA, std::make_integer_sequence<int, MT>{});
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -136,11 +151,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   constexpr int WN = 4 / WK;
   constexpr int BM = 16 * MT;
   constexpr int BNn = 16 * NT * WN;
-  constexpr int DLPAD = BP + 2;          // == 2 (mod 4): conflict-free A reads
+  constexpr int DLPAD = BP + 4;          // 16-byte aligned rows, 4 banks apart: conflict-free b128
   constexpr int NQ = BP / 16;            // quads per tile
   // buffer layout: [dy: BM*DLPAD][pad to 16B][table: BP ints + 16][x: maxSpans*Lpad]
   constexpr int DYF = ((BM * DLPAD + 3) / 4) * 4;
-  constexpr int TBF = BP + 16;
+  constexpr int TBF = BP + 16 * 2 * WK;   // + the quads the pipeline prefetches past the end
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,14 +222,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
       const int qc = valid ? q : qlast;
       const int r = (int)fdivw(qc, p.divWo), c = qc - r * p.Wo;
       // span-offset table, [qd][BP/4] so a lane reads 4 consecutive k-steps at once
-      if (wave == 0) tbl[(pl & 3) * (BP / 4) + (pl >> 2)] = (r - r0) * xsY + (c - c0);
+      if (wave == 0) tbl[pl] = (r - r0) * xsY + (c - c0);
       const float* src = dyb + (long)r * p.dsY + c;
       for (int co = wave; co < BM; co += 4) {
         float* dst = dyl + co * DLPAD + 64 * j;
         const int cg = min(m0 + co, p.Cout - 1);
         // invalid positions must contribute 0
-        if (p.dbg & 32) w_glds4(valid ? src + (long)cg * p.dsC : p.zeros, dst);
-        else dst[lane] = valid ? src[(long)cg * p.dsC] : 0.f;
+        w_glds4(valid ? src + (long)cg * p.dsC : p.zeros, dst);
       }
     }
     // input spans, 16 B per lane; the tensor's very last row goes by dwords
@@ -231,9 +245,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   };
 
   // the quad pipeline reads one quad of offsets past the table: keep them in range
-  if (tid < 32) {
-    int* t = reinterpret_cast<int*>(smem + (tid >> 4) * p.bufFloats + DYF);
-    t[BP + (tid & 15)] = 0;
+  for (int i = tid; i < 2 * (TBF - BP); i += 256) {
+    const int bsel = i / (TBF - BP);
+    int* t = reinterpret_cast<int*>(smem + bsel * p.bufFloats + DYF);
+    t[BP + (i - bsel * (TBF - BP))] = 0;
   }
   if (tb < te) stage(tb, 0);
   for (int tt = tb; tt < te; ++tt) {
@@ -244,16 +259,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     if (p.dbg & 2) continue;
     const float* dyl = smem + cur * p.bufFloats;
     const unsigned xbase = w_lds_addr(dyl + DYF + TBF);
-    // A: row (mb*16 + l15), column 4*s + qd ; table: [qd][BP/4]
-    unsigned addrA = w_lds_addr(dyl + l15 * DLPAD + qd) + 64u * (unsigned)wk;
-    unsigned addrT = w_lds_addr(dyl + DYF + qd * (BP / 4)) + 16u * (unsigned)wk;
+    // A: row (mb*16 + l15), columns 16*quad + 4*qd .. +3 ; table: natural order
+    unsigned addrA = w_lds_addr(dyl + l15 * DLPAD + 4 * qd) + 64u * (unsigned)wk;
+    unsigned addrT = w_lds_addr(dyl + DYF + 4 * qd) + 64u * (unsigned)wk;
 
     QuadRegs<MT, NT, DLPAD> g0, g1;
 #define E2_MFMA(G)                                                       \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                        \
     _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                    \
     _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                    \
-      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[j][mb], G.b[j][nb], acc[mb][nb], 0, 0, 0);
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[mb][j], G.b[j][nb], acc[mb][nb], 0, 0, 0);
 #define E2_WAIT()                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
     __builtin_amdgcn_sched_barrier(0);
@@ -261,21 +276,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
     i32x4 io0 = w_lds_ld128(addrT);
     E2_WAIT()
     asm volatile("" : "+v"(io0));
-    addrT += 16u * WK;
+    addrT += 64u * WK;
     g0.load(addrA, addrT, xbase, lanebase, io0);   // also fetches the offsets of the next quad
     E2_WAIT()
     g0.touch();
     constexpr int NQW = NQ / WK;                   // quads per wave
     int q = 0;
     for (; q + 1 < NQW; q += 2) {
-      addrA += 64u * WK; addrT += 16u * WK;
+      addrA += 64u * WK; addrT += 64u * WK;
       g1.load(addrA, addrT, xbase, lanebase, g0.io);
       __builtin_amdgcn_sched_barrier(0);
       E2_MFMA(g0)
       __builtin_amdgcn_sched_barrier(0);
       E2_WAIT()
       g1.touch();
-      addrA += 64u * WK; addrT += 16u * WK;
+      addrA += 64u * WK; addrT += 64u * WK;
       g0.load(addrA, addrT, xbase, lanebase, g1.io);   // past the end: reads slack
       __builtin_amdgcn_sched_barrier(0);
       E2_MFMA(g1)
@@ -387,9 +402,9 @@ static int w_maxspans(const WgradArgs& a, int BNn) {
   return cis * a.kd;
 }
 static size_t w_buf_floats(const WgradArgs& a, int MT, int BNn, int BP) {
-  const size_t dyf = (((size_t)16 * MT * (BP + 2) + 3) / 4) * 4;
+  const size_t dyf = (((size_t)16 * MT * (BP + 4) + 3) / 4) * 4;
   // + slack: the quad pipeline prefetches one quad past the end of the tile
-  return dyf + (BP + 16) + (size_t)w_maxspans(a, BNn) * w_lpad(w_lmax(a, BP)) + 64;
+  return dyf + (BP + 128) + (size_t)w_maxspans(a, BNn) * w_lpad(w_lmax(a, BP)) + 64;
 }
 
 struct WCfg { int MT, NT, WK, BP, PS; };
