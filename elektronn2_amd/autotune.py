@@ -79,7 +79,11 @@ def igemm_candidates(cout, cin, k, out_sp):
     q = out_sp[1] * out_sp[2]
     cands = []
     cinp = -(-cin // 4) * 4
-    ccs = sorted(set(c for c in (4, 8, 16, 32, cinp) if c <= max(cinp, 4) and c <= 32))
+    fast = k[2] in (1, 3, 4, 5)
+    # channel-chunk sizes: fewest barriers first, but several so that LDS limits
+    # and the number of work-groups per CU can trade off
+    opts = (8, 16, 24, 32, 48, 64, cinp) if fast else (4, 8, 16, 32, cinp)
+    ccs = sorted(set(c for c in opts if c <= max(cinp, 4) and c <= (64 if fast else 32)))
     for mt in _best_mts(mblocks, IGEMM_MTS, keep=4):
         nmt = -(-mblocks // mt)
         for nt in (1, 2, 4):

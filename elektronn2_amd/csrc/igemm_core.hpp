@@ -1,0 +1,388 @@
+// igemm_core.hpp -- device side of the implicit-GEMM convolution (see conv_igemm.hip
+// for the algorithm and the host side).  Included by the per-kernel-width
+// translation units conv_igemm_k{1,3,4,5}.hip so that they compile in parallel.
+#pragma once
+#include "common.hpp"
+#include <utility>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+struct IgemmP {
+  const float* in;
+  const float* wp;
+  float* out;
+  int Cin, Cout, kd, kh, kw, THW;
+  int Do, Ho, Wo, Q;
+  long isN, isC, isZ, isY;
+  long osN, osC, osZ, osY;
+  int ciP, coP;
+  int Lpad, CC, Din, N;
+  int dbg;                // timing ablations only (E2_IGEMM_DBG): 1 = stage once, 2 = no MFMA
+  int nPT, nMT, splitK, nChunkC;
+  int atomic;
+  int upz, upy, upx;
+  int bufFloats;          // floats per LDS buffer
+};
+
+// async global -> LDS copies (no VGPR destination); LDS address is
+// wave-uniform base + lane*size, the global source is per lane.
+__device__ __forceinline__ void glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 4, 0, 0);
+}
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(uintptr_t)(lds_vp)p;
+}
+
+// Operand loads are inline asm so that hipcc's waitcnt pass does not see them:
+// the kernel retires them with its own s_waitcnt AFTER the MFMAs of the current
+// group have been issued (cdna guide 5.7 form iii).
+template <int OFF>
+__device__ __forceinline__ float lds_ld(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+// weights: scalar base + per-lane byte offset + immediate
+template <int OFF>
+__device__ __forceinline__ float gl_ld(const float* sbase, unsigned voff) {
+  float v;
+  asm volatile("global_load_dword %0, %1, %2 offset:%3"
+               : "=v"(v) : "v"(voff), "s"(sbase), "i"(OFF));
+  return v;
+}
+
+// operands of one group: TPG taps x (MT weight blocks + NT position blocks)
+template <int MT, int NT, int TPG>
+struct GRegs {
+  float a[TPG][MT];
+  float b[TPG][NT];
+  // keep every asm-load destination allocated until the s_waitcnt that retires
+  // the loads: a destination that is never read again could otherwise be handed
+  // to another value while its data is still in flight.
+  __device__ __forceinline__ void touch() {
+#pragma unroll
+    for (int t = 0; t < TPG; ++t) {
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb) asm volatile("" : "+v"(a[t][mb]));
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) asm volatile("" : "+v"(b[t][nb]));
+    }
+  }
+};
+
+// addresses of a group's operands
+template <int NT, int KW, int GU>
+struct GAddr {
+  const float* abase;           // SGPR pair: first weight row of the group (+ m0)
+  unsigned voff[KW * GU];       // per-lane byte offset of tap j: 4*((4j+qd)*coP + l15)
+  unsigned b[GU][NT];           // LDS byte address of tap 0 of channel group u
+};
+
+// read r of a group, in issue order: all weight (global) loads first -- they have
+// the longer latency -- then the input (LDS) reads
+template <int MT, int NT, int KW, int GU, int R>
+__device__ __forceinline__ void group_read(GRegs<MT, NT, KW * GU>& g, const GAddr<NT, KW, GU>& ad) {
+  constexpr int TPG = KW * GU;
+  if constexpr (R < TPG * MT) {
+    constexpr int j = R / MT, mb = R % MT;
+    g.a[j][mb] = gl_ld<mb * 64>(ad.abase, ad.voff[j]);
+  } else {
+    constexpr int rb = R - TPG * MT;
+    constexpr int j = rb / NT, nb = rb % NT;
+    g.b[j][nb] = lds_ld<(j % KW) * 4>(ad.b[j / KW][nb]);
+  }
+}
+template <int MT, int NT, int KW, int GU, int R0, int R1>
+__device__ __forceinline__ void group_reads(GRegs<MT, NT, KW * GU>& g, const GAddr<NT, KW, GU>& ad) {
+  if constexpr (R0 < R1) {
+    group_read<MT, NT, KW, GU, R0>(g, ad);
+    group_reads<MT, NT, KW, GU, R0 + 1, R1>(g, ad);
+  }
+}
+// One group step, hand-scheduled: MFMA i of the CURRENT group, then reads
+// [r0, r1) of the NEXT group, spread over the first ~3/4 of the MFMAs (a wave may
+// have at most 15 LDS operations outstanding -- lgkmcnt is 4 bits -- so a burst
+// would stall the wave and the matrix pipe behind it; 1-2 reads per 32-cycle
+// MFMA slot are free).
+template <int MT, int NT, int KW, int GU, int I>
+__device__ __forceinline__ void group_steps(const GRegs<MT, NT, KW * GU>& cur,
+                                            GRegs<MT, NT, KW * GU>& nxt, f32x4 (&acc)[MT][NT],
+                                            const GAddr<NT, KW, GU>& ad) {
+  constexpr int TPG = KW * GU;
+  constexpr int M = TPG * MT * NT, R = TPG * (MT + NT);
+  constexpr int j = I / (MT * NT), mb = (I / NT) % MT, nb = I % NT;
+  acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[j][mb], cur.b[j][nb], acc[mb][nb],
+                                                     0, 0, 0);
+  constexpr int r0 = (I * R * 4) / (3 * M) < R ? (I * R * 4) / (3 * M) : R;
+  constexpr int r1 = ((I + 1) * R * 4) / (3 * M) < R ? ((I + 1) * R * 4) / (3 * M) : R;
+  group_reads<MT, NT, KW, GU, r0, r1>(nxt, ad);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (I + 1 < M) group_steps<MT, NT, KW, GU, I + 1>(cur, nxt, acc, ad);
+}
+template <int MT, int NT, int TPG, int I>
+__device__ __forceinline__ void group_mfma(const GRegs<MT, NT, TPG>& cur, f32x4 (&acc)[MT][NT]) {
+  constexpr int j = I / (MT * NT), mb = (I / NT) % MT, nb = I % NT;
+  acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[j][mb], cur.b[j][nb], acc[mb][nb],
+                                                     0, 0, 0);
+  if constexpr (I + 1 < TPG * MT * NT) group_mfma<MT, NT, TPG, I + 1>(cur, acc);
+}
+
+// ---------------------------------------------------------------------------
+// The kernel.  Eight waves: 0-3 compute (side by side along the positions),
+// 4-7 are PRODUCERS that only issue the LDS-DMA of the next chunk's input spans
+// and wait for it.  (Measured on gfx950, tools/ubench/group_loop.hip: DMA bytes
+// landing in LDS stall the ds_reads of the compute waves at ~32 B/clk whoever
+// issues them, so the staged bytes per MFMA are what costs; the weights -- 5x the
+// bytes of the input spans -- therefore bypass LDS: each lane fetches its A
+// operands straight from the packed image in L2/L1 with global_load_dword.)
+//
+// Group = GU channel groups x KW taps of one tap row (GU > 1 only for 1x1 taps).
+// Group g+1's operands are fetched while group g computes; the first group of a
+// chunk is fetched in the open (its weights before the chunk's barrier), which
+// costs ~1k cycles per chunk -- chunks are made as large as LDS allows.
+template <int MT, int NT, int KW, int GU>
+__global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = 16 * MT, BN = 64 * NT;
+  constexpr int TPG = KW * GU;
+  const int CC = p.CC;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave8 & 3;
+  const bool producer = wave8 >= 4;
+  const int l15 = lane & 15, qd = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int pt = bid % p.nPT; bid /= p.nPT;
+  const int z = bid % p.Do;  bid /= p.Do;
+  const int mt = bid % p.nMT; bid /= p.nMT;
+  const int ks = bid % p.splitK;
+  const int n = bid / p.splitK;
+
+  const int m0 = mt * BM;
+  const int q0 = pt * BN;
+  const int qlast = min(q0 + BN, p.Q) - 1;
+  const int r0 = q0 / p.Wo, c0 = q0 - r0 * p.Wo;
+  const int rl = qlast / p.Wo, cl = qlast - rl * p.Wo;
+  const int isY = (int)p.isY;
+  const long span_lo = (long)r0 * p.isY + c0;
+  const int L = (rl - r0) * isY + (cl - c0) + (p.kh - 1) * isY + p.kw;
+  const int Lpad = p.Lpad;
+
+  const int nChunks = p.kd * p.nChunkC;
+  const int per = (nChunks + p.splitK - 1) / p.splitK;
+  const int cb = ks * per, ce = min(cb + per, nChunks);
+  const int nCG = (p.Cin + 3) >> 2;          // channel groups that carry data
+  const int CG = CC >> 2;
+
+  // channel groups of chunk ch, rounded up to whole groups of GU
+  auto chunk_cgs = [&](int ch, int& dz, int& cgi0) {
+    dz = ch / p.nChunkC;
+    cgi0 = (ch - dz * p.nChunkC) * CG;
+    const int cgs = min(CG, nCG - cgi0);
+    return ((cgs + GU - 1) / GU) * GU;
+  };
+
+  if (producer) {
+    // ---- producers: input spans of chunk ch -> LDS buffer (ch - cb) & 1 -----
+    const int pw = wave8 - 4;
+    const int nJ = (L + 63) >> 6;
+    const int nJ16 = (L + 255) >> 8;
+    const float* in_n = p.in + (long)n * p.isN + (long)z * p.isZ + span_lo;
+    auto stage = [&](int ch, int buf) {
+      int dz, cgi0;
+      const int ccs = 4 * chunk_cgs(ch, dz, cgi0);
+      float* xl = smem + buf * p.bufFloats;
+      const float* xb = in_n + (long)dz * p.isZ;
+      for (int cc = pw; cc < ccs; cc += 4) {
+        const int ci = min(cgi0 * 4 + cc, p.Cin - 1);   // padded channels carry zero weights
+        const float* src = xb + (long)ci * p.isC;
+        float* dst = xl + cc * Lpad;
+        // 16-byte pieces (256 floats per wave instruction); lanes past the span
+        // are masked off, the straddling lane over-reads <= 12 bytes, which stays
+        // inside the tensor except on its very last row: that row goes by dwords.
+        const bool tail_row = (ci == p.Cin - 1) && (z + dz == p.Din - 1) && (n == p.N - 1);
+        if (!tail_row) {
+          for (int j = 0; j < nJ16; ++j) {
+            const int u = 256 * j + 4 * lane;
+            if (u < L) glds16(src + u, dst + 256 * j);
+          }
+        } else {
+          for (int j = 0; j < nJ; ++j)
+            if (64 * j + lane < L) glds4(src + 64 * j + lane, dst + 64 * j);
+        }
+      }
+    };
+    if (cb < ce) stage(cb, 0);
+    for (int ch = cb; ch < ce; ++ch) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                       // chunk ch is in LDS; buffer of ch-1 is free
+      if (ch + 1 < ce && !(p.dbg & 1)) stage(ch + 1, ((ch - cb) & 1) ^ 1);
+    }
+    return;
+  }
+
+  // ---- compute waves ----------------------------------------------------------
+  int posoff[NT];
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) {
+    int q = min(q0 + wave * (16 * NT) + nb * 16 + l15, p.Q - 1);
+    int r = q / p.Wo, c = q - r * p.Wo;
+    posoff[nb] = (r - r0) * isY + (c - c0) + qd * Lpad;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  GAddr<NT, KW, GU> ad;
+#pragma unroll
+  for (int j = 0; j < TPG; ++j) ad.voff[j] = 4u * (unsigned)((4 * j + qd) * p.coP + l15);
+  const long rowF = 4L * p.coP;                       // floats per tap (4 channel rows)
+  const long grpF = (long)TPG * rowF;                 // floats per group
+  auto chunk_abase = [&](int dz, int cgi0) {
+    return p.wp + ((long)(dz * (p.ciP >> 2) + cgi0) * p.THW) * rowF + m0;
+  };
+  const unsigned stepY = 4u * (unsigned)isY;
+  const unsigned stepCg = 16u * (unsigned)Lpad;       // bytes between channel groups in LDS
+
+  GRegs<MT, NT, TPG> g0, g1;
+#define E2_WAIT()                                                         \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
+  __builtin_amdgcn_sched_barrier(0);
+#define E2_ADV()                                                          \
+  {                                                                       \
+    ad.abase += grpF;                                                     \
+    ++ty;                                                                 \
+    const bool wrap = (ty == p.kh);                                       \
+    const unsigned d = wrap ? (GU * stepCg - (unsigned)(p.kh - 1) * stepY) : stepY; \
+    ty = wrap ? 0 : ty;                                                   \
+    _Pragma("unroll") for (int u = 0; u < GU; ++u)                        \
+    _Pragma("unroll") for (int nb = 0; nb < NT; ++nb) ad.b[u][nb] += d;   \
+  }
+  for (int ch = cb; ch < ce; ++ch) {
+    const int cur = (ch - cb) & 1;
+    int dz, cgi0;
+    const int nG = (chunk_cgs(ch, dz, cgi0) / GU) * p.kh;
+    // weights of the first group: independent of the LDS contents, start them early
+    ad.abase = chunk_abase(dz, cgi0);
+    group_reads<MT, NT, KW, GU, 0, TPG * MT>(g0, ad);
+    __syncthreads();                         // the producers saw their DMA land
+    if (p.dbg & 2) continue;
+    const unsigned xbase = lds_addr(smem + cur * p.bufFloats);
+#pragma unroll
+    for (int u = 0; u < GU; ++u)
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+        ad.b[u][nb] = xbase + 4u * (unsigned)posoff[nb] + (unsigned)u * stepCg;
+    group_reads<MT, NT, KW, GU, TPG * MT, TPG * (MT + NT)>(g0, ad);
+    E2_WAIT()
+    g0.touch();
+    int ty = 0;
+    int g = 0;
+    for (; g + 1 < nG; g += 2) {
+      E2_ADV()
+      __builtin_amdgcn_sched_barrier(0);
+      group_steps<MT, NT, KW, GU, 0>(g0, g1, acc, ad);   // compute g, fetch g+1
+      E2_WAIT()
+      g1.touch();
+      E2_ADV()
+      __builtin_amdgcn_sched_barrier(0);
+      group_steps<MT, NT, KW, GU, 0>(g1, g0, acc, ad);   // past the end: slack rows
+      E2_WAIT()
+      g0.touch();
+    }
+    if (g < nG) group_mfma<MT, NT, TPG, 0>(g0, acc);
+  }
+#undef E2_WAIT
+#undef E2_ADV
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  g0.touch();
+  g1.touch();
+
+  // ---- epilogue: D col = position (lane&15), row = channel 4*qd+reg -------
+  const int R = p.upz * p.upy * p.upx;
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) {
+    const int q = q0 + wave * (16 * NT) + nb * 16 + l15;
+    if (q >= p.Q) continue;
+    const int r = q / p.Wo, c = q - r * p.Wo;
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = m0 + mb * 16 + 4 * qd + rr;
+        if (co >= p.Cout) continue;
+        float* dst;
+        if (R == 1) {
+          dst = p.out + (long)n * p.osN + (long)co * p.osC + (long)z * p.osZ +
+                (long)r * p.osY + c;
+        } else {
+          const int cr = co / R, sub = co - cr * R;
+          const int rz = sub / (p.upy * p.upx);
+          const int rem = sub - rz * (p.upy * p.upx);
+          const int ry = rem / p.upx, rx = rem - ry * p.upx;
+          dst = p.out + (long)n * p.osN + (long)cr * p.osC +
+                (long)(z * p.upz + rz) * p.osZ + (long)(r * p.upy + ry) * p.osY +
+                (c * p.upx + rx);
+        }
+        const float v = acc[mb][nb][rr];
+        if (p.atomic) unsafeAtomicAdd(dst, v);
+        else *dst = v;
+      }
+    }
+  }
+}
+
+// ---- launch helpers ----------------------------------------------------------
+template <int MT, int NT, int KW, int GU>
+static int igemm_launch(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&igemm_kernel<MT, NT, KW, GU>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((igemm_kernel<MT, NT, KW, GU>), dim3(grid), dim3(512), lds, ctx->stream, p);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// all (MT, NT) instances of one kernel width
+template <int KW, int GU>
+static int igemm_dispatch(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int grid, size_t lds) {
+#define E2_CASE(M)                                                              \
+  case M:                                                                       \
+    if (NT == 1) return igemm_launch<M, 1, KW, GU>(ctx, p, grid, lds);          \
+    if (NT == 2) return igemm_launch<M, 2, KW, GU>(ctx, p, grid, lds);          \
+    break;
+#define E2_CASE4(M)                                                             \
+  case M:                                                                       \
+    if (NT == 1) return igemm_launch<M, 1, KW, GU>(ctx, p, grid, lds);          \
+    if (NT == 2) return igemm_launch<M, 2, KW, GU>(ctx, p, grid, lds);          \
+    if (NT == 4) return igemm_launch<M, 4, KW, GU>(ctx, p, grid, lds);          \
+    break;
+  switch (MT) {
+    E2_CASE4(1) E2_CASE4(2) E2_CASE4(3) E2_CASE4(4) E2_CASE4(5) E2_CASE(6)
+    E2_CASE(7) E2_CASE(8) E2_CASE(10) E2_CASE(13)
+  }
+#undef E2_CASE
+#undef E2_CASE4
+  e2_set_error("igemm: no instance MT=%d NT=%d", MT, NT);
+  return 2;
+}
+
+// entry points of the per-width translation units
+int e2i_igemm_launch_k1(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k3(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k4(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k5(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_generic(e2_ctx*, const IgemmP&, int MT, int NT, int grid, size_t lds);

@@ -77,12 +77,30 @@ def test_conv3d_fwd_dgrad_wgrad(ctx, case):
 
 
 @pytest.mark.parametrize("force", ["1,1,4,1", "2,2,8,2", "3,1,4,4", "13,2,4,1", "10,1,8,2",
-                                   "5,2,4,1", "7,1,8,1", "8,2,4,2", "4,1,8,1", "6,2,4,1"])
+                                   "5,2,4,1", "7,1,8,1", "8,2,4,2", "4,1,8,1", "6,2,4,1",
+                                   "7,2,24,1", "4,4,16,1", "13,1,24,3", "3,4,12,2"])
 def test_conv3d_fwd_forced_tilings(ctx, force):
     """Every MT/NT instance, both CC values and split-K (atomic epilogue)."""
     rng = np.random.RandomState(7)
     x = rng.rand(1, 24, 5, 13, 37).astype(np.float32)
     w = (rng.randn(200, 24, 3, 2, 3) / 12).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    y = torch.full(y_ref.shape, float("nan"), device="cuda")
+    os.environ["E2_IGEMM_FORCE"] = force
+    try:
+        ctx.conv3d_fwd(dev(x), dev(w), y)
+    finally:
+        del os.environ["E2_IGEMM_FORCE"]
+    assert relerr(y, y_ref) < TOL
+
+
+@pytest.mark.parametrize("force", ["7,2,32,1", "13,1,16,2", "2,4,48,1", "5,2,64,1", "1,1,8,1"])
+def test_conv3d_1x1_forced_tilings(ctx, force):
+    """1x1x1 taps (plain GEMM): GU = 4 channel groups per step when CC % 16 == 0,
+    ragged last chunk (Cin = 70)."""
+    rng = np.random.RandomState(17)
+    x = rng.rand(2, 70, 3, 11, 19).astype(np.float32)
+    w = (rng.randn(100, 70, 1, 1, 1) / 8).astype(np.float32)
     y_ref = O.conv3d_fwd(x, w)
     y = torch.full(y_ref.shape, float("nan"), device="cuda")
     os.environ["E2_IGEMM_FORCE"] = force
