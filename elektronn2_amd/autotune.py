@@ -98,23 +98,26 @@ def igemm_candidates(cout, cin, k, out_sp):
 
 
 def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
+    """"MT,NT,WK,BP,PS": WK 1 = direct kernel (dy from global memory; BP 128/256),
+    WK 0 = LDS-staged kernel (BP 64/128), WK 4 = LDS-staged, waves split K (tiny N)."""
     mblocks = -(-cout // 16)
     T = k[0] * k[1] * k[2]
     nblocks = -(-(cin * T) // 16)
     q = out_sp[1] * out_sp[2]
+    qpad = out_sp[1] * (out_sp[2] + 2 * (k[2] - 1))       # span of a padded gradient plane
     cands = []
     for mt in _best_mts(mblocks, WGRAD_MTS, keep=3):
         nmt = -(-mblocks // mt)
-        variants = [(1, 1), (2, 1), (4, 1)]
+        variants = [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0), (4, 0)]
         if nblocks <= 2:
-            variants = [(1, 4), (1, 1)]
+            variants = [(1, 4), (1, 0), (1, 1)]
         for nt, wk in variants:
-            wn = 4 // wk
+            wn = 1 if wk == 4 else 4
             if nt > 1 and 16 * nt * wn > 16 * nblocks:
                 continue
             nnt = -(-nblocks // (nt * wn))
-            for bp in (64, 128):
-                tiles = out_sp[0] * (-(-q // bp))
+            for bp in ((128, 256) if wk == 1 else (64, 128)):
+                tiles = out_sp[0] * (-(-(qpad if wk == 1 else q) // bp))
                 for fill in (1, 2, 4):
                     ps = max(1, min(tiles, (n_cu * fill) // max(1, nmt * nnt)))
                     cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, ps))

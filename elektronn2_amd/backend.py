@@ -57,6 +57,7 @@ def _load():
         "e2_conv3d_dgrad_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_wgrad": (C.c_int, [vp, P5, P5, fp, i, i, i]),
         "e2_conv3d_wgrad_acc": (C.c_int, [vp, P5, P5, fp, i, i, i]),
+        "e2_conv3d_wgrad_pad": (C.c_int, [vp, P5, P5, fp, i, i, i, i]),
         "e2_pack_job_bytes": (sz, []),
         "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
         "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
@@ -204,6 +205,14 @@ class Context:
         fn = _lib.e2_conv3d_wgrad_acc if accumulate else _lib.e2_conv3d_wgrad
         _chk(fn(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw), kd, kh, kw),
              "e2_conv3d_wgrad")
+
+    def conv3d_wgrad_pad(self, x, dy_pad, dw, accumulate=False):
+        """wgrad from the zero-padded gradient buffer (borders zero, >= 64 readable
+        bytes after its last element): the direct kernel."""
+        kd, kh, kw = dw.shape[2:]
+        _chk(_lib.e2_conv3d_wgrad_pad(self.h, C.byref(t5(x)), C.byref(t5(dy_pad)), _fp(dw),
+                                      kd, kh, kw, 1 if accumulate else 0),
+             "e2_conv3d_wgrad_pad")
 
     def make_pack_jobs(self, jobs):
         """jobs: list of (w tensor, wp tensor, mode).  Returns a device byte tensor

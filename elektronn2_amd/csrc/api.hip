@@ -185,6 +185,35 @@ static int wgrad_impl(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy, fl
   a.flip = 1;
   a.upR = 1;
   a.accumulate = accumulate;
+  a.dy_padded = 0;
+  return e2i_wgrad_conv(ctx, a);
+}
+
+extern "C" int e2_conv3d_wgrad_pad(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy_pad,
+                                   float* dw, int kd, int kh, int kw, int accumulate) {
+  E2_REQUIRE(ctx && dw, "conv3d_wgrad_pad: null argument");
+  if (int rc = view_ok(x, "conv3d_wgrad_pad x")) return rc;
+  if (int rc = view_ok(dy_pad, "conv3d_wgrad_pad dy_pad")) return rc;
+  E2_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1, "conv3d_wgrad_pad: bad kernel");
+  const int Do = dy_pad->d - 2 * (kd - 1), Ho = dy_pad->h - 2 * (kh - 1),
+            Wo = dy_pad->w - 2 * (kw - 1);
+  E2_REQUIRE(dy_pad->n == x->n && Do == x->d - kd + 1 && Ho == x->h - kh + 1 &&
+                 Wo == x->w - kw + 1 && Do > 0 && Ho > 0 && Wo > 0,
+             "conv3d_wgrad_pad: padded dy (%d,%d,%d) does not match x (%d,%d,%d), kernel %d,%d,%d",
+             dy_pad->d, dy_pad->h, dy_pad->w, x->d, x->h, x->w, kd, kh, kw);
+  WgradArgs a;
+  a.x = x->ptr;
+  a.dy = dy_pad->ptr + (int64_t)(kd - 1) * dy_pad->sd + (int64_t)(kh - 1) * dy_pad->sh + (kw - 1);
+  a.dw = dw;
+  a.N = x->n; a.Cin = x->c; a.Cout = dy_pad->c;
+  a.kd = kd; a.kh = kh; a.kw = kw;
+  a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+  a.xsN = x->sn; a.xsC = x->sc; a.xsZ = x->sd; a.xsY = x->sh;
+  a.dsN = dy_pad->sn; a.dsC = dy_pad->sc; a.dsZ = dy_pad->sd; a.dsY = dy_pad->sh;
+  a.flip = 1;
+  a.upR = 1;
+  a.accumulate = accumulate;
+  a.dy_padded = 1;
   return e2i_wgrad_conv(ctx, a);
 }
 
@@ -282,6 +311,7 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
     g.x = x->ptr; g.dy = s2d; g.dw = dw;
     g.N = x->n; g.Cin = cin; g.Cout = cout * R;
     g.kd = g.kh = g.kw = 1;
+    g.dy_padded = 0;
     g.Do = x->d; g.Ho = x->h; g.Wo = x->w;
     g.xsN = x->sn; g.xsC = x->sc; g.xsZ = x->sd; g.xsY = x->sh;
     g.dsN = (long)cout * R * S; g.dsC = S; g.dsZ = (long)x->h * x->w; g.dsY = x->w;

@@ -79,10 +79,16 @@ struct WgradArgs {
   int flip;           // store tap index reversed
   int upR;            // >1: rows are (co*R + r); store dw[co][col][r] (UpConv)
   int accumulate;     // 1: dw += grad (caller zeroed it); 0: dw = grad
+  int dy_padded;      // 1: dy is the interior of a zero-padded buffer (row gaps hold
+                      //    zeros, >= 64 readable bytes follow its last element)
 };
 int e2i_upconv_dpre_s2d(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* yout, int pz,
                         int py, int px, int act, float* s2d, float* dbias);
 int e2i_wgrad_conv(e2_ctx*, const WgradArgs& a);
+// conv_wgrad_direct.hip: dy operand straight from global memory (needs dy_padded)
+int e2i_wgrad_direct(e2_ctx*, const WgradArgs& a, int MT, int NT, int BP, int PS);
+int e2i_wgrad_direct_lpad(const WgradArgs& a, int BP);
+size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP);
 
 // view helpers (pointwise.hip)
 int e2i_fill_view(e2_ctx*, const e2_tensor5* v, float value);

@@ -420,12 +420,47 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
   const long Q = (long)a.Ho * a.Wo;
   WCfg best{0, 0, 0, 0, 0};
   double bestCost = 1e300;
+  const double dw_bytes = 4.0 * a.Cout * (double)NTOT;
   const char* force = getenv("E2_WGRAD_FORCE");
   if (force) {
     WCfg f{0, 0, 0, 0, 0};
     if (sscanf(force, "%d,%d,%d,%d,%d", &f.MT, &f.NT, &f.WK, &f.BP, &f.PS) == 5) { *ok = 1; return f; }
   }
-  const double dw_bytes = 4.0 * a.Cout * (double)NTOT;
+  if (a.dy_padded && nblocks > 2) {
+    // direct kernel (conv_wgrad_direct.hip): no dy staging; tiles of 128/256 span positions
+    const long S = (long)(a.Ho - 1) * a.dsY + a.Wo;
+    for (int MT : kWMTs) {
+      if (MT > mblocks && MT != 1) continue;
+      const int nMT = e2_cdiv(mblocks, MT);
+      for (int NT = 1; NT <= 4; NT *= 2) {
+        if (16 * NT * 4 > 16 * nblocks && NT > 1) continue;
+        const int nNT = e2_cdiv(nblocks, NT * 4);
+        for (int BP = 128; BP <= 256; BP *= 2) {
+          if (BP == 256 && S <= 128) continue;
+          const size_t lds = 2 * e2i_wgrad_direct_buf_floats(a, NT, BP) * 4;
+          if (lds > 160 * 1024) continue;
+          const int slots = ctx->num_cu;
+          const int nPT = (int)((S + BP - 1) / BP);
+          const long tiles = (long)a.N * a.Do * nPT;
+          const long base = (long)nMT * nNT;
+          for (int fill = 1; fill <= 2; ++fill) {
+            long PS = std::max<long>(1, ((long)slots * fill + base - 1) / base);
+            PS = std::min(PS, tiles);
+            const int per = (int)((tiles + PS - 1) / PS);
+            const double tile = (BP / 4.0) * MT * NT * 35.0 + (BP / 16.0) * 150.0 + 1200.0;
+            const double flush = 16.0 * MT * 16.0 * NT * 4 * 0.6;
+            const double wg_time = per * tile + flush + 5000.0;
+            const long wgs = base * PS;
+            const double rounds = (double)((wgs + slots - 1) / slots);
+            const double atom = (double)PS * dw_bytes / 1.3e12 * 2.4e9 + dw_bytes / 4e12 * 2.4e9;
+            const double cost = rounds * wg_time + atom;
+            if (cost < bestCost) { bestCost = cost; best = WCfg{MT, NT, 1, BP, (int)PS}; }
+          }
+        }
+      }
+    }
+    if (best.MT) { *ok = 1; return best; }
+  }
   for (int MT : kWMTs) {
     if (MT > mblocks && MT != 1) continue;
     const int nMT = e2_cdiv(mblocks, MT);
@@ -479,6 +514,11 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   WCfg c = choose_wcfg(ctx, a, &ok);
   E2_REQUIRE(ok, "wgrad: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d)", a.Cin, a.Cout,
              a.kd, a.kh, a.kw);
+  // WK field: 1 = direct kernel when dy is padded (BP 128/256), else the LDS-staged
+  // kernel; 0 = LDS-staged kernel forced; 4 = LDS-staged kernel, waves split K
+  if (a.dy_padded && c.WK == 1 && (c.BP == 128 || c.BP == 256))
+    return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS);
+  if (c.WK == 0) c.WK = 1;
   E2_REQUIRE(c.BP == 64 || c.BP == 128, "wgrad: BP must be 64 or 128");
   E2_REQUIRE(c.WK == 1 || (c.WK == 4 && c.NT == 1), "wgrad: WK=4 needs NT=1");
   WgradP p;

@@ -1,0 +1,448 @@
+// conv_wgrad_direct.hip -- weight gradient, "direct" variant: the dy operand comes
+// straight from global memory, only the input spans go through LDS.
+//
+//   G[co][(ci,dz,ty,tx)] = sum_{n,z,s} dy_pad[n][co][z][s] * x[n][ci][z+dz][xoff(s)+ty*sY+tx]
+//
+// Same GEMM view as conv_wgrad.hip (M = Cout, N = Cin*T with the taps flattened
+// into N, K = positions, partial tile kept in MFMA accumulators over a range of
+// position tiles, one atomic flush), with three differences that follow from the
+// measurement in tools/ubench/group_loop.hip (bytes landing in LDS by DMA stall
+// the ds_reads of the compute waves at ~32 B/clk):
+//   * K runs over the MEMORY span s of the zero-padded gradient plane
+//     (s = r*dsY + c, c in [0, dsY)), not over the output positions: the padding
+//     columns between two rows hold zeros (the buffer is the one dgrad reads), so
+//     they add nothing, and 4 consecutive k are 4 consecutive floats.  Lane
+//     (l15, qd) fetches A[co = 16*mb + l15][s = 16q + 4qd .. +3] with ONE
+//     global_load_dwordx4 per row block and quad -- dy never touches LDS.
+//   * a small LDS table maps s -> offset of the position inside the staged input
+//     span (gap columns are clamped to the row's last position: their dy is 0).
+//   * four PRODUCER waves build the table and issue the LDS-DMA of the input spans
+//     of the next tile; the four compute waves only load operands and issue MFMAs.
+// Positions past the end of a plane's span (the last, partial quad of a plane) are
+// masked out of A with v_cndmask after the load.
+#include "common.hpp"
+#include <stdlib.h>
+#include <algorithm>
+#include <utility>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+namespace {
+
+__device__ __forceinline__ void d_glds4(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 4, 0, 0);
+}
+__device__ __forceinline__ void d_glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_vp)g, (lds_vp)l, 16, 0, 0);
+}
+__device__ __forceinline__ float d_lds_ld(unsigned addr) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ i32x4 d_lds_ld128(unsigned addr) {
+  i32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ f32x4 d_gl_ld128(const float* sbase, unsigned voff) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase));
+  return v;
+}
+__device__ __forceinline__ unsigned d_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(lds_vp)p;
+}
+
+struct FastDivD { unsigned d, m, sh; };
+static inline FastDivD mk_divd(unsigned d) {
+  FastDivD f; f.d = d;
+  if (d <= 1) { f.m = 0; f.sh = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << (31 + l)) + d - 1) / d);
+  f.sh = l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fdivd(unsigned n, const FastDivD& f) {
+  return f.d <= 1 ? n : (__umulhi(n, f.m) >> f.sh);
+}
+
+struct WdP {
+  const float* x;
+  const float* dy;        // interior origin of the zero-padded gradient buffer
+  float* dw;
+  int Cin, Cout, kd, kh, kw, T, THW;
+  int Do, Ho, Wo, S;      // S = (Ho-1)*dsY + Wo: span of one gradient plane
+  long xsN, xsC, xsZ, xsY;
+  long dsN, dsC, dsZ, dsY;
+  int flip, upR;
+  int NTOT;
+  int Lpad;
+  int nMT, nNT, nPS;
+  int nPT, tilesTotal;
+  int maxSpans;
+  int bufFloats;
+  int Din, N;
+  int dbg;
+  FastDivD divDsY;
+};
+
+// one quad = 16 span positions = 4 k-steps; lane quarter qd owns 16q + 4qd + j
+template <int MT, int NT>
+struct DQuad {
+  f32x4 a[MT];          // a[mb][j]
+  float b[4][NT];
+  i32x4 io;             // span offsets of the NEXT quad
+  __device__ __forceinline__ void touch() {
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) asm volatile("" : "+v"(a[mb]));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) asm volatile("" : "+v"(b[j][nb]));
+    asm volatile("" : "+v"(io));
+  }
+  __device__ __forceinline__ void load_a(const float* abase, const unsigned (&voff)[MT]) {
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) a[mb] = d_gl_ld128(abase, voff[mb]);
+  }
+  __device__ __forceinline__ void load_b(unsigned addrT, unsigned xbase, const int (&lanebase)[NT],
+                                         const i32x4& cur_io) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+        b[j][nb] = d_lds_ld(xbase + 4u * (unsigned)(lanebase[nb] + cur_io[j]));
+    io = d_lds_ld128(addrT);
+  }
+  // zero the k-steps whose span position lies past `lim` (relative to the quad's lane)
+  __device__ __forceinline__ void mask(int lim) {
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[mb][j] = (j <= lim) ? a[mb][j] : 0.f;
+  }
+};
+
+template <int MT, int NT, int BP>
+__global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = 16 * MT;
+  constexpr int BNn = 16 * NT * 4;
+  constexpr int TBF = BP + 16;           // + the quad of offsets fetched past the end
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave8 >= 4;
+  const int wn = wave8 & 3;
+  const int l15 = lane & 15, qd = lane >> 4;
+
+  int bid = blockIdx.x;
+  const int nt = bid % p.nNT; bid /= p.nNT;
+  const int mt = bid % p.nMT;
+  const int ps = bid / p.nMT;
+
+  const int m0 = mt * BM;
+  const int n0 = nt * BNn;
+  const int nEnd = min(n0 + BNn, p.NTOT) - 1;
+  const int ciA = n0 / p.T;
+  const int ciB = nEnd / p.T;
+  const int nSpans = (ciB - ciA + 1) * p.kd;
+  const int xsY = (int)p.xsY, dsY = (int)p.dsY;
+  const int Lpad = p.Lpad;
+
+  const int per = (p.tilesTotal + p.nPS - 1) / p.nPS;
+  const int tb = ps * per, te = min(tb + per, p.tilesTotal);
+
+  if (producer) {
+    const int pw = wave8 - 4;
+    auto stage = [&](int tt, int buf) {
+      int* tbl = reinterpret_cast<int*>(smem + buf * p.bufFloats);
+      float* xl = smem + buf * p.bufFloats + TBF;
+      const int pt = tt % p.nPT;
+      const int zz = tt / p.nPT;
+      const int z = zz % p.Do;
+      const int n = zz / p.Do;
+      const int s0 = pt * BP;
+      const int sLast = min(s0 + BP, p.S) - 1;
+      const int r0 = (int)fdivd(s0, p.divDsY), c0 = min(s0 - r0 * dsY, p.Wo - 1);
+      const int rl = (int)fdivd(sLast, p.divDsY), cl = min(sLast - rl * dsY, p.Wo - 1);
+      const int span_lo = r0 * xsY + c0;
+      const int L = rl * xsY + cl - span_lo + (p.kh - 1) * xsY + p.kw;
+      // span position -> offset inside the staged input span
+      for (int i = pw * 64 + lane; i < BP; i += 256) {
+        const int s = min(s0 + i, sLast);
+        const int r = (int)fdivd(s, p.divDsY);
+        const int c = min(s - r * dsY, p.Wo - 1);
+        tbl[i] = r * xsY + c - span_lo;
+      }
+      // input spans, 16 B per lane; lanes past the span are masked off, the
+      // straddling lane over-reads <= 12 bytes, which stays inside the tensor
+      // except on its very last row: that row goes by dwords.
+      const float* xb = p.x + (long)n * p.xsN + (long)z * p.xsZ + span_lo;
+      const int nJ = (L + 63) >> 6;
+      const int nJ16 = (L + 255) >> 8;
+      for (int slot = pw; slot < nSpans; slot += 4) {
+        const int cs = slot / p.kd;
+        const int dz = slot - cs * p.kd;
+        const int ci = ciA + cs;
+        const float* src = xb + (long)ci * p.xsC + (long)dz * p.xsZ;
+        float* dst = xl + slot * Lpad;
+        const bool tail_row = (ci == p.Cin - 1) && (z + dz == p.Din - 1) && (n == p.N - 1);
+        if (!tail_row) {
+          for (int j = 0; j < nJ16; ++j) {
+            const int u = 256 * j + 4 * lane;
+            if (u < L) d_glds16(src + u, dst + 256 * j);
+          }
+        } else {
+          for (int j = 0; j < nJ; ++j)
+            if (64 * j + lane < L) d_glds4(src + 64 * j + lane, dst + 64 * j);
+        }
+      }
+    };
+    // the quad pipeline reads one quad of offsets past the table: keep them in range
+    if (pw == 0 && lane < 32) {
+      int* t = reinterpret_cast<int*>(smem + (lane >> 4) * p.bufFloats);
+      t[BP + (lane & 15)] = 0;
+    }
+    if (tb < te) stage(tb, 0);
+    for (int tt = tb; tt < te; ++tt) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tt + 1 < te && !(p.dbg & 1)) stage(tt + 1, ((tt - tb) & 1) ^ 1);
+    }
+    return;
+  }
+
+  // ---- compute waves ----------------------------------------------------------
+  int lanebase[NT];
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) {
+    const int jn = min(n0 + (wn * NT + nb) * 16 + l15, p.NTOT - 1);
+    const int ci = jn / p.T;
+    const int tap = jn - ci * p.T;
+    const int dz = tap / p.THW;
+    const int t2 = tap - dz * p.THW;
+    const int ty = t2 / p.kw, tx = t2 - ty * p.kw;
+    lanebase[nb] = ((ci - ciA) * p.kd + dz) * Lpad + ty * xsY + tx;
+  }
+  unsigned voffA[MT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) {
+    const int co = min(m0 + mb * 16 + l15, p.Cout - 1);      // padded rows: discarded at the flush
+    voffA[mb] = 4u * (unsigned)((long)co * p.dsC + 4 * qd);
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  DQuad<MT, NT> g0, g1;
+#define E2_MFMA(G)                                                       \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
+  _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                      \
+  _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                      \
+    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[mb][j], G.b[j][nb], acc[mb][nb], 0, 0, 0);
+#define E2_WAIT()                                                        \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int tt = tb; tt < te; ++tt) {
+    const int cur = (tt - tb) & 1;
+    const int pt = tt % p.nPT;
+    const int zz = tt / p.nPT;
+    const int z = zz % p.Do;
+    const int n = zz / p.Do;
+    const int s0 = pt * BP;
+    const int len = min(s0 + BP, p.S) - s0;          // valid span positions of the tile
+    const int nQ = (len + 15) >> 4;
+    const int lastLim = len - 16 * (nQ - 1) - 1 - 4 * qd;   // last valid j of this lane in the last quad
+    const bool partial = (len & 15) != 0;
+    const float* abase = p.dy + (long)n * p.dsN + (long)z * p.dsZ + s0;
+    // operands of the first quad: dy does not depend on the LDS contents
+    g0.load_a(abase, voffA);
+    __syncthreads();                                  // the producers' table + spans landed
+    if (p.dbg & 2) { E2_WAIT() g0.touch(); continue; }
+    const float* bufp = smem + cur * p.bufFloats;
+    const unsigned xbase = d_lds_addr(bufp + TBF);
+    unsigned addrT = d_lds_addr(bufp + 4 * qd);
+    i32x4 io0 = d_lds_ld128(addrT);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(io0));
+    addrT += 64u;
+    g0.load_b(addrT, xbase, lanebase, io0);           // + the offsets of quad 1
+    E2_WAIT()
+    g0.touch();
+    if (nQ == 1 && partial) g0.mask(lastLim);
+    for (int q = 0; q < nQ; q += 2) {
+      const bool has1 = q + 1 < nQ;
+      if (has1) {
+        abase += 16; addrT += 64u;
+        g1.load_a(abase, voffA);
+        g1.load_b(addrT, xbase, lanebase, g0.io);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      E2_MFMA(g0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!has1) break;
+      E2_WAIT()
+      g1.touch();
+      if (q + 2 == nQ && partial) g1.mask(lastLim);
+      const bool has2 = q + 2 < nQ;
+      if (has2) {
+        abase += 16; addrT += 64u;
+        g0.load_a(abase, voffA);
+        g0.load_b(addrT, xbase, lanebase, g1.io);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      E2_MFMA(g1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (!has2) break;
+      E2_WAIT()
+      g0.touch();
+      if (q + 3 == nQ && partial) g0.mask(lastLim);
+    }
+  }
+#undef E2_MFMA
+#undef E2_WAIT
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  g0.touch();
+  g1.touch();
+
+  // ---- flush: row = co (4*qd+reg), col = n-index (lane&15) -----------------
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) {
+    const int jn = n0 + (wn * NT + nb) * 16 + l15;
+    if (jn >= p.NTOT) continue;
+    int col = jn;
+    if (p.flip) {
+      const int ci = jn / p.T;
+      const int tap = jn - ci * p.T;
+      col = ci * p.T + (p.T - 1 - tap);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = m0 + mb * 16 + 4 * qd + rr;
+        if (co < p.Cout) {
+          float* dst;
+          if (p.upR > 1) {
+            const int cr = co / p.upR;
+            dst = p.dw + ((long)cr * p.NTOT + col) * p.upR + (co - cr * p.upR);
+          } else {
+            dst = p.dw + (long)co * p.NTOT + col;
+          }
+          unsafeAtomicAdd(dst, acc[mb][nb][rr]);
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int BP>
+static int launch_d(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&wgrad_direct_kernel<MT, NT, BP>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wgrad_direct_kernel<MT, NT, BP>), dim3(grid), dim3(512), lds, ctx->stream, p);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int MT>
+static int dispatch_d2(e2_ctx* ctx, const WdP& p, int NT, int BP, int grid, size_t lds) {
+  if (BP == 128) {
+    if (NT == 1) return launch_d<MT, 1, 128>(ctx, p, grid, lds);
+    if (NT == 2) return launch_d<MT, 2, 128>(ctx, p, grid, lds);
+    if (NT == 4) return launch_d<MT, 4, 128>(ctx, p, grid, lds);
+  } else if (BP == 256) {
+    if (NT == 1) return launch_d<MT, 1, 256>(ctx, p, grid, lds);
+    if (NT == 2) return launch_d<MT, 2, 256>(ctx, p, grid, lds);
+    if (NT == 4) return launch_d<MT, 4, 256>(ctx, p, grid, lds);
+  }
+  e2_set_error("wgrad(direct): no instance NT=%d BP=%d", NT, BP);
+  return 2;
+}
+
+}  // namespace
+
+// geometry helpers shared with the host-side tiling choice (conv_wgrad.hip)
+int e2i_wgrad_direct_lpad(const WgradArgs& a, int BP) {
+  const int rows = (BP + (int)a.dsY - 2) / (int)a.dsY;      // rows crossed by BP span positions
+  const int lmax = rows * (int)a.xsY + (a.Wo - 1) + (a.kh - 1) * (int)a.xsY + a.kw;
+  int lp = ((lmax + 3 + 3) / 4) * 4;                        // + the straddling DMA lane
+  if ((lp & 31) == 0) lp += 4;
+  return lp;
+}
+static int d_maxspans(const WgradArgs& a, int BNn) {
+  const int T = a.kd * a.kh * a.kw;
+  int cis = (BNn - 1) / T + 2;
+  if (cis > a.Cin) cis = a.Cin;
+  return cis * a.kd;
+}
+size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP) {
+  return (size_t)(BP + 16) + (size_t)d_maxspans(a, 16 * NT * 4) * e2i_wgrad_direct_lpad(a, BP) + 64;
+}
+
+int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, int PS) {
+  E2_REQUIRE(BP == 128 || BP == 256, "wgrad(direct): BP must be 128 or 256");
+  E2_REQUIRE(a.xsY < (1 << 20) && a.dsY < (1 << 20), "wgrad: row stride too large");
+  E2_REQUIRE((long)a.Cout * a.dsC < (1L << 29), "wgrad(direct): gradient sample too large");
+  WdP p;
+  p.x = a.x; p.dy = a.dy; p.dw = a.dw;
+  p.Cin = a.Cin; p.Cout = a.Cout; p.kd = a.kd; p.kh = a.kh; p.kw = a.kw;
+  p.THW = a.kh * a.kw; p.T = a.kd * p.THW;
+  p.Do = a.Do; p.Ho = a.Ho; p.Wo = a.Wo;
+  p.S = (a.Ho - 1) * (int)a.dsY + a.Wo;
+  p.xsN = a.xsN; p.xsC = a.xsC; p.xsZ = a.xsZ; p.xsY = a.xsY;
+  p.dsN = a.dsN; p.dsC = a.dsC; p.dsZ = a.dsZ; p.dsY = a.dsY;
+  p.flip = a.flip;
+  p.upR = a.upR > 1 ? a.upR : 1;
+  const long NTOT = (long)a.Cin * p.T;
+  E2_REQUIRE(NTOT < (1L << 30), "wgrad: Cin*T too large");
+  p.NTOT = (int)NTOT;
+  const int BNn = 16 * NT * 4;
+  p.Lpad = e2i_wgrad_direct_lpad(a, BP);
+  p.maxSpans = d_maxspans(a, BNn);
+  p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), MT);
+  p.nNT = e2_cdiv(e2_cdiv(p.NTOT, 16), NT * 4);
+  p.nPT = e2_cdiv(p.S, BP);
+  p.tilesTotal = a.N * a.Do * p.nPT;
+  p.nPS = std::max(1, std::min(PS, p.tilesTotal));
+  p.bufFloats = (int)e2i_wgrad_direct_buf_floats(a, NT, BP);
+  p.Din = a.Do + a.kd - 1;
+  p.N = a.N;
+  p.divDsY = mk_divd((unsigned)a.dsY);
+  p.dbg = getenv("E2_WGRAD_DBG") ? atoi(getenv("E2_WGRAD_DBG")) : 0;
+  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  E2_REQUIRE(lds <= 160 * 1024, "wgrad(direct): tiling needs %zu B of LDS", lds);
+  const long grid = (long)p.nMT * p.nNT * p.nPS;
+  E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
+  if (!a.accumulate)
+    E2_CHECK_HIP(hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.Cout * p.NTOT, ctx->stream));
+  if (getenv("E2_VERBOSE"))
+    fprintf(stderr, "[e2] wgrad(direct) Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d BP=%d PS=%d grid=%ld lds=%zu\n",
+            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, MT, NT, BP, p.nPS, grid, lds);
+  switch (MT) {
+    case 1: return dispatch_d2<1>(ctx, p, NT, BP, (int)grid, lds);
+    case 2: return dispatch_d2<2>(ctx, p, NT, BP, (int)grid, lds);
+    case 3: return dispatch_d2<3>(ctx, p, NT, BP, (int)grid, lds);
+    case 4: return dispatch_d2<4>(ctx, p, NT, BP, (int)grid, lds);
+    case 5: return dispatch_d2<5>(ctx, p, NT, BP, (int)grid, lds);
+    case 7: return dispatch_d2<7>(ctx, p, NT, BP, (int)grid, lds);
+  }
+  e2_set_error("wgrad(direct): no instance MT=%d", MT);
+  return 2;
+}

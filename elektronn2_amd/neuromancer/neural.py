@@ -271,7 +271,11 @@ class Conv(NeuralLayer):
         plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 0))
         if plan.training:
             pad = [kk - 1 for kk in k]
-            dyp = plan.zeros((N, self.n_f) + tuple(osp[i] + 2 * pad[i] for i in range(3)))
+            # zero-padded output gradient: dgrad runs a plain correlation over it and
+            # wgrad fetches it 16 bytes per lane (64 B of slack behind the last element)
+            pshape = (N, self.n_f) + tuple(osp[i] + 2 * pad[i] for i in range(3))
+            flat = plan.zeros_flat(int(np.prod(pshape)) + 32)
+            dyp = flat[:int(np.prod(pshape))].view(pshape)
             plan.scratch[self, 'dy_pad'] = dyp
             plan.scratch[self, 'dy'] = dyp[:, :, pad[0]:pad[0] + osp[0],
                                            pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]]
@@ -311,12 +315,13 @@ class Conv(NeuralLayer):
                               self.activation_func, dy, plan.pgrad(self.b))
         cin = self.parent.shape['f']
         dw = plan.pgrad(self.w)
+        dyp = plan.scratch[self, 'dy_pad']
         sigw = (self.n_f, cin) + tuple(self.filter_shape) + tuple(dy.shape[2:]) + \
             (x.stride(3), dy.stride(3))
         plan.tuned('wgrad', sigw,
                    autotune.wgrad_candidates(self.n_f, cin, self.filter_shape, dy.shape[2:]),
-                   lambda: ctx.conv3d_wgrad(x, dy, dw, accumulate=True),
-                   fn_tune=lambda: ctx.conv3d_wgrad(x, dy, dw, accumulate=False))
+                   lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=True),
+                   fn_tune=lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=False))
         if plan.needs_grad(self.parent):
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

@@ -111,6 +111,36 @@ def test_conv3d_1x1_forced_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
+@pytest.mark.parametrize("force", ["1,1,1,128,3", "2,2,1,256,5", "3,4,1,128,2", "4,1,1,256,7",
+                                   "5,2,1,128,1", "7,4,1,128,3", "7,2,1,256,2", "7,1,1,128,40"])
+@pytest.mark.parametrize("k", [(2, 3, 3), (1, 1, 1), (1, 4, 1)])
+def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
+    """direct kernel: dy from the zero-padded buffer; partial quads at the plane ends,
+    N = 2, kd > 1, no padding at all (1x1x1), column padding only (1,4,1)."""
+    rng = np.random.RandomState(9)
+    x = rng.rand(2, 9, 4, 12, 21).astype(np.float32)
+    w = (rng.randn(100, 9, *k) / 8).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dw_ref = O.conv3d_wgrad(dy, x, w.shape)
+    osp = y_ref.shape[2:]
+    pad = [kk - 1 for kk in k]
+    pshape = (2, 100) + tuple(osp[i] + 2 * pad[i] for i in range(3))
+    flat = torch.zeros(int(np.prod(pshape)) + 16, device="cuda")
+    flat[-16:] = float("nan")              # the slack may be read, never used
+    dyp = flat[:int(np.prod(pshape))].view(pshape)
+    dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
+    dw = torch.full(w.shape, float("nan"), device="cuda")
+    os.environ["E2_WGRAD_FORCE"] = force
+    try:
+        ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
+        assert relerr(dw, dw_ref) < TOL
+        ctx.conv3d_wgrad_pad(dev(x), dyp, dw, accumulate=True)
+        assert relerr(dw, 2 * dw_ref) < TOL
+    finally:
+        del os.environ["E2_WGRAD_FORCE"]
+
+
 @pytest.mark.parametrize("force", ["1,1,1,64,3", "2,2,1,128,5", "3,4,1,64,2", "4,1,4,128,7",
                                    "5,2,1,64,1", "7,4,1,128,3", "1,1,4,64,2", "7,1,1,64,4"])
 def test_conv3d_wgrad_forced_tilings(ctx, force):

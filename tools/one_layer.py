@@ -14,14 +14,19 @@ osp = (D - kd + 1, H - kh + 1, W - kw + 1)
 x = torch.rand(1, cin, D, H, W, device="cuda")
 w = torch.randn(cout, cin, *k, device="cuda") * 0.05
 y = torch.empty(1, cout, *osp, device="cuda")
-dyp = torch.randn(1, cout, *[osp[i] + 2 * (k[i] - 1) for i in range(3)], device="cuda")
+pshape = (1, cout) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+import numpy as np
+flat = torch.zeros(int(np.prod(pshape)) + 16, device="cuda")
+dyp = flat[:int(np.prod(pshape))].view(pshape)
+dyp[:, :, kd - 1:kd - 1 + osp[0], kh - 1:kh - 1 + osp[1], kw - 1:kw - 1 + osp[2]] = torch.randn(1, cout, *osp, device="cuda")
 dy = dyp[:, :, kd - 1:kd - 1 + osp[0], kh - 1:kh - 1 + osp[1], kw - 1:kw - 1 + osp[2]]
 dx = torch.empty_like(x); dw = torch.empty_like(w)
 ws = torch.empty(ctx.conv_ws_bytes(cout, cin, k) // 4 + 64, device="cuda")
 ctx.conv3d_pack(w, 0 if op == "fwd" else 1, ws)
 fn = {"fwd": lambda: ctx.conv3d_fwd_packed(x, ws, cout, k, y),
       "dgrad": lambda: ctx.conv3d_dgrad_packed(dyp, ws, cin, k, dx),
-      "wgrad": lambda: ctx.conv3d_wgrad(x, dy, dw)}[op]
+      "wgrad": lambda: ctx.conv3d_wgrad(x, dy, dw),
+      "wgradp": lambda: ctx.conv3d_wgrad_pad(x, dyp, dw)}[op]
 for _ in range(3):
     fn()
 e0, e1 = ctx.event(), ctx.event()
