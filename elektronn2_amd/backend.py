@@ -240,10 +240,19 @@ class Context:
                                         w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
                                         C.byref(t5(out))), "e2_conv1_pool_act_fwd")
 
-    def conv1_pool_act_bwd(self, x, w, bias, dout, pool, act, dw, dbias):
+    @staticmethod
+    def conv1_bwd_ws_bytes(dout_shape, k):
+        n, cout, d, ho, wo = (int(v) for v in dout_shape)
+        return int(_lib.e2_conv1_bwd_workspace_bytes(n, cout, d, ho, wo, k[1], k[2]))
+
+    def conv1_pool_act_bwd(self, x, w, bias, dout, pool, act, dw, dbias, ws=None):
+        if ws is None:
+            ws = torch.empty(self.conv1_bwd_ws_bytes(dout.shape, w.shape[2:]) // 4 + 16,
+                             dtype=torch.float32, device=self.device)
         _chk(_lib.e2_conv1_pool_act_bwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias),
                                         C.byref(t5(dout)), w.shape[3], w.shape[4], pool[1],
-                                        pool[2], ACT[act], _fp(dw), _fp(dbias)),
+                                        pool[2], ACT[act], _fp(dw), _fp(dbias),
+                                        C.c_void_p(ws.data_ptr()), ws.numel() * 4),
              "e2_conv1_pool_act_bwd")
 
     # ---- pool / bias / act ---------------------------------------------------

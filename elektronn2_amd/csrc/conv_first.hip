@@ -13,9 +13,10 @@
 //   backward: the conv values are RECOMPUTED from the same window (no 59.6 MB
 //             read), ties handled like Theano's MaxPoolGrad (every element equal
 //             to the window max gets the gradient, relu'(0) = 0.5); the lane's
-//             dw[tap] contributions are reduced wave-shuffle -> LDS -> one global
-//             atomic per (co,tap) per work-group; work-groups are persistent so
-//             the atomic count stays ~256 per address.
+//             dw[tap] contributions are reduced with a transposing butterfly
+//             (15 cross-lane moves per 16 taps) -> LDS -> 17 sums per (tile,
+//             channel) in a workspace; a second tiny kernel adds the tiles up
+//             (contended same-line atomics were the cost of the first version).
 // VALU kernels: bounded by HBM (read 3 MB, write 15 MB / read 3+15 MB).
 #include "common.hpp"
 #include <algorithm>
@@ -97,76 +98,115 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(First p, int nTiles) {
   }
 }
 
+// Transposing butterfly: every lane holds T = 16 partial sums v[0..15] (one per
+// tap); after 4 exchange steps lane l holds in v[0] the sum over its 16-lane group
+// of tap bitrev4(l & 15).  15 cross-lane moves instead of 16 x 4.
+template <int MASK, int N>
+__device__ __forceinline__ void ff_bfly_step(float (&v)[16], int lane) {
+  const bool up = (lane & MASK) != 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float keep = up ? v[i + N] : v[i];
+    const float send = up ? v[i] : v[i + N];
+    v[i] = keep + __shfl_xor(send, MASK, 64);
+  }
+}
+__device__ __forceinline__ void ff_butterfly16(float (&v)[16], int lane) {
+  ff_bfly_step<1, 8>(v, lane);
+  ff_bfly_step<2, 4>(v, lane);
+  ff_bfly_step<4, 2>(v, lane);
+  ff_bfly_step<8, 1>(v, lane);
+}
+
+// One work-group = one tile of 32 x 8 pooled outputs, all channels: the window is
+// loaded once, the lane's dw[tap] contributions of a channel are reduced with the
+// butterfly -> LDS -> 17 sums per (tile, channel) stored to the workspace
+// part[tile][co][T+1]; first_bwd_reduce_kernel adds the tiles up.
 template <int KH, int KW, int PY, int PX>
-__global__ __launch_bounds__(256) void first_bwd_kernel(First p, int nTiles) {
+__global__ __launch_bounds__(256) void first_bwd_kernel(First p, float* __restrict__ part) {
   constexpr int T = KH * KW;
-  __shared__ float red[4][T + 1];
+  static_assert(T == 16 || T == 36, "tap count");
+  __shared__ float red[2][16][T + 1];
   const int lane_x = threadIdx.x & 31, row = threadIdx.x >> 5;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // channel-outer: the lane keeps its dw[tap] partial sums of ONE output channel
-  // in registers over all of the work-group's tiles (windows are re-read from
-  // L1/L2), so the cross-lane reduction runs once per channel, not per tile.
+  const int lane = threadIdx.x & 63;
+  const int grp = threadIdx.x >> 4;                 // 16 groups of 16 lanes
+  const int tile = blockIdx.x;
+  float win[PY + KH - 1][PX + KW - 1];
+  int n, z, yo, xo;
+  const bool valid = first_load_window<KH, KW, PY, PX>(p, tile, lane_x, row, win, n, z, yo, xo);
+  const float* gp = p.dout + (long)n * p.osN + (long)z * p.osD + (long)yo * p.osH + xo;
   for (int co = 0; co < p.Cout; ++co) {
     const float* wc = p.w + co * T;
     const float bv = p.bias[co];
-    float dwa[KH][KW];
+    float c[PY][PX];
+    float m = -INFINITY;
 #pragma unroll
-    for (int ty = 0; ty < KH; ++ty)
+    for (int a = 0; a < PY; ++a)
 #pragma unroll
-      for (int tx = 0; tx < KW; ++tx) dwa[ty][tx] = 0.f;
-    float gsum = 0.f;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
-      float win[PY + KH - 1][PX + KW - 1];
-      int n, z, yo, xo;
-      const bool valid = first_load_window<KH, KW, PY, PX>(p, tile, lane_x, row, win, n, z, yo, xo);
-      float c[PY][PX];
-      float m = -INFINITY;
-#pragma unroll
-      for (int a = 0; a < PY; ++a)
-#pragma unroll
-        for (int b = 0; b < PX; ++b) {
-          c[a][b] = first_conv<KH, KW, PY, PX>(win, wc, a, b);
-          m = fmaxf(m, c[a][b]);
-        }
-      float g = valid ? p.dout[(long)n * p.osN + (long)co * p.osC + (long)z * p.osD +
-                               (long)yo * p.osH + xo] : 0.f;
-      if (p.act == E2_ACT_RELU) {
-        const float pre = m + bv;
-        g *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
+      for (int b = 0; b < PX; ++b) {
+        c[a][b] = first_conv<KH, KW, PY, PX>(win, wc, a, b);
+        m = fmaxf(m, c[a][b]);
       }
-      gsum += g;
-#pragma unroll
-      for (int a = 0; a < PY; ++a)
-#pragma unroll
-        for (int b = 0; b < PX; ++b) {
-          const float gm = (c[a][b] == m) ? g : 0.f;     // every tied maximum gets the gradient
-#pragma unroll
-          for (int ty = 0; ty < KH; ++ty)
-#pragma unroll
-            for (int tx = 0; tx < KW; ++tx) dwa[ty][tx] = fmaf(gm, win[a + ty][b + tx], dwa[ty][tx]);
-        }
+    float g = valid ? gp[(long)co * p.osC] : 0.f;
+    if (p.act == E2_ACT_RELU) {
+      const float pre = m + bv;
+      g *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
     }
-    // wave shuffle -> LDS -> one global atomic per (co, tap) per work-group
+    float (&rb)[16][T + 1] = red[co & 1];
+    // taps in chunks of 16: dw partials of the lane, then the transposing butterfly
 #pragma unroll
-    for (int ty = 0; ty < KH; ++ty)
+    for (int t0 = 0; t0 < T; t0 += 16) {
+      float v[16];
 #pragma unroll
-      for (int tx = 0; tx < KW; ++tx) {
-        const float s = ff_wave_sum(dwa[ty][tx]);
-        if (lane == 0) red[wave][ty * KW + tx] = s;
+      for (int i = 0; i < 16; ++i) {
+        const int t = t0 + i;
+        float acc = 0.f;
+        if (t < T) {
+          const int ty = t / KW, tx = t % KW;
+#pragma unroll
+          for (int a = 0; a < PY; ++a)
+#pragma unroll
+            for (int b = 0; b < PX; ++b)      // every tied maximum gets the gradient
+              acc = fmaf((c[a][b] == m) ? g : 0.f, win[a + ty][b + tx], acc);
+        }
+        v[i] = acc;
       }
-    const float gs = ff_wave_sum(gsum);
-    if (lane == 0) red[wave][T] = gs;
+      ff_butterfly16(v, lane);
+      const int l15 = lane & 15;
+      const int tap = t0 + ((l15 & 1) << 3 | (l15 & 2) << 1 | (l15 & 4) >> 1 | (l15 & 8) >> 3);
+      if (tap < T) rb[grp][tap] = v[0];
+    }
+    float gs = g;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) gs += __shfl_xor(gs, o, 64);
+    if ((lane & 15) == 0) rb[grp][T] = gs;
     __syncthreads();
     if (threadIdx.x <= T) {
-      const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
-                      red[3][threadIdx.x];
-      if (v != 0.f) {
-        // tap position t  <->  weight index T-1-t (flip, F1)
-        if (threadIdx.x < T) unsafeAtomicAdd(p.dw + co * T + (T - 1 - threadIdx.x), v);
-        else unsafeAtomicAdd(p.dbias + co, v);
-      }
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) sum += rb[k][threadIdx.x];
+      part[((long)tile * p.Cout + co) * (T + 1) + threadIdx.x] = sum;
     }
-    __syncthreads();
+    // red[] is double buffered: the next channel writes the other half, and the
+    // barrier of that channel orders this read before the half is written again
+  }
+}
+
+// dw[co][T-1-t] += sum_tiles part[tile][co][t];  dbias[co] += sum_tiles part[tile][co][T]
+__global__ __launch_bounds__(256) void first_bwd_reduce_kernel(const float* __restrict__ part,
+                                                               int nTiles, int Cout, int T,
+                                                               float* dw, float* dbias) {
+  const int per = (nTiles + gridDim.y - 1) / gridDim.y;
+  const int t0 = blockIdx.y * per, t1 = min(t0 + per, nTiles);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = Cout * (T + 1);
+  if (idx >= total) return;
+  float s = 0.f;
+  for (int t = t0; t < t1; ++t) s += part[(long)t * total + idx];
+  const int co = idx / (T + 1), k = idx - co * (T + 1);
+  if (s != 0.f) {
+    if (k < T) unsafeAtomicAdd(dw + co * T + (T - 1 - k), s);    // tap t <-> weight index T-1-t (flip, F1)
+    else unsafeAtomicAdd(dbias + co, s);
   }
 }
 
@@ -219,11 +259,19 @@ extern "C" int e2_conv1_pool_act_fwd(e2_ctx* ctx, const e2_tensor5* x, const flo
   return 0;
 }
 
-/* dw (cout*kh*kw) and dbias (cout) are ACCUMULATED into: zero them first. */
+extern "C" size_t e2_conv1_bwd_workspace_bytes(int n, int cout, int d, int ho, int wo, int kh,
+                                               int kw) {
+  const long tiles = (long)n * d * e2_cdiv(ho, 8) * e2_cdiv(wo, 32);
+  return sizeof(float) * (size_t)tiles * cout * (kh * kw + 1);
+}
+
+/* dw (cout*kh*kw) and dbias (cout) are ACCUMULATED into: zero them first.
+ * ws: e2_conv1_bwd_workspace_bytes(n, cout, d, ho, wo, kh, kw) bytes, (ho, wo) = pooled dims. */
 extern "C" int e2_conv1_pool_act_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
                                      const float* bias, const e2_tensor5* dout, int kh, int kw,
-                                     int py, int px, int act, float* dw, float* dbias) {
-  E2_REQUIRE(ctx && w && bias && dw && dbias, "conv1_pool_act_bwd: null argument");
+                                     int py, int px, int act, float* dw, float* dbias,
+                                     void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && w && bias && dw && dbias && ws, "conv1_pool_act_bwd: null argument");
   const int v = first_supported(1, kh, kw, 1, py, px);
   E2_REQUIRE(v, "conv1_pool_act_bwd: unsupported kernel/pool %dx%d / %dx%d", kh, kw, py, px);
   First p{};
@@ -231,12 +279,19 @@ extern "C" int e2_conv1_pool_act_bwd(e2_ctx* ctx, const e2_tensor5* x, const flo
     return rc;
   p.w = w; p.bias = bias; p.dout = dout->ptr; p.dw = dw; p.dbias = dbias; p.act = act;
   const long nTiles = (long)p.N * p.D * p.tilesY * p.tilesX;
-  const int grid = (int)std::min<long>(nTiles, ctx->num_cu * 2);
-  const size_t lds = 0;
+  E2_REQUIRE(nTiles < (1L << 31), "conv1_pool_act_bwd: too many tiles");
+  E2_REQUIRE(ws_bytes >= e2_conv1_bwd_workspace_bytes(p.N, p.Cout, p.D, p.Ho, p.Wo, kh, kw),
+             "conv1_pool_act_bwd: workspace too small");
+  float* part = (float*)ws;
   if (v == 1)
-    hipLaunchKernelGGL((first_bwd_kernel<4, 4, 2, 2>), dim3(grid), dim3(256), lds, ctx->stream, p, (int)nTiles);
+    hipLaunchKernelGGL((first_bwd_kernel<4, 4, 2, 2>), dim3((int)nTiles), dim3(256), 0, ctx->stream, p, part);
   else
-    hipLaunchKernelGGL((first_bwd_kernel<6, 6, 2, 2>), dim3(grid), dim3(256), lds, ctx->stream, p, (int)nTiles);
+    hipLaunchKernelGGL((first_bwd_kernel<6, 6, 2, 2>), dim3((int)nTiles), dim3(256), 0, ctx->stream, p, part);
+  E2_CHECK_HIP(hipGetLastError());
+  const int T = kh * kw, total = p.Cout * (T + 1);
+  const int slices = (int)std::min<long>(nTiles, 64);
+  hipLaunchKernelGGL(first_bwd_reduce_kernel, dim3(e2_cdiv(total, 256), slices), dim3(256), 0,
+                     ctx->stream, part, (int)nTiles, p.Cout, T, dw, dbias);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

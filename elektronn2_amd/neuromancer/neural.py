@@ -261,6 +261,9 @@ class Conv(NeuralLayer):
         k = self.filter_shape
         if self._fused_first(plan):
             plan.alloc_out(self)
+            if plan.training:
+                nb = plan.ctx.conv1_bwd_ws_bytes(plan.out_shape(self), k)
+                plan.scratch[self, 'ws1'] = plan.empty_flat(nb // 4 + 16)
             return
         osp = [psp[i] - k[i] + 1 for i in range(3)]
         plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
@@ -307,7 +310,7 @@ class Conv(NeuralLayer):
         if self._fused_first(plan):
             ctx.conv1_pool_act_bwd(x, plan.param(self.w), plan.param(self.b), plan.grad[self],
                                    self.pool_shape, self.activation_func, plan.pgrad(self.w),
-                                   plan.pgrad(self.b))
+                                   plan.pgrad(self.b), ws=plan.scratch[self, 'ws1'])
             return
         y = plan.scratch[self, 'y']
         dy = plan.scratch[self, 'dy']

@@ -119,9 +119,13 @@ int e2_conv1_supported(int cin, int kd, int kh, int kw, int pz, int py, int px);
 int e2_conv1_pool_act_fwd(e2_ctx*, const e2_tensor5* x, const float* w,
                           const float* bias, int cout, int kh, int kw, int py,
                           int px, int act, const e2_tensor5* out);
+/* workspace of the backward: per-tile partial sums, (n, cout, d, ho, wo) = dims of
+ * the POOLED output gradient */
+size_t e2_conv1_bwd_workspace_bytes(int n, int cout, int d, int ho, int wo, int kh, int kw);
 int e2_conv1_pool_act_bwd(e2_ctx*, const e2_tensor5* x, const float* w,
                           const float* bias, const e2_tensor5* dout, int kh,
-                          int kw, int py, int px, int act, float* dw, float* dbias);
+                          int kw, int py, int px, int act, float* dw, float* dbias,
+                          void* ws, size_t ws_bytes);
 
 /* ---- pool + bias + activation  (computations.py:538-631 pooling();
  *      neural.py:705-712; computations.py:57-134 apply_activation) -------- */
