@@ -207,7 +207,7 @@ class Context:
              "e2_conv3d_wgrad")
 
     def conv3d_wgrad_pad(self, x, dy_pad, dw, accumulate=False):
-        """wgrad from the zero-padded gradient buffer (borders zero, >= 64 readable
+        """wgrad from the zero-padded gradient buffer (borders zero, >= 128 readable
         bytes after its last element): the direct kernel."""
         kd, kh, kw = dw.shape[2:]
         _chk(_lib.e2_conv3d_wgrad_pad(self.h, C.byref(t5(x)), C.byref(t5(dy_pad)), _fp(dw),

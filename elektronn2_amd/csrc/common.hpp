@@ -80,7 +80,7 @@ struct WgradArgs {
   int upR;            // >1: rows are (co*R + r); store dw[co][col][r] (UpConv)
   int accumulate;     // 1: dw += grad (caller zeroed it); 0: dw = grad
   int dy_padded;      // 1: dy is the interior of a zero-padded buffer (row gaps hold
-                      //    zeros, >= 64 readable bytes follow its last element)
+                      //    zeros, >= 128 readable bytes follow its last element)
 };
 int e2i_upconv_dpre_s2d(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* yout, int pz,
                         int py, int px, int act, float* s2d, float* dbias);

@@ -18,8 +18,9 @@
 //     span (gap columns are clamped to the row's last position: their dy is 0).
 //   * four PRODUCER waves build the table and issue the LDS-DMA of the input spans
 //     of the next tile; the four compute waves only load operands and issue MFMAs.
-// Positions past the end of a plane's span (the last, partial quad of a plane) are
-// masked out of A with v_cndmask after the load.
+// Positions past the end of a plane's span (the last one or two quads of a plane) are
+// masked out of A with v_cndmask after the load; the loads themselves may run up to
+// 31 floats past the span, hence the 128 B of slack the entry point asks for.
 #include "common.hpp"
 #include <stdlib.h>
 #include <algorithm>
@@ -128,6 +129,56 @@ struct DQuad {
   }
 };
 
+// addresses the next quad's loads need
+template <int MT, int NT>
+struct DAddr {
+  const float* abase;
+  unsigned voff[MT];
+  unsigned addrT;
+  unsigned xbase;
+  int lanebase[NT];
+};
+// load r of the next quad, in issue order: dy rows (global, longest latency), the
+// offsets of the quad after it, then the gathered inputs (LDS)
+template <int MT, int NT, int R>
+__device__ __forceinline__ void dquad_read(DQuad<MT, NT>& g, const DAddr<MT, NT>& ad,
+                                           const i32x4& cur_io) {
+  if constexpr (R < MT) {
+    g.a[R] = d_gl_ld128(ad.abase, ad.voff[R]);
+  } else if constexpr (R == MT) {
+    g.io = d_lds_ld128(ad.addrT);
+  } else {
+    constexpr int rb = R - MT - 1;
+    constexpr int j = rb / NT, nb = rb % NT;
+    g.b[j][nb] = d_lds_ld(ad.xbase + 4u * (unsigned)(ad.lanebase[nb] + cur_io[j]));
+  }
+}
+template <int MT, int NT, int R0, int R1>
+__device__ __forceinline__ void dquad_reads(DQuad<MT, NT>& g, const DAddr<MT, NT>& ad,
+                                            const i32x4& cur_io) {
+  if constexpr (R0 < R1) {
+    dquad_read<MT, NT, R0>(g, ad, cur_io);
+    dquad_reads<MT, NT, R0 + 1, R1>(g, ad, cur_io);
+  }
+}
+// MFMA i of the current quad, then its share of the next quad's loads (spread over
+// the first 3/4 of the MFMAs; PF = false: no next quad)
+template <int MT, int NT, bool PF, int I>
+__device__ __forceinline__ void dquad_steps(const DQuad<MT, NT>& cur, DQuad<MT, NT>& nxt,
+                                            f32x4 (&acc)[MT][NT], const DAddr<MT, NT>& ad,
+                                            const i32x4& nio) {
+  constexpr int M = 4 * MT * NT, R = MT + 1 + 4 * NT;
+  constexpr int j = I / (MT * NT), mb = (I / NT) % MT, nb = I % NT;
+  acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[mb][j], cur.b[j][nb], acc[mb][nb], 0, 0, 0);
+  if constexpr (PF) {
+    constexpr int r0 = (I * R * 4) / (3 * M) < R ? (I * R * 4) / (3 * M) : R;
+    constexpr int r1 = ((I + 1) * R * 4) / (3 * M) < R ? ((I + 1) * R * 4) / (3 * M) : R;
+    dquad_reads<MT, NT, r0, r1>(nxt, ad, nio);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (I + 1 < M) dquad_steps<MT, NT, PF, I + 1>(cur, nxt, acc, ad, nio);
+}
+
 template <int MT, int NT, int BP>
 __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -230,11 +281,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     const int ty = t2 / p.kw, tx = t2 - ty * p.kw;
     lanebase[nb] = ((ci - ciA) * p.kd + dz) * Lpad + ty * xsY + tx;
   }
-  unsigned voffA[MT];
+  DAddr<MT, NT> ad;
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) ad.lanebase[nb] = lanebase[nb];
 #pragma unroll
   for (int mb = 0; mb < MT; ++mb) {
     const int co = min(m0 + mb * 16 + l15, p.Cout - 1);      // padded rows: discarded at the flush
-    voffA[mb] = 4u * (unsigned)((long)co * p.dsC + 4 * qd);
+    ad.voff[mb] = 4u * (unsigned)((long)co * p.dsC + 4 * qd);
   }
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -243,73 +296,89 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   DQuad<MT, NT> g0, g1;
-#define E2_MFMA(G)                                                       \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                          \
-  _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                      \
-  _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                      \
-    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[mb][j], G.b[j][nb], acc[mb][nb], 0, 0, 0);
 #define E2_WAIT()                                                        \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
   __builtin_amdgcn_sched_barrier(0);
 
-  for (int tt = tb; tt < te; ++tt) {
-    const int cur = (tt - tb) & 1;
+  // geometry of a tile.  Quads come in pairs (the two register sets ping-pong), so
+  // a tile at the end of a plane may carry one quad that lies wholly past the span:
+  // it is masked to zero like the tail of the partial quad before it.
+  auto tile_geom = [&](int tt, int& nQ, int& len) {
     const int pt = tt % p.nPT;
     const int zz = tt / p.nPT;
     const int z = zz % p.Do;
     const int n = zz / p.Do;
     const int s0 = pt * BP;
-    const int len = min(s0 + BP, p.S) - s0;          // valid span positions of the tile
-    const int nQ = (len + 15) >> 4;
-    const int lastLim = len - 16 * (nQ - 1) - 1 - 4 * qd;   // last valid j of this lane in the last quad
-    const bool partial = (len & 15) != 0;
-    const float* abase = p.dy + (long)n * p.dsN + (long)z * p.dsZ + s0;
-    // operands of the first quad: dy does not depend on the LDS contents
-    g0.load_a(abase, voffA);
+    len = min(s0 + BP, p.S) - s0;                    // valid span positions of the tile
+    nQ = 2 * ((len + 31) >> 5);
+    return p.dy + (long)n * p.dsN + (long)z * p.dsZ + s0;
+  };
+  // zero the k-steps of quad qi that lie past the tile's span
+#define E2_MASK(G, qi)                                                   \
+  if (16 * ((qi) + 1) > len) G.mask(len - 16 * (qi) - 1 - 4 * qd);
+  int nQ = 0, len = 0;
+  if (tb < te) {
+    // first quad of the first tile, fetched in the open
+    ad.abase = tile_geom(tb, nQ, len);
+    g0.load_a(ad.abase, ad.voff);                     // dy does not depend on the LDS contents
     __syncthreads();                                  // the producers' table + spans landed
-    if (p.dbg & 2) { E2_WAIT() g0.touch(); continue; }
-    const float* bufp = smem + cur * p.bufFloats;
-    const unsigned xbase = d_lds_addr(bufp + TBF);
-    unsigned addrT = d_lds_addr(bufp + 4 * qd);
-    i32x4 io0 = d_lds_ld128(addrT);
+    ad.xbase = d_lds_addr(smem + TBF);
+    ad.addrT = d_lds_addr(smem + 4 * qd);
+    i32x4 io0 = d_lds_ld128(ad.addrT);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" : "+v"(io0));
-    addrT += 64u;
-    g0.load_b(addrT, xbase, lanebase, io0);           // + the offsets of quad 1
+    ad.addrT += 64u;
+    g0.load_b(ad.addrT, ad.xbase, lanebase, io0);     // + the offsets of quad 1
     E2_WAIT()
     g0.touch();
-    if (nQ == 1 && partial) g0.mask(lastLim);
-    for (int q = 0; q < nQ; q += 2) {
-      const bool has1 = q + 1 < nQ;
-      if (has1) {
-        abase += 16; addrT += 64u;
-        g1.load_a(abase, voffA);
-        g1.load_b(addrT, xbase, lanebase, g0.io);
-      }
+    E2_MASK(g0, 0)
+  }
+  for (int tt = tb; tt < te; ++tt) {
+    // g0 holds quad 0 of tile tt; nQ is even
+    int q = 0;
+    for (; q + 2 < nQ; q += 2) {
+      ad.abase += 16; ad.addrT += 64u;
       __builtin_amdgcn_sched_barrier(0);
-      E2_MFMA(g0)
-      __builtin_amdgcn_sched_barrier(0);
-      if (!has1) break;
+      dquad_steps<MT, NT, true, 0>(g0, g1, acc, ad, g0.io);   // compute q, fetch q+1
       E2_WAIT()
       g1.touch();
-      if (q + 2 == nQ && partial) g1.mask(lastLim);
-      const bool has2 = q + 2 < nQ;
-      if (has2) {
-        abase += 16; addrT += 64u;
-        g0.load_a(abase, voffA);
-        g0.load_b(addrT, xbase, lanebase, g1.io);
-      }
+      E2_MASK(g1, q + 1)
+      ad.abase += 16; ad.addrT += 64u;
       __builtin_amdgcn_sched_barrier(0);
-      E2_MFMA(g1)
-      __builtin_amdgcn_sched_barrier(0);
-      if (!has2) break;
+      dquad_steps<MT, NT, true, 0>(g1, g0, acc, ad, g1.io);   // compute q+1, fetch q+2
       E2_WAIT()
       g0.touch();
-      if (q + 3 == nQ && partial) g0.mask(lastLim);
+      E2_MASK(g0, q + 2)
+    }
+    ad.abase += 16; ad.addrT += 64u;
+    __builtin_amdgcn_sched_barrier(0);
+    dquad_steps<MT, NT, true, 0>(g0, g1, acc, ad, g0.io);     // quad nQ-2, fetch the last one
+    E2_WAIT()
+    g1.touch();
+    E2_MASK(g1, q + 1)
+    // While the tile's last quad (g1) computes, fetch the first quad of the NEXT
+    // tile: its barrier, its first offsets, then the loads.
+    if (tt + 1 < te) {
+      ad.abase = tile_geom(tt + 1, nQ, len);
+      __syncthreads();                                // tile tt+1 landed; nobody reads tile tt's buffer any more
+      const float* bufp = smem + ((tt + 1 - tb) & 1) * p.bufFloats;
+      ad.xbase = d_lds_addr(bufp + TBF);
+      ad.addrT = d_lds_addr(bufp + 4 * qd);
+      i32x4 io0 = d_lds_ld128(ad.addrT);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(io0));
+      ad.addrT += 64u;
+      dquad_steps<MT, NT, true, 0>(g1, g0, acc, ad, io0);
+      E2_WAIT()
+      g0.touch();
+      E2_MASK(g0, 0)
+    } else {
+      dquad_steps<MT, NT, false, 0>(g1, g0, acc, ad, g1.io);
     }
   }
-#undef E2_MFMA
+#undef E2_MASK
 #undef E2_WAIT
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   g0.touch();

@@ -275,7 +275,7 @@ class Conv(NeuralLayer):
         if plan.training:
             pad = [kk - 1 for kk in k]
             # zero-padded output gradient: dgrad runs a plain correlation over it and
-            # wgrad fetches it 16 bytes per lane (64 B of slack behind the last element)
+            # wgrad fetches it 16 bytes per lane (128 B of slack behind the last element)
             pshape = (N, self.n_f) + tuple(osp[i] + 2 * pad[i] for i in range(3))
             flat = plan.zeros_flat(int(np.prod(pshape)) + 32)
             dyp = flat[:int(np.prod(pshape))].view(pshape)

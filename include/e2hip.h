@@ -95,7 +95,7 @@ int e2_conv3d_wgrad_acc(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy,
 /* Fast path of the same gradient for the training plan: dy_pad is the ZERO-PADDED
  * gradient buffer that e2_conv3d_dgrad_packed reads, shape (n, cout, do+2(kd-1),
  * ho+2(kh-1), wo+2(kw-1)); the interior holds dy, the borders MUST be zero, and
- * at least 64 readable bytes must follow the buffer's last element (the kernel
+ * at least 128 readable bytes must follow the buffer's last element (the kernel
  * fetches dy straight from memory, 16 bytes per lane, and masks what lies past a
  * plane).  accumulate: 0 = dw is overwritten, 1 = dw += gradient. */
 int e2_conv3d_wgrad_pad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy_pad,

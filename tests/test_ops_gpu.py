@@ -126,8 +126,8 @@ def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
     osp = y_ref.shape[2:]
     pad = [kk - 1 for kk in k]
     pshape = (2, 100) + tuple(osp[i] + 2 * pad[i] for i in range(3))
-    flat = torch.zeros(int(np.prod(pshape)) + 16, device="cuda")
-    flat[-16:] = float("nan")              # the slack may be read, never used
+    flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
+    flat[-32:] = float("nan")              # the slack may be read, never used
     dyp = flat[:int(np.prod(pshape))].view(pshape)
     dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
     dw = torch.full(w.shape, float("nan"), device="cuda")

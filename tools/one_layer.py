@@ -16,7 +16,7 @@ w = torch.randn(cout, cin, *k, device="cuda") * 0.05
 y = torch.empty(1, cout, *osp, device="cuda")
 pshape = (1, cout) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
 import numpy as np
-flat = torch.zeros(int(np.prod(pshape)) + 16, device="cuda")
+flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
 dyp = flat[:int(np.prod(pshape))].view(pshape)
 dyp[:, :, kd - 1:kd - 1 + osp[0], kh - 1:kh - 1 + osp[1], kw - 1:kw - 1 + osp[2]] = torch.randn(1, cout, *osp, device="cuda")
 dy = dyp[:, :, kd - 1:kd - 1 + osp[0], kh - 1:kh - 1 + osp[1], kw - 1:kw - 1 + osp[2]]
