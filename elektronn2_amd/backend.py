@@ -61,6 +61,8 @@ def _load():
         "e2_pack_job_bytes": (sz, []),
         "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
         "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
+        "e2_stream_fork": (C.c_int, [vp, C.c_void_p]),
+        "e2_stream_join": (C.c_int, [vp, C.c_void_p]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5]),
         "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp]),
@@ -152,6 +154,12 @@ class Context:
         self.stream = stream
         _chk(_lib.e2_ctx_set_stream(self.h, C.c_void_p(stream.cuda_stream)),
              "e2_ctx_set_stream")
+
+    def stream_fork(self, side: torch.cuda.Stream):
+        _chk(_lib.e2_stream_fork(self.h, C.c_void_p(side.cuda_stream)), "e2_stream_fork")
+
+    def stream_join(self, side: torch.cuda.Stream):
+        _chk(_lib.e2_stream_join(self.h, C.c_void_p(side.cuda_stream)), "e2_stream_join")
 
     def synchronize(self):
         _chk(_lib.e2_stream_synchronize(self.h), "e2_stream_synchronize")

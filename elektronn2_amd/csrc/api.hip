@@ -32,6 +32,8 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->num_cu = prop.multiProcessorCount;
   c->capturing = false;
   c->zeros = nullptr;
+  c->fork_next = 0;
+  for (int i = 0; i < 32; ++i) c->fork_ev[i] = nullptr;
   if (hipMalloc(&c->zeros, 1024) != hipSuccess || hipMemset(c->zeros, 0, 1024) != hipSuccess) {
     delete c;
     e2_set_error("e2_ctx_create: cannot allocate the zero page");
@@ -43,7 +45,39 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
 
 extern "C" int e2_ctx_destroy(e2_ctx* ctx) {
   if (ctx && ctx->zeros) (void)hipFree(ctx->zeros);
+  if (ctx)
+    for (int i = 0; i < 32; ++i)
+      if (ctx->fork_ev[i]) (void)hipEventDestroy(ctx->fork_ev[i]);
   delete ctx;
+  return 0;
+}
+
+// Fork / join a second stream (also while the context's stream is being captured:
+// the side stream joins the capture, the launches on it become a parallel branch of
+// the graph).  Independent kernels -- the weight gradient of a layer and the data
+// gradient that feeds the layer below -- then share the chip: the work-groups of one
+// fill the CUs the other leaves idle (tails, 220-work-group grids on 256 CUs).
+static int fork_event(e2_ctx* ctx, hipEvent_t* ev) {
+  const int i = ctx->fork_next;
+  ctx->fork_next = (i + 1) & 31;
+  if (!ctx->fork_ev[i]) E2_CHECK_HIP(hipEventCreateWithFlags(&ctx->fork_ev[i], hipEventDisableTiming));
+  *ev = ctx->fork_ev[i];
+  return 0;
+}
+extern "C" int e2_stream_fork(e2_ctx* ctx, void* side) {
+  E2_REQUIRE(ctx && side && ctx->stream, "stream_fork: null argument / default stream");
+  hipEvent_t ev;
+  if (int rc = fork_event(ctx, &ev)) return rc;
+  E2_CHECK_HIP(hipEventRecord(ev, ctx->stream));
+  E2_CHECK_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(side), ev, 0));
+  return 0;
+}
+extern "C" int e2_stream_join(e2_ctx* ctx, void* side) {
+  E2_REQUIRE(ctx && side && ctx->stream, "stream_join: null argument / default stream");
+  hipEvent_t ev;
+  if (int rc = fork_event(ctx, &ev)) return rc;
+  E2_CHECK_HIP(hipEventRecord(ev, reinterpret_cast<hipStream_t>(side)));
+  E2_CHECK_HIP(hipStreamWaitEvent(ctx->stream, ev, 0));
   return 0;
 }
 

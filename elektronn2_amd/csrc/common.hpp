@@ -12,6 +12,8 @@ struct e2_ctx {
   int num_cu;
   bool capturing;
   float* zeros;        // 1 KiB of zeros in device memory (masked-lane DMA source)
+  hipEvent_t fork_ev[32];   // dependency events of e2_stream_fork / e2_stream_join
+  int fork_next;
 };
 
 void e2_set_error(const char* fmt, ...);

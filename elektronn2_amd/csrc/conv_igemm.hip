@@ -36,6 +36,7 @@
 #include "igemm_core.hpp"
 #include <stdlib.h>
 #include <algorithm>
+#include <vector>
 
 // ---- weight packing ---------------------------------------------------------
 // Wp[dz][cg = ic/4][t = ty*kw+tx][qd = ic%4][oc (coP)], zero padded: the K order
@@ -277,8 +278,13 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   E2_REQUIRE(p.nMT * 16 * c.MT <= a.coP, "igemm: packed coP too small");
   if (fast) E2_REQUIRE(((a.Cin + 15) / 16) * 16 <= a.ciP, "igemm: packed ciP too small");
   else E2_REQUIRE(p.nChunkC * c.CC <= a.ciP, "igemm: packed ciP too small");
-  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "igemm: forced tiling needs %zu B of LDS", lds);
+  // wide epilogue (fast path): dense output rows, plain stores
+  const size_t tile_lds = (size_t)4 * 16 * c.MT * (16 * c.NT + 4) * 4;
+  p.wide = (fast && p.splitK == 1 && a.upz * a.upy * a.upx == 1 && a.osY == a.Wo &&
+            std::max(lds, tile_lds) <= 160 * 1024 && !getenv("E2_IGEMM_NARROW")) ? 1 : 0;
+  if (p.wide) lds = std::max(lds, tile_lds);
   const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
   E2_REQUIRE(grid < (1L << 31), "igemm: grid too large");
   if (p.atomic) {
@@ -296,16 +302,48 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
       if (rc) return rc;
     }
   }
+  // debug: per-work-group timeline stamps (fast path only), printed after a sync
+  p.stamps = nullptr;
+  static unsigned long long* stamp_buf = nullptr;
+  const bool want_stamps = getenv("E2_IGEMM_STAMPS") != nullptr && fast && !ctx->capturing;
+  if (want_stamps) {
+    if (!stamp_buf) E2_CHECK_HIP(hipMalloc(&stamp_buf, 8 * sizeof(unsigned long long) * 65536));
+    E2_REQUIRE(grid <= 65536, "igemm stamps: grid too large");
+    E2_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long) * grid, ctx->stream));
+    p.stamps = stamp_buf;
+  }
   // 1x1 taps: four channel groups per pipeline step when the chunk allows it
   const int GU = (fast && p.THW == 1 && c.CC % 16 == 0) ? 4 : 1;
   if (getenv("E2_VERBOSE"))
     fprintf(stderr, "[e2] igemm Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d CC=%d SK=%d GU=%d grid=%ld lds=%zu\n",
             a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, GU, grid, lds);
+  int rc;
   switch (a.kw) {
-    case 1: return e2i_igemm_launch_k1(ctx, p, c.MT, c.NT, GU, (int)grid, lds);
-    case 3: return e2i_igemm_launch_k3(ctx, p, c.MT, c.NT, GU, (int)grid, lds);
-    case 4: return e2i_igemm_launch_k4(ctx, p, c.MT, c.NT, GU, (int)grid, lds);
-    case 5: return e2i_igemm_launch_k5(ctx, p, c.MT, c.NT, GU, (int)grid, lds);
+    case 1: rc = e2i_igemm_launch_k1(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+    case 3: rc = e2i_igemm_launch_k3(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+    case 4: rc = e2i_igemm_launch_k4(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+    case 5: rc = e2i_igemm_launch_k5(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+    default: rc = e2i_igemm_launch_generic(ctx, p, c.MT, c.NT, (int)grid, lds);
   }
-  return e2i_igemm_launch_generic(ctx, p, c.MT, c.NT, (int)grid, lds);
+  if (rc == 0 && want_stamps) {
+    std::vector<unsigned long long> h(8 * grid);
+    E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    E2_CHECK_HIP(hipMemcpy(h.data(), stamp_buf, 8 * sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+    unsigned long long r0 = ~0ull, r1 = 0;
+    double s_first = 0, s_loop = 0, s_epi = 0, s_tot = 0, max_tot = 0;
+    for (long b = 0; b < grid; ++b) {
+      const unsigned long long* s = &h[8 * b];
+      r0 = std::min(r0, s[0]); r1 = std::max(r1, s[5]);
+      s_first += (double)(s[2] - s[1]); s_loop += (double)(s[3] - s[2]);
+      s_epi += (double)(s[4] - s[3]); s_tot += (double)(s[4] - s[1]);
+      max_tot = std::max(max_tot, (double)(s[4] - s[1]));
+    }
+    double last_start = 0;
+    for (long b = 0; b < grid; ++b) last_start = std::max(last_start, (double)(h[8 * b] - r0));
+    fprintf(stderr, "[e2 stamps] grid=%ld  span(first start..last end)=%.2f us  last block start +%.2f us | per block (cycles, mean): "
+            "to first barrier %.0f, main loop %.0f, epilogue %.0f, total %.0f (max %.0f)\n",
+            grid, (double)(r1 - r0) * 0.01, last_start * 0.01, s_first / grid, s_loop / grid, s_epi / grid,
+            s_tot / grid, max_tot);
+  }
+  return rc;
 }

@@ -24,6 +24,9 @@ struct IgemmP {
   int atomic;
   int upz, upy, upx;
   int bufFloats;          // floats per LDS buffer
+  unsigned long long* stamps;   // debug (E2_IGEMM_STAMPS): 8 s_memtime stamps per work-group
+  int wide;               // 1: epilogue transposes the tile through LDS and stores 16 B per lane
+                          //    (dense output rows, no split-K, no UpConv scatter)
 };
 
 // async global -> LDS copies (no VGPR destination); LDS address is
@@ -224,10 +227,13 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
       __syncthreads();                       // chunk ch is in LDS; buffer of ch-1 is free
       if (ch + 1 < ce && !(p.dbg & 1)) stage(ch + 1, ((ch - cb) & 1) ^ 1);
     }
+    if (p.wide) __syncthreads();             // the compute waves reuse LDS for the epilogue
     return;
   }
 
   // ---- compute waves ----------------------------------------------------------
+  unsigned long long* st = (p.stamps && tid == 0) ? p.stamps + 8L * blockIdx.x : nullptr;
+  if (st) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = __builtin_amdgcn_s_memtime(); }
   int posoff[NT];
 #pragma unroll
   for (int nb = 0; nb < NT; ++nb) {
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
     ad.abase = chunk_abase(dz, cgi0);
     group_reads<MT, NT, KW, GU, 0, TPG * MT>(g0, ad);
     __syncthreads();                         // the producers saw their DMA land
+    if (st && ch == cb) st[2] = __builtin_amdgcn_s_memtime();
     if (p.dbg & 2) continue;
     const unsigned xbase = lds_addr(smem + cur * p.bufFloats);
 #pragma unroll
@@ -305,7 +312,52 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   g0.touch();
   g1.touch();
+  if (st) st[3] = __builtin_amdgcn_s_memtime();
 
+  // ---- epilogue, wide form: the wave's 16*MT x 16*NT tile goes through LDS so that
+  // a lane stores 4 consecutive positions of one channel (16 B): 4x fewer store
+  // instructions than the accumulator layout allows (the scalar form took ~10k
+  // cycles per work-group, store-issue bound).
+  if (p.wide) {
+    constexpr int STR = 16 * NT + 4;           // row stride: 4*STR == 16 (mod 32) banks
+    constexpr int LPR = 4 * NT;                // lanes per tile row
+    constexpr int RPI = 64 / LPR;              // rows per store instruction
+    __syncthreads();                           // every wave is done with the input spans
+    float* tile = smem + wave * (16 * MT * STR);
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          tile[(mb * 16 + 4 * qd + rr) * STR + nb * 16 + l15] = acc[mb][nb][rr];
+    // same wave reads back what it wrote: LDS operations of a wave complete in order
+    const int rl_ = lane / LPR, c4 = lane - rl_ * LPR;
+    const int qw = q0 + wave * (16 * NT) + 4 * c4;
+    float* ob = p.out + (long)n * p.osN + (long)z * p.osZ + qw;   // dense rows: offset = q
+#pragma unroll
+    for (int it = 0; it < (16 * MT) / RPI; ++it) {
+      const int row = it * RPI + rl_;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * STR + 4 * c4);
+      const int co = m0 + row;
+      if (co < p.Cout) {
+        float* dst = ob + (long)co * p.osC;
+        if (qw + 3 < p.Q) {
+          *reinterpret_cast<f32x4*>(dst) = v;            // 16 B, possibly unaligned
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (qw + e < p.Q) dst[e] = v[e];
+        }
+      }
+    }
+    if (st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      st[4] = __builtin_amdgcn_s_memtime();
+      st[5] = __builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
   // ---- epilogue: D col = position (lane&15), row = channel 4*qd+reg -------
   const int R = p.upz * p.upy * p.upx;
 #pragma unroll
@@ -337,6 +389,11 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
         else *dst = v;
       }
     }
+  }
+  if (st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[4] = __builtin_amdgcn_s_memtime();
+    st[5] = __builtin_amdgcn_s_memrealtime();
   }
 }
 

@@ -295,6 +295,7 @@ class Conv(NeuralLayer):
             return
         y = plan.scratch[self, 'y']
         wp = plan.scratch[self, 'wp_f']       # packed by the plan's multi-pack launch
+        plan.join_side()                      # ... which runs on the side stream
         cin = self.parent.shape['f']
         sig = (0, self.n_f, cin) + tuple(self.filter_shape) + tuple(y.shape[2:]) + \
             (x.stride(3),)
@@ -321,10 +322,12 @@ class Conv(NeuralLayer):
         dyp = plan.scratch[self, 'dy_pad']
         sigw = (self.n_f, cin) + tuple(self.filter_shape) + tuple(dy.shape[2:]) + \
             (x.stride(3), dy.stride(3))
-        plan.tuned('wgrad', sigw,
-                   autotune.wgrad_candidates(self.n_f, cin, self.filter_shape, dy.shape[2:]),
-                   lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=True),
-                   fn_tune=lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=False))
+        # the weight gradient is independent of the data-gradient chain below: side stream
+        plan.on_side(lambda: plan.tuned(
+            'wgrad', sigw,
+            autotune.wgrad_candidates(self.n_f, cin, self.filter_shape, dy.shape[2:]),
+            lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=True),
+            fn_tune=lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=False)))
         if plan.needs_grad(self.parent):
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

@@ -125,6 +125,29 @@ class Plan(object):
         autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing,
                             fn_tune=fn_tune)
 
+    # ---- second stream ----------------------------------------------------------------
+    def on_side(self, fn):
+        """run the launches of ``fn`` on the side stream, ordered after everything
+        issued on the main stream so far"""
+        if not self.use_side:
+            return fn()
+        ctx = self.ctx
+        main = ctx.stream
+        ctx.stream_fork(self.side)
+        ctx.set_stream(self.side)
+        try:
+            with torch.cuda.stream(self.side):
+                fn()
+        finally:
+            ctx.set_stream(main)
+        self._side_dirty = True
+
+    def join_side(self):
+        """main stream waits for the side stream (no-op when nothing ran there)"""
+        if self._side_dirty:
+            self.ctx.stream_join(self.side)
+            self._side_dirty = False
+
     # ---- gradient routing ----------------------------------------------------------
     def grad_slot(self, node):
         """(buffer, first): first == True -> the caller must OVERWRITE it."""
@@ -151,6 +174,14 @@ class Plan(object):
         self.ctx = get_ctx()
         self.batch = int(batch)
         self.stream = torch.cuda.Stream(device=self.ctx.device)
+        # second stream: weight gradients (and the weight repack) run next to the
+        # data-gradient chain; inside the captured graph they are parallel branches
+        self.side = torch.cuda.Stream(device=self.ctx.device)
+        self._side_dirty = False
+        import os
+        # measured (profiles/r01 notes in DESIGN.md): two MFMA-bound kernels sharing the
+        # chip finish no sooner than back to back -- off unless E2_SIDE_STREAM=1
+        self.use_side = os.environ.get("E2_SIDE_STREAM", "0") == "1"
         self.out, self.grad, self.scratch = {}, {}, {}
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
@@ -171,9 +202,10 @@ class Plan(object):
     # ---- kernel sequences ----------------------------------------------------------------
     def _emit_forward(self):
         if self._pack_dev is not None:       # all packed weight images, one launch
-            self.ctx.conv3d_pack_multi(*self._pack_dev)
+            self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev))
         for n in self.nodes:
             n._plan_fwd(self)
+        self.join_side()
 
     def _emit_backward(self):
         self.ctx.fill(self.model.G, 0.0)
@@ -181,6 +213,7 @@ class Plan(object):
         for n in reversed(self.nodes):
             if id(n) in self._loss_anc and (self.needs_grad(n) or n is self.loss_node):
                 n._plan_bwd(self)
+        self.join_side()
 
     def _emit_update(self):
         if self.step in ('Adam', 'SGD'):

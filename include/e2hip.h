@@ -218,6 +218,14 @@ int e2_event_record(e2_ctx*, e2_event*);
 int e2_event_elapsed_ms(e2_event* start, e2_event* stop, float* ms); /* syncs stop */
 int e2_event_destroy(e2_event*);
 int e2_stream_synchronize(e2_ctx*);
+/* Second stream for independent work (wgrad of a layer next to the dgrad chain):
+ * fork = `side` waits for everything issued on the context's stream so far;
+ * join = the context's stream waits for everything issued on `side`.  Both work
+ * while the context's stream is being captured (the side stream becomes a parallel
+ * branch of the graph; join it before e2_graph_end).  Launch on the side stream by
+ * pointing the context at it with e2_ctx_set_stream and back. */
+int e2_stream_fork(e2_ctx*, void* side_stream);
+int e2_stream_join(e2_ctx*, void* side_stream);
 
 #ifdef __cplusplus
 }
