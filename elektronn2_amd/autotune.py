@@ -74,7 +74,7 @@ def _best_mts(mblocks, options, keep=3):
     return [s[2] for s in scored[:keep]]
 
 
-def igemm_candidates(cout, cin, k, out_sp):
+def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     mblocks = -(-cout // 16)
     q = out_sp[1] * out_sp[2]
     cands = []
@@ -90,7 +90,7 @@ def igemm_candidates(cout, cin, k, out_sp):
             if nt == 4 and mt > 5:
                 continue
             base = out_sp[0] * (-(-q // (64 * nt))) * nmt
-            sks = (1,) if base >= 200 else (1, 2, 4)
+            sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 6)
             for cc in ccs:
                 for sk in sks:
                     cands.append("%d,%d,%d,%d" % (mt, nt, cc, sk))

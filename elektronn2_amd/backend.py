@@ -55,6 +55,8 @@ def _load():
         "e2_conv3d_pack": (C.c_int, [vp, fp, i, i, i, i, i, i, vp, sz]),
         "e2_conv3d_fwd_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_dgrad_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
+        "e2_conv3d_fwd_packed_act": (C.c_int, [vp, P5, vp, i, i, i, i, fp, i, P5]),
+        "e2_bias_act_bwd_out": (C.c_int, [vp, P5, P5, i, P5, fp]),
         "e2_conv3d_wgrad": (C.c_int, [vp, P5, P5, fp, i, i, i]),
         "e2_conv3d_wgrad_acc": (C.c_int, [vp, P5, P5, fp, i, i, i]),
         "e2_conv3d_wgrad_pad": (C.c_int, [vp, P5, P5, fp, i, i, i, i]),
@@ -207,6 +209,16 @@ class Context:
         _chk(_lib.e2_conv3d_dgrad_packed(self.h, C.byref(t5(dy_pad)),
                                          C.c_void_p(wp.data_ptr()), cin, k[0], k[1], k[2],
                                          C.byref(t5(dx))), "e2_conv3d_dgrad_packed")
+
+    def conv3d_fwd_packed_act(self, x, wp, cout, k, bias, act, out):
+        """conv + bias + activation in one launch (layers that do not pool)"""
+        _chk(_lib.e2_conv3d_fwd_packed_act(self.h, C.byref(t5(x)), C.c_void_p(wp.data_ptr()),
+                                           cout, k[0], k[1], k[2], _fp(bias), ACT[act],
+                                           C.byref(t5(out))), "e2_conv3d_fwd_packed_act")
+
+    def bias_act_bwd_out(self, dout, out, act, dy, dbias):
+        _chk(_lib.e2_bias_act_bwd_out(self.h, C.byref(t5(dout)), C.byref(t5(out)), ACT[act],
+                                      C.byref(t5(dy)), _fp(dbias)), "e2_bias_act_bwd_out")
 
     def conv3d_wgrad(self, x, dy, dw, accumulate=False):
         kd, kh, kw = dw.shape[2:]

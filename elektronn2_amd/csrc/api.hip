@@ -147,6 +147,34 @@ extern "C" int e2_conv3d_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void
   return e2i_igemm_conv(ctx, a);
 }
 
+extern "C" int e2_conv3d_fwd_packed_act(e2_ctx* ctx, const e2_tensor5* x, const void* wp,
+                                        int cout, int kd, int kh, int kw, const float* bias,
+                                        int act, const e2_tensor5* out) {
+  E2_REQUIRE(ctx && wp && bias, "conv3d_fwd_act: null argument");
+  E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "conv3d_fwd_act: bad act %d", act);
+  if (int rc = view_ok(x, "conv3d_fwd_act x")) return rc;
+  if (int rc = view_ok(out, "conv3d_fwd_act out")) return rc;
+  E2_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1, "conv3d_fwd_act: bad kernel %d,%d,%d", kd, kh, kw);
+  E2_REQUIRE(out->n == x->n && out->c == cout && out->d == x->d - kd + 1 &&
+                 out->h == x->h - kh + 1 && out->w == x->w - kw + 1,
+             "conv3d_fwd_act: out is (%d,%d,%d,%d,%d), expected (%d,%d,%d,%d,%d)", out->n,
+             out->c, out->d, out->h, out->w, x->n, cout, x->d - kd + 1, x->h - kh + 1,
+             x->w - kw + 1);
+  E2_REQUIRE(out->sh == out->w && (kw == 1 || kw == 3 || kw == 4 || kw == 5),
+             "conv3d_fwd_act: needs dense output rows and a kernel width of 1, 3, 4 or 5");
+  IgemmArgs a;
+  a.in = x->ptr; a.wp = (const float*)wp; a.out = out->ptr;
+  a.N = x->n; a.Cin = x->c; a.Cout = cout;
+  a.kd = kd; a.kh = kh; a.kw = kw;
+  a.Do = out->d; a.Ho = out->h; a.Wo = out->w;
+  a.isN = x->sn; a.isC = x->sc; a.isZ = x->sd; a.isY = x->sh;
+  a.osN = out->sn; a.osC = out->sc; a.osZ = out->sd; a.osY = out->sh;
+  e2i_pack_dims(cout, x->c, &a.ciP, &a.coP);
+  a.upz = a.upy = a.upx = 1;
+  a.bias = bias; a.act = act;
+  return e2i_igemm_conv(ctx, a);
+}
+
 extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, const void* wp,
                                       int cin, int kd, int kh, int kw,
                                       const e2_tensor5* dx) {

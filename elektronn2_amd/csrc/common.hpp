@@ -57,6 +57,11 @@ struct IgemmArgs {
   // upconv scatter mode: out channel oc' = co*R + r, stored at
   // out[n][co][pz*z+rz][py*y+ry][px*x+rx]; R = pz*py*px (1 = off)
   int upz, upy, upx;
+  // fused epilogue (conv forward of a layer that does not pool): out = act(conv + bias[oc]);
+  // relu writes -0.0 where the pre-activation was NEGATIVE and +0.0 where it was exactly
+  // zero, so that the backward can tell relu'(0) = 0.5 from 0 without the pre-activation
+  const float* bias = nullptr;
+  int act = 0;
 };
 int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
 

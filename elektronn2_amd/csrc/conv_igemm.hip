@@ -271,7 +271,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   p.nPT = e2_cdiv(p.Q, BN);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), c.MT);
   p.nChunkC = e2_cdiv(a.Cin, c.CC);
-  p.splitK = std::min(c.SK, a.kd * p.nChunkC);
+  p.splitK = a.bias ? 1 : std::min(c.SK, a.kd * p.nChunkC);     // the fused epilogue cannot split K
   p.atomic = (p.splitK > 1) ? 1 : 0;
   p.upz = a.upz; p.upy = a.upy; p.upx = a.upx;
   p.bufFloats = (int)buf_floats(a, c.MT, BN, c.CC);
@@ -285,6 +285,9 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   p.wide = (fast && p.splitK == 1 && a.upz * a.upy * a.upx == 1 && a.osY == a.Wo &&
             std::max(lds, tile_lds) <= 160 * 1024 && !getenv("E2_IGEMM_NARROW")) ? 1 : 0;
   if (p.wide) lds = std::max(lds, tile_lds);
+  p.bias = a.bias; p.act = a.act;
+  E2_REQUIRE(!a.bias || p.wide, "igemm: the fused bias/act epilogue needs dense output rows, a "
+             "specialised kernel width and %zu B of LDS", tile_lds);
   const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
   E2_REQUIRE(grid < (1L << 31), "igemm: grid too large");
   if (p.atomic) {

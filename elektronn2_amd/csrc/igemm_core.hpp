@@ -25,6 +25,8 @@ struct IgemmP {
   int upz, upy, upx;
   int bufFloats;          // floats per LDS buffer
   unsigned long long* stamps;   // debug (E2_IGEMM_STAMPS): 8 s_memtime stamps per work-group
+  const float* bias;      // fused bias (+ act) in the wide epilogue, or nullptr
+  int act;
   int wide;               // 1: epilogue transposes the tile through LDS and stores 16 B per lane
                           //    (dense output rows, no split-K, no UpConv scatter)
 };
@@ -338,9 +340,18 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
 #pragma unroll
     for (int it = 0; it < (16 * MT) / RPI; ++it) {
       const int row = it * RPI + rl_;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * STR + 4 * c4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * STR + 4 * c4);
       const int co = m0 + row;
       if (co < p.Cout) {
+        if (p.bias) {
+          const float bv = p.bias[co];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = v[e] + bv;
+            if (p.act == E2_ACT_RELU) t = (t > 0.f) ? t : ((t == 0.f) ? 0.f : -0.f);
+            v[e] = t;
+          }
+        }
         float* dst = ob + (long)co * p.osC;
         if (qw + 3 < p.Q) {
           *reinterpret_cast<f32x4*>(dst) = v;            // 16 B, possibly unaligned

@@ -181,6 +181,41 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(View5 dout, View5 y,
   }
 }
 
+// backward of the FUSED conv+bias+act forward (no pooling): dy = dout * act'(out),
+// relu' read off the activated output: > 0 -> 1, +0.0 -> 0.5 (pre-activation was
+// exactly 0), -0.0 -> 0 (it was negative; see e2_conv3d_fwd_packed_act); dbias += sum
+__global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out, int act,
+                                                          View5 dy, float* __restrict__ dbias,
+                                                          FastDiv dw, FastDiv dh,
+                                                          unsigned chunk) {
+  __shared__ float red[4];
+  const unsigned S = (unsigned)dout.d * dout.h * dout.w;
+  const unsigned s0 = blockIdx.x * chunk;
+  const unsigned s1 = min(s0 + chunk, S);
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* obase = out.p + (long)n * out.sn + (long)c * out.sc;
+  const float* gbase = dout.p + (long)n * dout.sn + (long)c * dout.sc;
+  float* dbase = dy.p + (long)n * dy.sn + (long)c * dy.sc;
+  float gsum = 0.f;
+  for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
+    const unsigned t = fdiv(s, dw);
+    const unsigned xo = s - t * dout.w;
+    const unsigned zo = fdiv(t, dh);
+    const unsigned yo = t - zo * dout.h;
+    float g = gbase[(long)zo * dout.sd + (long)yo * dout.sh + xo];
+    if (act == E2_ACT_RELU) {
+      const float o = obase[(long)zo * out.sd + (long)yo * out.sh + xo];
+      g *= (o > 0.f) ? 1.f : (__builtin_signbit(o) ? 0.f : 0.5f);
+    }
+    gsum += g;
+    dbase[(long)zo * dy.sd + (long)yo * dy.sh + xo] = g;
+  }
+  if (dbias != nullptr) {
+    const float tot = block_sum256(gsum, red);
+    if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(dbias + c, tot);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // UpConv helpers: dpre in space-to-depth layout
 //   s2d[n][co*R + r][z][y][x] = dout[n][co][pz*z+rz][py*y+ry][px*x+rx] * act'(yout)
@@ -525,6 +560,26 @@ extern "C" int e2_pool_bias_act_bwd(e2_ctx* ctx, const e2_tensor5* dout,
   E2_REQUIRE(ctx, "pool_bias_act_bwd: null ctx");
   E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "pool_bias_act_bwd: bad act %d", act);
   return pool_bwd_common(ctx, dout, y, bias, pz, py, px, act, dy, dbias, 0);
+}
+
+extern "C" int e2_bias_act_bwd_out(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* out,
+                                   int act, const e2_tensor5* dy, float* dbias) {
+  E2_REQUIRE(ctx, "bias_act_bwd_out: null ctx");
+  E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "bias_act_bwd_out: bad act %d", act);
+  if (int rc = check_view(dout, "bias_act_bwd_out dout")) return rc;
+  if (int rc = check_view(out, "bias_act_bwd_out out")) return rc;
+  if (int rc = check_view(dy, "bias_act_bwd_out dy")) return rc;
+  E2_REQUIRE(dout->n == out->n && dout->c == out->c && dout->d == out->d && dout->h == out->h &&
+                 dout->w == out->w && dy->n == out->n && dy->c == out->c && dy->d == out->d &&
+                 dy->h == out->h && dy->w == out->w, "bias_act_bwd_out: shape mismatch");
+  View5 vd = mk(dout), vo = mk(out), vdy = mk(dy);
+  E2_REQUIRE((long)vd.d * vd.h * vd.w < (1L << 31), "bias_act_bwd_out: channel too large");
+  const FastDiv dw = mk_div(vd.w), dh = mk_div(vd.h);
+  const unsigned chunk = pw_chunk(vd);
+  hipLaunchKernelGGL(act_bwd_out_kernel, grid_chunked(vd, chunk), dim3(256), 0, ctx->stream, vd,
+                     vo, act, vdy, dbias, dw, dh, chunk);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int e2_maxpool3d_fwd(e2_ctx* ctx, const e2_tensor5* x, int pz, int py, int px,

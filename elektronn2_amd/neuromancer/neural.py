@@ -255,6 +255,18 @@ class Conv(NeuralLayer):
                 plan.ctx.conv1_supported(1, self.filter_shape, self.pool_shape) and
                 not plan.needs_grad(self.parent))
 
+    def _fused_act(self, plan):
+        """no pooling and a specialised kernel width: bias + activation go into the
+        conv kernel's epilogue, the pre-activation is never stored"""
+        if not (all(p == 1 for p in self.pool_shape) and self.filter_shape[2] in (1, 3, 4, 5)
+                and type(self) is Conv and not self._fused_first(plan)):
+            return False
+        # the fused epilogue cannot split K: only where the output alone yields enough
+        # work-groups to fill the chip (small late layers keep split-K + pointwise pass)
+        osp = self.shape.spatial_shape
+        tiles = plan.batch * osp[0] * (-(-(osp[1] * osp[2]) // 128)) * (-(-self.n_f // 112))
+        return tiles >= 160
+
     def _plan_alloc(self, plan):
         N = plan.batch
         psp = self.parent.shape.spatial_shape
@@ -266,7 +278,8 @@ class Conv(NeuralLayer):
                 plan.scratch[self, 'ws1'] = plan.empty_flat(nb // 4 + 16)
             return
         osp = [psp[i] - k[i] + 1 for i in range(3)]
-        plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
+        if not self._fused_act(plan):
+            plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
         plan.alloc_out(self)
         cin = self.parent.shape['f']
         nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
@@ -293,10 +306,21 @@ class Conv(NeuralLayer):
             ctx.conv1_pool_act_fwd(x, plan.param(self.w), plan.param(self.b), self.pool_shape,
                                    self.activation_func, plan.out[self])
             return
-        y = plan.scratch[self, 'y']
         wp = plan.scratch[self, 'wp_f']       # packed by the plan's multi-pack launch
         plan.join_side()                      # ... which runs on the side stream
         cin = self.parent.shape['f']
+        if self._fused_act(plan):
+            out = plan.out[self]
+            sig = (2, self.n_f, cin) + tuple(self.filter_shape) + tuple(out.shape[2:]) + \
+                (x.stride(3),)
+            plan.tuned('igemm', sig,
+                       autotune.igemm_candidates(self.n_f, cin, self.filter_shape,
+                                                 out.shape[2:], split_k=False),
+                       lambda: ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self.filter_shape,
+                                                         plan.param(self.b),
+                                                         self.activation_func, out))
+            return
+        y = plan.scratch[self, 'y']
         sig = (0, self.n_f, cin) + tuple(self.filter_shape) + tuple(y.shape[2:]) + \
             (x.stride(3),)
         plan.tuned('igemm', sig,
@@ -313,10 +337,13 @@ class Conv(NeuralLayer):
                                    self.pool_shape, self.activation_func, plan.pgrad(self.w),
                                    plan.pgrad(self.b), ws=plan.scratch[self, 'ws1'])
             return
-        y = plan.scratch[self, 'y']
         dy = plan.scratch[self, 'dy']
-        ctx.pool_bias_act_bwd(plan.grad[self], y, plan.param(self.b), self.pool_shape,
-                              self.activation_func, dy, plan.pgrad(self.b))
+        if self._fused_act(plan):
+            ctx.bias_act_bwd_out(plan.grad[self], plan.out[self], self.activation_func, dy,
+                                 plan.pgrad(self.b))
+        else:
+            ctx.pool_bias_act_bwd(plan.grad[self], plan.scratch[self, 'y'], plan.param(self.b),
+                                  self.pool_shape, self.activation_func, dy, plan.pgrad(self.b))
         cin = self.parent.shape['f']
         dw = plan.pgrad(self.w)
         dyp = plan.scratch[self, 'dy_pad']

@@ -82,6 +82,19 @@ int e2_conv3d_fwd_packed(e2_ctx*, const e2_tensor5* x, const void* wp, int cout,
                          int kd, int kh, int kw, const e2_tensor5* y);
 int e2_conv3d_dgrad_packed(e2_ctx*, const e2_tensor5* dy_pad, const void* wp,
                            int cin, int kd, int kh, int kw, const e2_tensor5* dx);
+/* Conv layer WITHOUT pooling, fused: out = act(conv(x, w) + bias[oc]) in the GEMM's
+ * epilogue (neural.py:662-712 with pool_shape all ones).  Needs dense output rows
+ * and a kernel width of 1, 3, 4 or 5 (e2_conv3d_fwd_packed + e2_pool_bias_act_fwd
+ * otherwise).  relu stores -0.0 where the pre-activation was negative and +0.0
+ * where it was exactly 0 (equal values; the sign is what e2_bias_act_bwd_out reads
+ * to reproduce Theano's relu'(0) = 0.5). */
+int e2_conv3d_fwd_packed_act(e2_ctx*, const e2_tensor5* x, const void* wp, int cout,
+                             int kd, int kh, int kw, const float* bias, int act,
+                             const e2_tensor5* out);
+/* its backward: dy = dout * act'(out) (dy may be the interior of the padded gradient
+ * buffer), dbias[oc] += sum(dy) when dbias != NULL. */
+int e2_bias_act_bwd_out(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* out, int act,
+                        const e2_tensor5* dy, float* dbias);
 
 /* dw[cout][cin][kd][kh][kw] = d(loss)/dw (replaces GpuDnnConv3dGradW).
  * dy is the UNPADDED view (n, cout, do, ho, wo) (it may be the interior view

@@ -94,6 +94,37 @@ def test_conv3d_fwd_forced_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
+@pytest.mark.parametrize("act", ["relu", "lin"])
+@pytest.mark.parametrize("k", [(1, 3, 3), (1, 1, 1), (2, 4, 4)])
+def test_conv3d_fused_bias_act(ctx, act, k):
+    """conv + bias + act in the GEMM epilogue (layers without pooling) and its
+    backward from the activated output, incl. pre-activations that are EXACTLY zero
+    (relu'(0) = 0.5) and negative (relu' = 0): channels 0 / 1 have zero weights."""
+    rng = np.random.RandomState(21)
+    x = rng.rand(2, 10, 4, 12, 22).astype(np.float32)
+    w = (rng.randn(37, 10, *k) / 6).astype(np.float32)
+    b = (rng.randn(37) / 4).astype(np.float32)
+    w[0] = 0; b[0] = 0          # pre == 0 exactly
+    w[1] = 0; b[1] = -1         # pre < 0 exactly
+    out_ref, _ = O.conv_node_fwd(x, w, b, (1, 1, 1), act)
+    wd = dev(w)
+    ws = torch.empty(ctx.conv_ws_bytes(37, 10, k) // 4 + 64, device="cuda")
+    ctx.conv3d_pack(wd, 0, ws)
+    out = torch.full(out_ref.shape, float("nan"), device="cuda")
+    ctx.conv3d_fwd_packed_act(dev(x), ws, 37, k, dev(b), act, out)
+    assert relerr(out, out_ref) < TOL
+    dout = rng.randn(*out_ref.shape).astype(np.float32)
+    dy_ref, db_ref = O.bias_act_bwd(dout, O.conv3d_fwd(x, w), b, act)
+    dy = torch.full(out_ref.shape, float("nan"), device="cuda")
+    db = torch.zeros(37, device="cuda")
+    ctx.bias_act_bwd_out(dev(dout), out, act, dy, db)
+    assert relerr(dy, dy_ref) < TOL
+    assert relerr(db, db_ref) < 1e-4
+    if act == "relu":
+        g = dy.cpu().numpy()
+        assert np.array_equal(g[:, 0], 0.5 * dout[:, 0]) and not g[:, 1].any()
+
+
 @pytest.mark.parametrize("force", ["7,2,32,1", "13,1,16,2", "2,4,48,1", "5,2,64,1", "1,1,8,1"])
 def test_conv3d_1x1_forced_tilings(ctx, force):
     """1x1x1 taps (plain GEMM): GU = 4 channel groups per step when CC % 16 == 0,
