@@ -67,7 +67,9 @@ def _load():
         "e2_stream_join": (C.c_int, [vp, C.c_void_p]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5]),
-        "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp]),
+        "e2_conv1_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i, i]),
+        "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp,
+                                            C.c_void_p, C.c_size_t]),
         "e2_pool_bias_act_fwd": (C.c_int, [vp, P5, fp, i, i, i, i, P5]),
         "e2_pool_bias_act_bwd": (C.c_int, [vp, P5, P5, fp, i, i, i, i, P5, fp]),
         "e2_maxpool3d_fwd": (C.c_int, [vp, P5, i, i, i, P5]),
