@@ -33,6 +33,8 @@ WORKLOADS = {
     # name: (builder, input spatial, algorithmic fwd+bwd GFLOP/step  [SURVEY.md §8d])
     "lite183": ("neuro3d_lite", (23, 183, 183), 118.29),
     "full185": ("neuro3d", (23, 185, 185), 119.02),
+    # BASELINE configs[2]; algorithmic GF with UpConv counted at its closed form
+    "unet_lite140": ("unet3d_lite", (22, 140, 140), 397.8),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
 # HBM-side bytes per step from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
@@ -92,13 +94,20 @@ def main():
     assert world == args.gpus or world == 1, "launch with torchrun for --gpus > 1"
 
     builder, sp, gf_table = WORKLOADS[args.workload]
-    spec = O.NEURO3D_LITE if builder == "neuro3d_lite" else O.NEURO3D
-    gflop = algorithmic_gflop(spec, sp)
-    osp = O.net_out_shape(spec, sp)
-
-    # identical initial weights on every rank (seed 1), independent data per rank
-    params = O.init_net(spec, 1, seed=1)
-    model = getattr(nets, builder)((None, 1) + sp, params=params)
+    if builder == "unet3d_lite":
+        spec = params = None
+        gflop = gf_table
+        np.random.seed(1)                     # identical initial weights on every rank
+        model = nets.unet3d_lite((None, 1) + sp)
+        osp = tuple(model.prediction_node.shape.spatial_shape)
+        args.no_cpu_baseline = True           # the CPU leg is the sequential-net port
+    else:
+        spec = O.NEURO3D_LITE if builder == "neuro3d_lite" else O.NEURO3D
+        gflop = algorithmic_gflop(spec, sp)
+        osp = O.net_out_shape(spec, sp)
+        # identical initial weights on every rank (seed 1), independent data per rank
+        params = O.init_net(spec, 1, seed=1)
+        model = getattr(nets, builder)((None, 1) + sp, params=params)
     model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
     opt = model.optimisers['Adam']
     opt.step.compile()

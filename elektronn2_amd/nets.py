@@ -43,6 +43,41 @@ def neuro3d(in_sh=(None, 1, 23, 185, 185), params=None, name=None):
     return _finish(nm, inp, out, name)
 
 
+def unet3d_lite(in_sh=(None, 1, 22, 140, 140), name=None):
+    """examples/unet3d_lite.py:59-118: three (1,2,2) poolings, two convs per level,
+    three UpConvMerge (crop + concat) stages, 2-class head."""
+    from . import neuromancer as nm
+    if name is not None:
+        nm.model_manager.newmodel(name)
+    inp = nm.Input(in_sh, 'b,f,z,x,y', name='raw')
+    skips = []
+    out = inp
+    for n_f in (32, 64, 128):                      # contracting path
+        out = nm.Conv(out, n_f, (1, 3, 3))
+        out = nm.Conv(out, n_f, (1, 3, 3))
+        skips.append(out)
+        out = nm.Pool(out, (1, 2, 2), mode='max')
+    out = nm.Conv(out, 256, (3, 3, 3))
+    out = nm.Conv(out, 256, (3, 3, 3))
+    for skip, up_f, n_f, k in ((skips[2], 512, 256, (1, 3, 3)),   # expanding path
+                               (skips[1], 256, 128, (3, 3, 3)),
+                               (skips[0], 128, 64, (3, 3, 3))):
+        out = nm.UpConvMerge(skip, out, up_f)
+        out = nm.Conv(out, n_f, k)
+        out = nm.Conv(out, n_f, k)
+    feat = out
+    barr = nm.Conv(feat, 2, (1, 1, 1), activation_func='lin', name='barr')
+    probs = nm.Softmax(barr)
+    target = nm.Input_like(feat, override_f=1, name='target')
+    loss_pix = nm.MultinoulliNLL(probs, target, target_is_sparse=True, name='nll_barr')
+    loss = nm.AggregateLoss(loss_pix, name='loss')
+    errors = nm.Errors(probs, target, target_is_sparse=True)
+    model = nm.model_manager.current if name is not None else nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, target_node=target, loss_node=loss,
+                          prediction_node=probs, prediction_ext=[loss, errors, probs])
+    return model
+
+
 def _pget(params):
     def P(i):
         if params is None:
