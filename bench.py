@@ -90,7 +90,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        parallel.init_from_env("nccl")
+        # RCCL ("nccl") on the GPU node; E2_DIST_BACKEND=gloo only to rehearse the
+        # multi-rank flow where the ranks have to share one GPU
+        parallel.init_from_env(os.environ.get("E2_DIST_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, "launch with torchrun for --gpus > 1"
 
     builder, sp, gf_table = WORKLOADS[args.workload]
@@ -113,7 +115,8 @@ def main():
     opt.step.compile()
     plan = opt.step.func
     plan.use_graph = not args.no_graph
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", min(int(os.environ.get("LOCAL_RANK", "0")),
+                                   max(torch.cuda.device_count() - 1, 0)))
     rng = np.random.RandomState(parallel.rank_seed(0, rank))
     n_batches = 4
     xs = [torch.tensor(rng.rand(1, 1, *sp).astype(np.float32), device=dev)

@@ -21,8 +21,9 @@ def init_from_env(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(min(int(os.environ.get("LOCAL_RANK", "0")),
+                                  torch.cuda.device_count() - 1))
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
     return world
 

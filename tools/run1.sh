@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/test_model_gpu.py -x -q 2>&1 | tail -3
-timeout -k 10 300 python bench.py --workload unet_lite140 2>&1 | tail -1 | cut -c1-900
+export E2_DIST_BACKEND=gloo
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 3 2>&1 | tail -4 | cut -c1-700
