@@ -63,6 +63,11 @@ def _load():
         "e2_pack_job_bytes": (sz, []),
         "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
         "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
+        "e2_head_supported": (C.c_int, [i, i]),
+        "e2_head_fwd": (C.c_int, [vp, P5, fp, fp, i, P5, P5, fp]),
+        "e2_head_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
+        "e2_head_bwd": (C.c_int, [vp, P5, fp, P5, P5, fp, P5, i, fp, fp, fp, C.c_void_p,
+                                  C.c_size_t]),
         "e2_stream_fork": (C.c_int, [vp, C.c_void_p]),
         "e2_stream_join": (C.c_int, [vp, C.c_void_p]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
@@ -221,6 +226,34 @@ class Context:
     def bias_act_bwd_out(self, dout, out, act, dy, dbias):
         _chk(_lib.e2_bias_act_bwd_out(self.h, C.byref(t5(dout)), C.byref(t5(out)), ACT[act],
                                       C.byref(t5(dy)), _fp(dbias)), "e2_bias_act_bwd_out")
+
+    # ---- fused classifier head -------------------------------------------------
+    @staticmethod
+    def head_supported(cin, ncls):
+        return bool(_lib.e2_head_supported(int(cin), int(ncls)))
+
+    def head_fwd(self, x, w, bias, target, probs, stats):
+        _chk(_lib.e2_head_fwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias), probs.shape[1],
+                              C.byref(t5(target)) if target is not None else None,
+                              C.byref(t5(probs)), _fp(stats) if stats is not None else None),
+             "e2_head_fwd")
+
+    @staticmethod
+    def head_bwd_ws_bytes(x_shape, ncls):
+        n, cin, d, h, w = (int(v) for v in x_shape)
+        return int(_lib.e2_head_bwd_workspace_bytes(n, cin, int(ncls), d, h, w))
+
+    def head_bwd(self, x, w, probs, target, stats, dx, accumulate_dx, dw, dbias, loss_out,
+                 ws=None):
+        if ws is None:
+            ws = torch.empty(self.head_bwd_ws_bytes(x.shape, probs.shape[1]) // 4 + 16,
+                             dtype=torch.float32, device=self.device)
+        _chk(_lib.e2_head_bwd(self.h, C.byref(t5(x)), _fp(w), C.byref(t5(probs)),
+                              C.byref(t5(target)), _fp(stats),
+                              C.byref(t5(dx)) if dx is not None else None,
+                              1 if accumulate_dx else 0, _fp(dw), _fp(dbias),
+                              _fp(loss_out) if loss_out is not None else None,
+                              C.c_void_p(ws.data_ptr()), ws.numel() * 4), "e2_head_bwd")
 
     def conv3d_wgrad(self, x, dy, dw, accumulate=False):
         kd, kh, kw = dw.shape[2:]

@@ -56,6 +56,11 @@ class Softmax(Node):
         # kernel with the target and also fills the loss statistics.
         if plan.scratch.get((self, 'fused_nll')):
             return
+        head = self._head(plan)
+        if head is not None:                 # conv + softmax in one kernel
+            plan.ctx.head_fwd(plan.out[head.parent], plan.param(head.w), plan.param(head.b),
+                              None, plan.out[self], None)
+            return
         t = plan.scratch.get((self, 'dummy_t'))
         if t is None:
             sh = list(plan.out_shape(self))
@@ -64,6 +69,12 @@ class Softmax(Node):
             plan.scratch[self, 'dummy_t'] = t
         plan.ctx.softmax_nll_fwd(plan.out[self.parent], t, plan.out[self],
                                  plan.scratch[self, 'stats'])
+
+    def _head(self, plan):
+        """the parent Conv when it runs as a fused classifier head (csrc/head.hip)"""
+        p = self.parent
+        f = getattr(p, '_fused_head', None)
+        return p if (f is not None and f(plan) is self) else None
 
     def _plan_bwd(self, plan):
         if plan.scratch.get((self, 'fused_nll')):
@@ -104,15 +115,33 @@ class MultinoulliNLL(Node):
     def _plan_alloc(self, plan):
         plan.scratch[self.pred, 'fused_nll'] = True
         plan.scratch[self, 'loss'] = plan.zeros_flat(1)
+        head = self.pred._head(plan)
+        if head is not None and plan.training:
+            nb = plan.ctx.head_bwd_ws_bytes(plan.out_shape(head.parent), self.n_class)
+            plan.scratch[self, 'head_ws'] = plan.empty_flat(nb // 4 + 16)
         plan.out[self] = None        # the element-wise nll array is never materialised
 
     def _plan_fwd(self, plan):
         stats = plan.scratch[self.pred, 'stats']
         plan.ctx.fill(stats, 0.0)
+        head = self.pred._head(plan)
+        if head is not None:
+            plan.ctx.head_fwd(plan.out[head.parent], plan.param(head.w), plan.param(head.b),
+                              plan.out[self.target], plan.out[self.pred], stats)
+            return
         plan.ctx.softmax_nll_fwd(plan.out[self.pred.parent], plan.out[self.target],
                                  plan.out[self.pred], stats)
 
     def _plan_bwd(self, plan):
+        head = self.pred._head(plan)
+        if head is not None:
+            dst, first = (plan.grad_slot(head.parent) if plan.needs_grad(head.parent)
+                          else (None, True))
+            plan.ctx.head_bwd(plan.out[head.parent], plan.param(head.w), plan.out[self.pred],
+                              plan.out[self.target], plan.scratch[self.pred, 'stats'], dst,
+                              not first, plan.pgrad(head.w), plan.pgrad(head.b),
+                              plan.scratch[self, 'loss'], ws=plan.scratch[self, 'head_ws'])
+            return
         logits = self.pred.parent
         dst, first = plan.grad_slot(logits)
         if not first:

@@ -255,6 +255,25 @@ class Conv(NeuralLayer):
                 plan.ctx.conv1_supported(1, self.filter_shape, self.pool_shape) and
                 not plan.needs_grad(self.parent))
 
+    def _fused_head(self, plan):
+        """classifier head: this (1,1,1) 'lin' conv to <= 4 features feeds nothing but a
+        Softmax of the same plan -> conv + softmax (+ NLL and all gradients) run in the
+        fused head kernels (csrc/head.hip); returns that Softmax node or None."""
+        key = (self, 'head')
+        if key not in plan.scratch:
+            sm = None
+            kids = list(self.children.values())
+            if (type(self) is Conv and tuple(self.filter_shape) == (1, 1, 1)
+                    and all(p == 1 for p in self.pool_shape) and self.activation_func == 'lin'
+                    and len(kids) == 1 and type(kids[0]).__name__ == 'Softmax'
+                    and any(n is kids[0] for n in plan.nodes)
+                    and not any(n is self for n in plan.outputs)
+                    and plan.ctx.head_supported(self.parent.shape['f'], self.n_f)
+                    and not self._fused_first(plan)):
+                sm = kids[0]
+            plan.scratch[key] = sm
+        return plan.scratch[key]
+
     def _fused_act(self, plan):
         """no pooling and a specialised kernel width: bias + activation go into the
         conv kernel's epilogue, the pre-activation is never stored"""
@@ -271,6 +290,9 @@ class Conv(NeuralLayer):
         N = plan.batch
         psp = self.parent.shape.spatial_shape
         k = self.filter_shape
+        if self._fused_head(plan) is not None:
+            plan.out[self] = None             # the logits are never materialised
+            return
         if self._fused_first(plan):
             plan.alloc_out(self)
             if plan.training:
@@ -301,6 +323,8 @@ class Conv(NeuralLayer):
 
     def _plan_fwd(self, plan):
         ctx = plan.ctx
+        if self._fused_head(plan) is not None:
+            return                            # done by the Softmax / NLL node
         x = plan.out[self.parent]
         if self._fused_first(plan):
             ctx.conv1_pool_act_fwd(x, plan.param(self.w), plan.param(self.b), self.pool_shape,
@@ -331,6 +355,8 @@ class Conv(NeuralLayer):
 
     def _plan_bwd(self, plan):
         ctx = plan.ctx
+        if self._fused_head(plan) is not None:
+            return
         x = plan.out[self.parent]
         if self._fused_first(plan):
             ctx.conv1_pool_act_bwd(x, plan.param(self.w), plan.param(self.b), plan.grad[self],

@@ -194,6 +194,22 @@ int e2_fill(e2_ctx*, float* ptr, size_t n, float value);
 
 /* ---- loss (computations.py:175-176 softmax; loss.py:261-347
  *      MultinoulliNLL(target_is_sparse); loss.py:1357-1363 AggregateLoss) - */
+/* ---- classifier head, fused: 1x1x1 conv to ncls <= 4 'lin' features + channel softmax
+ *      + MultinoulliNLL (sparse target) and their gradients (neural.py:662-712 with a
+ *      (1,1,1) kernel, computations.py:175-176, loss.py:261-347).  w is the dense
+ *      (ncls, cin, 1,1,1) weight tensor.  stats = {sum of -log(p_t + 1e-5), #labelled},
+ *      zero it before e2_head_fwd; loss = stats[0] / (stats[1] + 1e-5).  target NULL:
+ *      probabilities only.  e2_head_bwd ACCUMULATES into dw / dbias; its workspace holds
+ *      per-work-group partial sums (e2_head_bwd_workspace_bytes). --------------------- */
+int e2_head_supported(int cin, int ncls);
+int e2_head_fwd(e2_ctx*, const e2_tensor5* x, const float* w, const float* bias, int ncls,
+                const e2_tensor5* target, const e2_tensor5* probs, float* stats);
+size_t e2_head_bwd_workspace_bytes(int n, int cin, int ncls, int d, int h, int w);
+int e2_head_bwd(e2_ctx*, const e2_tensor5* x, const float* w, const e2_tensor5* probs,
+                const e2_tensor5* target, const float* stats, const e2_tensor5* dx,
+                int accumulate_dx, float* dw, float* dbias, float* loss_out, void* ws,
+                size_t ws_bytes);
+
 /* probs = softmax_c(logits); loss_sum += sum_pos -log(p[target]+1e-5);
  * n_lab += #labelled (target in [0,C)).  stats = {loss_sum, n_lab} must be
  * zeroed by the caller.  target: (n,1,d,h,w) float class ids. */

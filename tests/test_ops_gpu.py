@@ -404,3 +404,42 @@ def test_fused_first_layer(ctx, k, sp):
     ctx.conv1_pool_act_bwd(dev(x), dev(w), dev(b), dev(dout), pool, 'relu', dw, db)
     assert relerr(dw, dw_ref) < TOL
     assert relerr(db, db_ref) < TOL
+
+
+@pytest.mark.parametrize("ncls,cin", [(2, 200), (3, 37), (4, 300)])
+def test_fused_classifier_head(ctx, ncls, cin):
+    """1x1x1 'lin' conv -> softmax -> MultinoulliNLL fused (csrc/head.hip): probs, loss
+    and all gradients vs the oracle; unlabelled voxels (target -1), strided input view,
+    a position count that is not a multiple of the 64-position tile, dx accumulation."""
+    rng = np.random.RandomState(31)
+    sp = (3, 7, 13)
+    xfull = rng.rand(2, cin + 3, *sp).astype(np.float32)
+    x = xfull[:, 2:2 + cin]                            # channel-sliced view
+    w = (rng.randn(ncls, cin, 1, 1, 1) / np.sqrt(cin)).astype(np.float32)
+    b = (rng.randn(ncls) / 4).astype(np.float32)
+    t = rng.randint(-1, ncls, (2, 1) + sp).astype(np.float32)
+    logits = O.conv3d_fwd(x, w) + b.reshape(1, -1, 1, 1, 1)
+    loss_ref, dlog, p_ref = O.nll_loss_and_grad(logits, t)
+    dw_ref = O.conv3d_wgrad(dlog, x, w.shape)
+    db_ref = dlog.sum(axis=(0, 2, 3, 4))
+    dx_ref = O.conv3d_dgrad(dlog, w, x.shape)
+    xd = dev(xfull)[:, 2:2 + cin]
+    probs = torch.full((2, ncls) + sp, float("nan"), device="cuda")
+    stats = torch.zeros(2, device="cuda")
+    ctx.head_fwd(xd, dev(w), dev(b), dev(t), probs, stats)
+    assert relerr(probs, p_ref) < TOL
+    probs2 = torch.full((2, ncls) + sp, float("nan"), device="cuda")
+    ctx.head_fwd(xd, dev(w), dev(b), None, probs2, None)      # prediction only
+    assert torch.equal(probs, probs2)
+    dx = torch.full(x.shape, 1e-3, device="cuda")
+    dw = torch.zeros(w.shape, device="cuda")
+    db = torch.zeros(ncls, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    ctx.head_bwd(xd, dev(w), probs, dev(t), stats, dx, True, dw, db, loss)
+    assert abs(float(loss) - loss_ref) / loss_ref < 1e-5
+    assert relerr(dx - 1e-3, dx_ref) < 1e-3              # accumulated onto a constant
+    assert relerr(dw, dw_ref) < TOL
+    assert relerr(db, db_ref) < 1e-4
+    dx2 = torch.full(x.shape, float("nan"), device="cuda")
+    ctx.head_bwd(xd, dev(w), probs, dev(t), stats, dx2, False, dw, db, None)
+    assert relerr(dx2, dx_ref) < TOL
