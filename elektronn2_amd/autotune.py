@@ -99,6 +99,7 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
 
 def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
     """"MT,NT,WK,BP,PS": WK 1 = direct kernel (dy from global memory; BP 128/256),
+    WK 14 = direct kernel whose four waves share one 16*NT n-tile and split the quads,
     WK 0 = LDS-staged kernel (BP 64/128), WK 4 = LDS-staged, waves split K (tiny N)."""
     mblocks = -(-cout // 16)
     T = k[0] * k[1] * k[2]
@@ -108,16 +109,16 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
     cands = []
     for mt in _best_mts(mblocks, WGRAD_MTS, keep=3):
         nmt = -(-mblocks // mt)
-        variants = [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0), (4, 0)]
+        variants = [(1, 1), (2, 1), (4, 1), (2, 14), (4, 14), (1, 0), (2, 0), (4, 0)]
         if nblocks <= 2:
-            variants = [(1, 4), (1, 0), (1, 1)]
+            variants = [(1, 4), (1, 0), (1, 1), (2, 14)]
         for nt, wk in variants:
-            wn = 1 if wk == 4 else 4
+            wn = 1 if wk in (4, 14) else 4
             if nt > 1 and 16 * nt * wn > 16 * nblocks:
                 continue
             nnt = -(-nblocks // (nt * wn))
-            for bp in ((128, 256) if wk == 1 else (64, 128)):
-                tiles = out_sp[0] * (-(-(qpad if wk == 1 else q) // bp))
+            for bp in ((128, 256) if wk in (1, 14) else (64, 128)):
+                tiles = out_sp[0] * (-(-(qpad if wk in (1, 14) else q) // bp))
                 for fill in (1, 2, 4):
                     ps = max(1, min(tiles, (n_cu * fill) // max(1, nmt * nnt)))
                     cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, ps))

@@ -346,7 +346,8 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
   float* wp = (float*)ws;
   size_t off = (up_pack_floats(cout, cin, R) + 63) & ~(size_t)63;
   float* s2d = wp + off;
-  if (dbias) E2_CHECK_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * cout, ctx->stream));
+  if (dbias)
+    if (int rc = e2i_fill_flat(ctx, dbias, (size_t)cout, 0.f)) return rc;
   if (int rc = e2i_upconv_dpre_s2d(ctx, dout, y, pz, py, px, act, s2d, dbias)) return rc;
   const long S = (long)x->d * x->h * x->w;
   if (dx) {

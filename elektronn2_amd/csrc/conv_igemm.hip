@@ -297,8 +297,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
     const int od = a.Do * a.upz, oh = a.Ho * a.upy, ow = a.Wo * a.upx;
     if (a.osY == ow && a.osZ == (long)oh * ow && a.osC == (long)od * oh * ow &&
         (a.N == 1 || a.osN == (long)oc * od * oh * ow)) {
-      E2_CHECK_HIP(hipMemsetAsync(a.out, 0, sizeof(float) * (size_t)a.N * oc * od * oh * ow,
-                                  ctx->stream));
+      if (int rc = e2i_fill_flat(ctx, a.out, (size_t)a.N * oc * od * oh * ow, 0.f)) return rc;
     } else {
       e2_tensor5 v{a.out, a.N, oc, od, oh, ow, a.osN, a.osC, a.osZ, a.osY};
       int rc = e2i_fill_view(ctx, &v, 0.f);

@@ -437,7 +437,7 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
         const int nNT = e2_cdiv(nblocks, NT * 4);
         for (int BP = 128; BP <= 256; BP *= 2) {
           if (BP == 256 && S <= 128) continue;
-          const size_t lds = 2 * e2i_wgrad_direct_buf_floats(a, NT, BP) * 4;
+          const size_t lds = 2 * e2i_wgrad_direct_buf_floats(a, NT, BP, 1) * 4;
           if (lds > 160 * 1024) continue;
           const int slots = ctx->num_cu;
           const int nPT = (int)((S + BP - 1) / BP);
@@ -515,9 +515,11 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   E2_REQUIRE(ok, "wgrad: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d)", a.Cin, a.Cout,
              a.kd, a.kh, a.kw);
   // WK field: 1 = direct kernel when dy is padded (BP 128/256), else the LDS-staged
-  // kernel; 0 = LDS-staged kernel forced; 4 = LDS-staged kernel, waves split K
-  if (a.dy_padded && c.WK == 1 && (c.BP == 128 || c.BP == 256))
-    return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS);
+  // kernel; 14 = direct kernel, waves split the quads of a tile (NT 2/4);
+  // 0 = LDS-staged kernel forced; 4 = LDS-staged kernel, waves split K
+  if (a.dy_padded && (c.WK == 1 || c.WK == 14) && (c.BP == 128 || c.BP == 256))
+    return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS, c.WK == 14 ? 4 : 1);
+  E2_REQUIRE(c.WK != 14, "wgrad: WK=14 needs the padded-gradient entry point and BP 128/256");
   if (c.WK == 0) c.WK = 1;
   E2_REQUIRE(c.BP == 64 || c.BP == 128, "wgrad: BP must be 64 or 128");
   E2_REQUIRE(c.WK == 1 || (c.WK == 4 && c.NT == 1), "wgrad: WK=4 needs NT=1");
@@ -554,7 +556,7 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   const long grid = (long)p.nMT * p.nNT * p.nPS;
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
   if (!a.accumulate)
-    E2_CHECK_HIP(hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.Cout * p.NTOT, ctx->stream));
+    if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.NTOT, 0.f)) return rc;
   if (getenv("E2_VERBOSE"))
     fprintf(stderr, "[e2] wgrad Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d WK=%d BP=%d PS=%d grid=%ld lds=%zu\n",
             a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.WK, c.BP, p.nPS, grid, lds);

@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <algorithm>
+#include <vector>
 #include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -90,6 +91,7 @@ struct WdP {
   int Din, N;
   int dbg;
   FastDivD divDsY;
+  unsigned long long* stamps;   // debug (E2_WGRAD_STAMPS): s_memtime stamps per work-group
 };
 
 // one quad = 16 span positions = 4 k-steps; lane quarter qd owns 16q + 4qd + j
@@ -179,17 +181,23 @@ __device__ __forceinline__ void dquad_steps(const DQuad<MT, NT>& cur, DQuad<MT, 
   if constexpr (I + 1 < M) dquad_steps<MT, NT, PF, I + 1>(cur, nxt, acc, ad, nio);
 }
 
-template <int MT, int NT, int BP>
+// WK = 4: the four compute waves share ONE 16*NT-wide n-tile and split the quads of
+// every position tile among them (wave w takes quads w, w+4, ...): for small or
+// awkward Cin*T (L1: 540) this keeps NT large -- enough MFMAs per pipeline step to
+// hide the operand loads -- without padding N up to 64*NT; the staged spans serve all
+// four waves.  Each wave flushes its own partial sums (4x the atomics of a small dw).
+template <int MT, int NT, int BP, int WK>
 __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = 16 * MT;
-  constexpr int BNn = 16 * NT * 4;
-  constexpr int TBF = BP + 16;           // + the quad of offsets fetched past the end
+  constexpr int BNn = 16 * NT * (4 / WK);
+  constexpr int TBF = BP + 64;           // + the offsets fetched past the end of a tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave8 >= 4;
-  const int wn = wave8 & 3;
+  const int wn = (WK == 4) ? 0 : (wave8 & 3);   // n-block column of the wave
+  const int wk = (WK == 4) ? (wave8 & 3) : 0;   // its share of the quads
   const int l15 = lane & 15, qd = lane >> 4;
 
   int bid = blockIdx.x;
@@ -256,9 +264,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
       }
     };
     // the quad pipeline reads one quad of offsets past the table: keep them in range
-    if (pw == 0 && lane < 32) {
-      int* t = reinterpret_cast<int*>(smem + (lane >> 4) * p.bufFloats);
-      t[BP + (lane & 15)] = 0;
+    if (pw < 2) {
+      int* t = reinterpret_cast<int*>(smem + pw * p.bufFloats);
+      t[BP + lane] = 0;
     }
     if (tb < te) stage(tb, 0);
     for (int tt = tb; tt < te; ++tt) {
@@ -270,6 +278,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   }
 
   // ---- compute waves ----------------------------------------------------------
+  unsigned long long* st = (p.stamps && tid == 0) ? p.stamps + 8L * blockIdx.x : nullptr;
+  if (st) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = __builtin_amdgcn_s_memtime(); }
   int lanebase[NT];
 #pragma unroll
   for (int nb = 0; nb < NT; ++nb) {
@@ -300,58 +310,67 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
   __builtin_amdgcn_sched_barrier(0);
 
-  // geometry of a tile.  Quads come in pairs (the two register sets ping-pong), so
-  // a tile at the end of a plane may carry one quad that lies wholly past the span:
-  // it is masked to zero like the tail of the partial quad before it.
-  auto tile_geom = [&](int tt, int& nQ, int& len) {
+  // geometry of a tile.  Every wave runs the same EVEN number of quads per tile (the
+  // two register sets ping-pong); quads that lie (partly) past the span are masked to
+  // zero and fetch from the last valid quad's address.
+  int nQ = 0, len = 0, aoff = 0, amax = 0;
+  const float* tbase = nullptr;
+  auto tile_geom = [&](int tt) {
     const int pt = tt % p.nPT;
     const int zz = tt / p.nPT;
     const int z = zz % p.Do;
     const int n = zz / p.Do;
     const int s0 = pt * BP;
     len = min(s0 + BP, p.S) - s0;                    // valid span positions of the tile
-    nQ = 2 * ((len + 31) >> 5);
-    return p.dy + (long)n * p.dsN + (long)z * p.dsZ + s0;
+    const int nQreal = (len + 15) >> 4;
+    nQ = 2 * ((nQreal + 2 * WK - 1) / (2 * WK));       // quads per wave
+    amax = 16 * (nQreal - 1);
+    tbase = p.dy + (long)n * p.dsN + (long)z * p.dsZ + s0;
+    aoff = 16 * wk;
+    ad.abase = tbase + min(aoff, amax);
   };
-  // zero the k-steps of quad qi that lie past the tile's span
-#define E2_MASK(G, qi)                                                   \
-  if (16 * ((qi) + 1) > len) G.mask(len - 16 * (qi) - 1 - 4 * qd);
-  int nQ = 0, len = 0;
+#define E2_ADV()                                                         \
+  aoff += 16 * WK; ad.abase = tbase + min(aoff, amax); ad.addrT += 64u * WK;
+  // zero the k-steps of this wave's local quad j that lie past the tile's span
+#define E2_MASK(G, j)                                                    \
+  { const int qi_ = wk + WK * (j);                                       \
+    if (16 * (qi_ + 1) > len) G.mask(len - 16 * qi_ - 1 - 4 * qd); }
   if (tb < te) {
     // first quad of the first tile, fetched in the open
-    ad.abase = tile_geom(tb, nQ, len);
+    tile_geom(tb);
     g0.load_a(ad.abase, ad.voff);                     // dy does not depend on the LDS contents
     __syncthreads();                                  // the producers' table + spans landed
     ad.xbase = d_lds_addr(smem + TBF);
-    ad.addrT = d_lds_addr(smem + 4 * qd);
+    ad.addrT = d_lds_addr(smem + 4 * qd) + 64u * (unsigned)wk;
     i32x4 io0 = d_lds_ld128(ad.addrT);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" : "+v"(io0));
-    ad.addrT += 64u;
-    g0.load_b(ad.addrT, ad.xbase, lanebase, io0);     // + the offsets of quad 1
+    ad.addrT += 64u * WK;
+    g0.load_b(ad.addrT, ad.xbase, lanebase, io0);     // + the offsets of the next quad
     E2_WAIT()
     g0.touch();
     E2_MASK(g0, 0)
   }
+  if (st) st[2] = __builtin_amdgcn_s_memtime();
   for (int tt = tb; tt < te; ++tt) {
-    // g0 holds quad 0 of tile tt; nQ is even
+    // g0 holds this wave's quad 0 of tile tt; nQ is even
     int q = 0;
     for (; q + 2 < nQ; q += 2) {
-      ad.abase += 16; ad.addrT += 64u;
+      E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
       dquad_steps<MT, NT, true, 0>(g0, g1, acc, ad, g0.io);   // compute q, fetch q+1
       E2_WAIT()
       g1.touch();
       E2_MASK(g1, q + 1)
-      ad.abase += 16; ad.addrT += 64u;
+      E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
       dquad_steps<MT, NT, true, 0>(g1, g0, acc, ad, g1.io);   // compute q+1, fetch q+2
       E2_WAIT()
       g0.touch();
       E2_MASK(g0, q + 2)
     }
-    ad.abase += 16; ad.addrT += 64u;
+    E2_ADV()
     __builtin_amdgcn_sched_barrier(0);
     dquad_steps<MT, NT, true, 0>(g0, g1, acc, ad, g0.io);     // quad nQ-2, fetch the last one
     E2_WAIT()
@@ -360,16 +379,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     // While the tile's last quad (g1) computes, fetch the first quad of the NEXT
     // tile: its barrier, its first offsets, then the loads.
     if (tt + 1 < te) {
-      ad.abase = tile_geom(tt + 1, nQ, len);
+      tile_geom(tt + 1);
       __syncthreads();                                // tile tt+1 landed; nobody reads tile tt's buffer any more
       const float* bufp = smem + ((tt + 1 - tb) & 1) * p.bufFloats;
       ad.xbase = d_lds_addr(bufp + TBF);
-      ad.addrT = d_lds_addr(bufp + 4 * qd);
+      ad.addrT = d_lds_addr(bufp + 4 * qd) + 64u * (unsigned)wk;
       i32x4 io0 = d_lds_ld128(ad.addrT);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" : "+v"(io0));
-      ad.addrT += 64u;
+      ad.addrT += 64u * WK;
       dquad_steps<MT, NT, true, 0>(g1, g0, acc, ad, io0);
       E2_WAIT()
       g0.touch();
@@ -378,11 +397,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
       dquad_steps<MT, NT, false, 0>(g1, g0, acc, ad, g1.io);
     }
   }
+#undef E2_ADV
 #undef E2_MASK
 #undef E2_WAIT
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   g0.touch();
   g1.touch();
+  if (st) st[3] = __builtin_amdgcn_s_memtime();
 
   // ---- flush: row = co (4*qd+reg), col = n-index (lane&15) -----------------
 #pragma unroll
@@ -413,35 +434,45 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
       }
     }
   }
+  if (st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[4] = __builtin_amdgcn_s_memtime();
+    st[5] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
-template <int MT, int NT, int BP>
+template <int MT, int NT, int BP, int WK>
 static int launch_d(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_direct_kernel<MT, NT, BP>),
+        reinterpret_cast<const void*>(&wgrad_direct_kernel<MT, NT, BP, WK>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_direct_kernel<MT, NT, BP>), dim3(grid), dim3(512), lds, ctx->stream, p);
+  hipLaunchKernelGGL((wgrad_direct_kernel<MT, NT, BP, WK>), dim3(grid), dim3(512), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 template <int MT>
-static int dispatch_d2(e2_ctx* ctx, const WdP& p, int NT, int BP, int grid, size_t lds) {
-  if (BP == 128) {
-    if (NT == 1) return launch_d<MT, 1, 128>(ctx, p, grid, lds);
-    if (NT == 2) return launch_d<MT, 2, 128>(ctx, p, grid, lds);
-    if (NT == 4) return launch_d<MT, 4, 128>(ctx, p, grid, lds);
+static int dispatch_d2(e2_ctx* ctx, const WdP& p, int NT, int BP, int WK, int grid, size_t lds) {
+  if (WK == 4) {
+    if (BP == 128 && NT == 2) return launch_d<MT, 2, 128, 4>(ctx, p, grid, lds);
+    if (BP == 128 && NT == 4) return launch_d<MT, 4, 128, 4>(ctx, p, grid, lds);
+    if (BP == 256 && NT == 2) return launch_d<MT, 2, 256, 4>(ctx, p, grid, lds);
+    if (BP == 256 && NT == 4) return launch_d<MT, 4, 256, 4>(ctx, p, grid, lds);
+  } else if (BP == 128) {
+    if (NT == 1) return launch_d<MT, 1, 128, 1>(ctx, p, grid, lds);
+    if (NT == 2) return launch_d<MT, 2, 128, 1>(ctx, p, grid, lds);
+    if (NT == 4) return launch_d<MT, 4, 128, 1>(ctx, p, grid, lds);
   } else if (BP == 256) {
-    if (NT == 1) return launch_d<MT, 1, 256>(ctx, p, grid, lds);
-    if (NT == 2) return launch_d<MT, 2, 256>(ctx, p, grid, lds);
-    if (NT == 4) return launch_d<MT, 4, 256>(ctx, p, grid, lds);
+    if (NT == 1) return launch_d<MT, 1, 256, 1>(ctx, p, grid, lds);
+    if (NT == 2) return launch_d<MT, 2, 256, 1>(ctx, p, grid, lds);
+    if (NT == 4) return launch_d<MT, 4, 256, 1>(ctx, p, grid, lds);
   }
-  e2_set_error("wgrad(direct): no instance NT=%d BP=%d", NT, BP);
+  e2_set_error("wgrad(direct): no instance NT=%d BP=%d WK=%d", NT, BP, WK);
   return 2;
 }
 
@@ -461,12 +492,13 @@ static int d_maxspans(const WgradArgs& a, int BNn) {
   if (cis > a.Cin) cis = a.Cin;
   return cis * a.kd;
 }
-size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP) {
-  return (size_t)(BP + 16) + (size_t)d_maxspans(a, 16 * NT * 4) * e2i_wgrad_direct_lpad(a, BP) + 64;
+size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP, int WK) {
+  return (size_t)(BP + 64) + (size_t)d_maxspans(a, 16 * NT * (4 / WK)) * e2i_wgrad_direct_lpad(a, BP) + 64;
 }
 
-int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, int PS) {
+int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, int PS, int WK) {
   E2_REQUIRE(BP == 128 || BP == 256, "wgrad(direct): BP must be 128 or 256");
+  E2_REQUIRE(WK == 1 || (WK == 4 && (NT == 2 || NT == 4)), "wgrad(direct): WK=4 needs NT 2 or 4");
   E2_REQUIRE(a.xsY < (1 << 20) && a.dsY < (1 << 20), "wgrad: row stride too large");
   E2_REQUIRE((long)a.Cout * a.dsC < (1L << 29), "wgrad(direct): gradient sample too large");
   WdP p;
@@ -482,15 +514,15 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   const long NTOT = (long)a.Cin * p.T;
   E2_REQUIRE(NTOT < (1L << 30), "wgrad: Cin*T too large");
   p.NTOT = (int)NTOT;
-  const int BNn = 16 * NT * 4;
+  const int BNn = 16 * NT * (4 / WK);
   p.Lpad = e2i_wgrad_direct_lpad(a, BP);
   p.maxSpans = d_maxspans(a, BNn);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), MT);
-  p.nNT = e2_cdiv(e2_cdiv(p.NTOT, 16), NT * 4);
+  p.nNT = e2_cdiv(e2_cdiv(p.NTOT, 16), NT * (4 / WK));
   p.nPT = e2_cdiv(p.S, BP);
   p.tilesTotal = a.N * a.Do * p.nPT;
   p.nPS = std::max(1, std::min(PS, p.tilesTotal));
-  p.bufFloats = (int)e2i_wgrad_direct_buf_floats(a, NT, BP);
+  p.bufFloats = (int)e2i_wgrad_direct_buf_floats(a, NT, BP, WK);
   p.Din = a.Do + a.kd - 1;
   p.N = a.N;
   p.divDsY = mk_divd((unsigned)a.dsY);
@@ -498,20 +530,49 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   const size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "wgrad(direct): tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
+  p.stamps = nullptr;
+  static unsigned long long* stamp_buf = nullptr;
+  const bool want_stamps = getenv("E2_WGRAD_STAMPS") != nullptr && !ctx->capturing && grid <= 65536;
+  if (want_stamps) {
+    if (!stamp_buf) E2_CHECK_HIP(hipMalloc(&stamp_buf, 8 * sizeof(unsigned long long) * 65536));
+    E2_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long) * grid, ctx->stream));
+    p.stamps = stamp_buf;
+  }
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
   if (!a.accumulate)
-    E2_CHECK_HIP(hipMemsetAsync(a.dw, 0, sizeof(float) * (size_t)a.Cout * p.NTOT, ctx->stream));
+    if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.NTOT, 0.f)) return rc;
   if (getenv("E2_VERBOSE"))
-    fprintf(stderr, "[e2] wgrad(direct) Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d BP=%d PS=%d grid=%ld lds=%zu\n",
-            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, MT, NT, BP, p.nPS, grid, lds);
+    fprintf(stderr, "[e2] wgrad(direct) Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d BP=%d WK=%d PS=%d grid=%ld lds=%zu\n",
+            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, MT, NT, BP, WK, p.nPS, grid, lds);
+  int rc = 2;
   switch (MT) {
-    case 1: return dispatch_d2<1>(ctx, p, NT, BP, (int)grid, lds);
-    case 2: return dispatch_d2<2>(ctx, p, NT, BP, (int)grid, lds);
-    case 3: return dispatch_d2<3>(ctx, p, NT, BP, (int)grid, lds);
-    case 4: return dispatch_d2<4>(ctx, p, NT, BP, (int)grid, lds);
-    case 5: return dispatch_d2<5>(ctx, p, NT, BP, (int)grid, lds);
-    case 7: return dispatch_d2<7>(ctx, p, NT, BP, (int)grid, lds);
+    case 1: rc = dispatch_d2<1>(ctx, p, NT, BP, WK, (int)grid, lds); break;
+    case 2: rc = dispatch_d2<2>(ctx, p, NT, BP, WK, (int)grid, lds); break;
+    case 3: rc = dispatch_d2<3>(ctx, p, NT, BP, WK, (int)grid, lds); break;
+    case 4: rc = dispatch_d2<4>(ctx, p, NT, BP, WK, (int)grid, lds); break;
+    case 5: rc = dispatch_d2<5>(ctx, p, NT, BP, WK, (int)grid, lds); break;
+    case 7: rc = dispatch_d2<7>(ctx, p, NT, BP, WK, (int)grid, lds); break;
+    default: e2_set_error("wgrad(direct): no instance MT=%d", MT);
   }
-  e2_set_error("wgrad(direct): no instance MT=%d", MT);
-  return 2;
+  if (rc == 0 && want_stamps) {
+    std::vector<unsigned long long> h(8 * grid);
+    E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    E2_CHECK_HIP(hipMemcpy(h.data(), stamp_buf, 8 * sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
+    unsigned long long r0 = ~0ull, r1 = 0;
+    double s_first = 0, s_loop = 0, s_epi = 0, s_tot = 0, max_tot = 0, last_start = 0;
+    for (long b = 0; b < grid; ++b) {
+      const unsigned long long* s = &h[8 * b];
+      r0 = std::min(r0, s[0]); r1 = std::max(r1, s[5]);
+      s_first += (double)(s[2] - s[1]); s_loop += (double)(s[3] - s[2]);
+      s_epi += (double)(s[4] - s[3]); s_tot += (double)(s[4] - s[1]);
+      max_tot = std::max(max_tot, (double)(s[4] - s[1]));
+    }
+    for (long b = 0; b < grid; ++b) last_start = std::max(last_start, (double)(h[8 * b] - r0));
+    const int per = (p.tilesTotal + p.nPS - 1) / p.nPS;
+    fprintf(stderr, "[e2 wgrad stamps] grid=%ld tiles/wg=%d  span=%.2f us  last start +%.2f us | per wg (cycles, mean): "
+            "to first quad %.0f, main loop %.0f (ideal %.0f), flush %.0f, total %.0f (max %.0f)\n",
+            grid, per, (double)(r1 - r0) * 0.01, last_start * 0.01, s_first / grid, s_loop / grid,
+            (double)per * (BP / 4 / WK) * MT * NT * 32.0, s_epi / grid, s_tot / grid, max_tot);
+  }
+  return rc;
 }

@@ -465,17 +465,21 @@ int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
   return 0;
 }
 
-extern "C" int e2_fill(e2_ctx* ctx, float* ptr, size_t n, float value) {
-  E2_REQUIRE(ctx && ptr, "e2_fill: null argument");
+// Flat fill as a KERNEL, also for zeros: hipMemsetAsync nodes inside a captured
+// hipGraph were observed to be re-ordered against the kernel that follows them on
+// replay (unet3d_lite: the split-K accumulation of a conv started from stale data in
+// ~1 of 3 processes); kernel nodes keep their order.
+int e2i_fill_flat(e2_ctx* ctx, float* ptr, size_t n, float value) {
   if (n == 0) return 0;
-  if (value == 0.f) {
-    E2_CHECK_HIP(hipMemsetAsync(ptr, 0, n * sizeof(float), ctx->stream));
-    return 0;
-  }
   int grid = (int)std::min<size_t>((n + 255) / 256, 8192);
   hipLaunchKernelGGL(fill_flat_kernel, dim3(grid), dim3(256), 0, ctx->stream, ptr, n, value);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int e2_fill(e2_ctx* ctx, float* ptr, size_t n, float value) {
+  E2_REQUIRE(ctx && ptr, "e2_fill: null argument");
+  return e2i_fill_flat(ctx, ptr, n, value);
 }
 
 extern "C" int e2_copy5(e2_ctx* ctx, const e2_tensor5* src, const e2_tensor5* dst,

@@ -47,7 +47,8 @@ class Plan(object):
         self.model = model if model is not None else getattr(self.outputs[0], '_model', None)
         if self.model is None:
             raise RuntimeError("plan: nodes are not registered in a model")
-        self.use_graph = use_graph
+        import os as _os
+        self.use_graph = use_graph and _os.environ.get('E2_NO_GRAPH', '0') != '1'
         self.ctx = None
         self.batch = None
         self.last_device_time = None

@@ -189,9 +189,14 @@ def test_unet3d_lite_native_size_parity():
     """BASELINE configs[2]: examples/unet3d_lite.py at its own input (1,1,22,140,140)
     -> (1,2,10,52,52), 398 GF per step: loss and every parameter gradient against the
     torch-CPU float64 evaluation of the same graph.  Output (loss) tolerance 1e-4
-    (north_star); gradient tolerance 3e-4 of each tensor's max magnitude: 20 fp32
-    layers deep, the worst tensor (conv6) sits at 1.5e-4 for this build AND for
-    torch-CPU fp32 (tools/unet_diag.py), whose worst tensor is at 1.3e-3."""
+    (north_star).  Gradient tolerance 1e-3 of each tensor's max magnitude: 20 fp32
+    layers deep, a pre-activation within fp32 rounding of zero lands on the other side
+    of the relu than in float64 and moves single gradient elements by O(1e-4..1e-3)
+    of the tensor's maximum (typical worst tensor 1.5e-4, seen up to 3.5e-4; torch-CPU
+    fp32 sits at 1.3e-3, tools/unet_diag.py).
+    Then the captured hipGraphs are replayed: loss and gradients must stay put (a
+    hipMemsetAsync node re-ordered against the split-K kernel behind it once broke
+    exactly this, see csrc/pointwise.hip e2i_fill_flat)."""
     from elektronn2_amd import neuromancer as nm, nets
     nm.model_manager.reset()
     np.random.seed(5)
@@ -209,4 +214,10 @@ def test_unet3d_lite_native_size_parity():
     for i, nme in enumerate(names):
         ref = G[nme]
         worst = max(worst, float(np.abs(g[i] - ref).max() / (np.abs(ref).max() + 1e-30)))
-    assert worst < 3 * TOL, worst
+    assert worst < 10 * TOL, worst
+    L0 = float(model.loss(x, t))
+    for _ in range(6):                       # call 2 captures, calls 3.. replay
+        g2 = model.gradients(x, t)
+        assert abs(float(model.loss(x, t)) - L0) / L0 < 1e-5
+        for a, b in zip(g, g2):
+            assert float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30)) < 2e-3

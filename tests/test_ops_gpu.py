@@ -143,7 +143,8 @@ def test_conv3d_1x1_forced_tilings(ctx, force):
 
 
 @pytest.mark.parametrize("force", ["1,1,1,128,3", "2,2,1,256,5", "3,4,1,128,2", "4,1,1,256,7",
-                                   "5,2,1,128,1", "7,4,1,128,3", "7,2,1,256,2", "7,1,1,128,40"])
+                                   "5,2,1,128,1", "7,4,1,128,3", "7,2,1,256,2", "7,1,1,128,40",
+                                   "3,4,14,256,3", "2,2,14,128,5", "7,2,14,256,1", "1,4,14,128,40"])
 @pytest.mark.parametrize("k", [(2, 3, 3), (1, 1, 1), (1, 4, 1)])
 def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
     """direct kernel: dy from the zero-padded buffer; partial quads at the plane ends,
@@ -159,6 +160,7 @@ def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
     pshape = (2, 100) + tuple(osp[i] + 2 * pad[i] for i in range(3))
     flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
     flat[-32:] = float("nan")              # the slack may be read, never used
+    dev(dy)                                # (keeps the allocator from handing back zeros)
     dyp = flat[:int(np.prod(pshape))].view(pshape)
     dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
     dw = torch.full(w.shape, float("nan"), device="cuda")
