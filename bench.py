@@ -38,10 +38,10 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
 # HBM-side bytes per step from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-# --pmc WRITE_SIZE runs of this script, profiles/r01_c_pmc_traffic.csv):
+# --pmc WRITE_SIZE runs of this script, profiles/r01_d_pmc_traffic.csv):
 # 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
 # It cannot be measured inside the timed run; null for workloads not profiled.
-PMC_TRAFFIC_BYTES = {"lite183": (2 * 825.9 + 475.1) * 1024 * 1024}
+PMC_TRAFFIC_BYTES = {"lite183": (2 * 822.1 + 417.7) * 1024 * 1024}
 
 
 def algorithmic_gflop(spec, sp):
@@ -193,7 +193,7 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "traffic": PMC_TRAFFIC_BYTES.get(args.workload),
                      "traffic_unit": "B/step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
-                                     "profiles/r01_c_pmc_traffic.csv)",
+                                     "profiles/r01_d_pmc_traffic.csv)",
                      "kernel": "training step (hipGraph): conv3d igemm fwd/dgrad/wgrad on "
                                "v_mfma_f32_16x16x4_f32 + pointwise + Adam",
                      "algorithmic_gflop_per_step": gflop,
