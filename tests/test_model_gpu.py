@@ -150,6 +150,35 @@ def test_unet_like_merge_parity():
         assert rel(g[names.index(n.name + '_b')], W[n.name][1].grad.numpy()) < TOL, n.name
 
 
+def test_graph_replay_equals_eager_at_baseline_size():
+    """C-lite@183 (BASELINE configs[1]): 12 Adam steps replayed from the captured
+    hipGraphs against the same 12 steps launched eagerly -- the losses must agree step
+    by step and the parameters at the end (what differs is only the order of fp32
+    atomics).  Guards the capture path (memset / kernel ordering, baked arguments)."""
+    from elektronn2_amd import neuromancer as nm
+    spec, sp = O.NEURO3D_LITE, (23, 183, 183)
+    params = O.init_net(spec, 1, seed=1)
+    rng = np.random.RandomState(11)
+    xs = [rng.rand(1, 1, *sp).astype(np.float32) for _ in range(3)]
+    ts = [rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+          for _ in range(3)]
+    runs = []
+    for use_graph in (True, False):
+        m = build('lite', sp, params)
+        m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        opt = m.optimisers['Adam']
+        opt.step.compile()
+        opt.step.func.use_graph = use_graph
+        losses = [float(m.trainingstep(xs[i % 3], ts[i % 3], optimiser='Adam')[0])
+                  for i in range(12)]
+        runs.append((losses, [p.get_value() for p in m.loss_node.all_trainable_params.values()]))
+    (lg, pg), (le, pe) = runs
+    for a, b in zip(lg, le):
+        assert abs(a - b) / abs(b) < 1e-5, (lg, le)
+    for a, b in zip(pg, pe):
+        assert rel(a, b) < 1e-4
+
+
 def torch_mirror(model, x, t, dtype):
     """evaluate the model's node graph with torch-CPU closed forms (oracle/torch_step.py)
     and return (loss, {param name: gradient}) from autograd"""
