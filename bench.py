@@ -73,12 +73,55 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("E2_CPU_BASELINE_CORES", "16"))))
 
 
+def dense_prediction_bench(args, rank, world):
+    """SURVEY 8(f)-3 (not the headline metric): Model.predict_dense of neuro3d_lite at the
+    BASELINE patch size over a (1,43,331,331) volume = 2x2x2 blocks x 32 stride offsets
+    = 256 forward passes per prediction; one "step" = one whole-volume prediction."""
+    from elektronn2_amd import nets
+    from oracle import e2_oracle as O
+    spec, sp = O.NEURO3D_LITE, (23, 183, 183)
+    model = nets.neuro3d_lite((None, 1) + sp, params=O.init_net(spec, 1, seed=1))
+    rng = np.random.RandomState(0)
+    raw = rng.rand(1, 43, 331, 331).astype(np.float32)
+    for _ in range(max(1, min(args.warmup, 2))):
+        pred = model.predict_dense(raw)
+    steps = max(1, min(args.steps, 5))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pred = model.predict_dense(raw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fwd_gf = sum(2.0 * nf * ci * np.prod(k) * np.prod(o) for nf, ci, k, o in _fwd_layers(spec, sp)) / 1e9
+    passes = 8 * 32
+    out = {"metric": "dense_prediction_voxels_per_sec", "value": float(np.prod(pred.shape[1:])) / dt,
+           "unit": "voxels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+           "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "neuro3d_lite predict_dense (1,43,331,331)->(2,39,293,293), "
+                                  "8 blocks x 32 stride offsets, host volume in / host prediction out"},
+           "roofline": {"bound": "mfma", "achieved": passes * fwd_gf / dt / 1e3,
+                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": passes * fwd_gf / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, "traffic": None}}
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def _fwd_layers(spec, sp):
+    cin = 1
+    for nf, k, p, _ in spec:
+        osp = [sp[i] - k[i] + 1 for i in range(3)]
+        yield nf, cin, k, osp
+        sp = [osp[i] // p[i] for i in range(3)]
+        cin = nf
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -95,6 +138,8 @@ def main():
         parallel.init_from_env(os.environ.get("E2_DIST_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, "launch with torchrun for --gpus > 1"
 
+    if args.workload == "dense183":
+        return dense_prediction_bench(args, rank, world)
     builder, sp, gf_table = WORKLOADS[args.workload]
     if builder == "unet3d_lite":
         spec = params = None

@@ -282,6 +282,10 @@ class Model(GraphManager):
     def predict(self, *args, **kwargs):
         return self.prediction_node(*args, **kwargs)
 
+    def predict_dense(self, raw_img, as_uint8=False, pad_raw=False):
+        """model.py:658-713 (without MFP): dense prediction of a whole volume"""
+        return self.prediction_node.predict_dense(raw_img, as_uint8=as_uint8, pad_raw=pad_raw)
+
     def predict_ext(self, *args, **kwargs):
         return self._prediction_ext_func(*args, **kwargs)
 

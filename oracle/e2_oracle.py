@@ -474,3 +474,73 @@ def net_train_steps(spec, params, x, target, n_steps, lr=5e-4, mom=0.9,
                                   wd, False)
             P[i], M[i], S[i] = (w, b), (mw, mb), (sw, sb)
     return losses, P
+
+
+# --------------------------------------------------------------------------
+# dense prediction (node_basic.py:805-1012, without MFP)
+# --------------------------------------------------------------------------
+def net_geometry(spec):
+    """(strides, fov, offsets) of a valid conv/pool stack, per spatial axis:
+    fov grows by (k-1)*stride_so_far then by (p-1)*stride_so_far, strides multiply by
+    the pool factors (neural.py:725-764); offsets = fov // 2 (graphutils.py:98-104)."""
+    strides, fov = np.ones(3, np.int64), np.ones(3, np.int64)
+    for n_f, k, p, _ in spec:
+        fov = fov + (np.asarray(k) - 1) * strides
+        fov = fov + (np.asarray(p) - 1) * strides
+        strides = strides * np.asarray(p)
+    return strides, fov, fov // 2
+
+
+def predict_dense(spec, params, raw, patch_sp, as_uint8=False, pad_raw=False):
+    """Restatement of Node.predict_dense / _predict_densetile for a sequential net
+    (probabilities = softmax of net_fwd): block tiling with zero-padded end blocks,
+    one forward pass per stride offset, outputs interleaved at [off::stride]."""
+    raw = np.asarray(raw)
+    m = 255.0 if raw.dtype.kind in 'iu' else 1.0
+    raw = raw.astype(np.float32) / np.float32(m)
+    strides, fov, offset = net_geometry(spec)
+    if pad_raw:
+        raw = np.pad(raw, [(0, 0)] + [(int(o), int(o)) for o in offset], mode='symmetric')
+    ps = np.asarray(patch_sp, np.int64)
+    out_sh = np.asarray(net_out_shape(spec, patch_sp), np.int64)
+    n_lab = spec[-1][0]
+    tile_sh = ps + strides - 1
+    prob_sh = out_sh * strides
+    raw_sh = np.asarray(raw.shape[1:], np.int64)
+    pred_sh = raw_sh - 2 * offset
+    pred = np.zeros((n_lab,) + tuple(pred_sh), np.uint8 if as_uint8 else np.float32)
+    n_t = [int(np.ceil(float(pred_sh[i]) / prob_sh[i])) for i in range(3)]
+    for zt in range(n_t[0]):
+        for xt in range(n_t[1]):
+            for yt in range(n_t[2]):
+                lo = np.array([zt, xt, yt]) * prob_sh
+                tile = raw[:, lo[0]:lo[0] + tile_sh[0], lo[1]:lo[1] + tile_sh[1],
+                           lo[2]:lo[2] + tile_sh[2]]
+                pad = tile_sh - np.asarray(tile.shape[1:])
+                if np.any(pad > 0):                     # end block: zero padding on the far side
+                    tile = np.pad(tile, [(0, 0)] + [(0, int(q)) for q in pad], mode='constant')
+                prob = np.zeros((n_lab,) + tuple(prob_sh), np.float32)
+                for oz in range(strides[0]):
+                    for ox in range(strides[1]):
+                        for oy in range(strides[2]):
+                            cut = tile[None, :, oz:oz + ps[0], ox:ox + ps[1], oy:oy + ps[2]]
+                            logits, _ = net_fwd(spec, params, cut)
+                            prob[:, oz::strides[0], ox::strides[1], oy::strides[2]] = \
+                                softmax(logits, 1)[0].astype(np.float32)
+                keep = np.minimum(prob_sh, pred_sh - lo)
+                prob = prob[:, :keep[0], :keep[1], :keep[2]]
+                if as_uint8:
+                    prob = prob * np.float32(255)
+                pred[:, lo[0]:lo[0] + keep[0], lo[1]:lo[1] + keep[1], lo[2]:lo[2] + keep[2]] = prob
+    return pred
+
+
+def predict_voxel(spec, params, raw, pos):
+    """independent check of predict_dense: the prediction at dense position ``pos``
+    is the net evaluated on the field-of-view patch that starts there."""
+    strides, fov, offset = net_geometry(spec)
+    z, x, y = (int(v) for v in pos)
+    cut = np.asarray(raw, np.float32)[None, :, z:z + fov[0], x:x + fov[1], y:y + fov[2]]
+    logits, _ = net_fwd(spec, params, cut)
+    assert logits.shape[2:] == (1, 1, 1), logits.shape
+    return softmax(logits, 1)[0, :, 0, 0, 0]

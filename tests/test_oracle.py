@@ -118,3 +118,32 @@ def test_step_golden_lite_and_fp32_port():
     assert np.abs(np.array(losses) - g['losses3']).max() / abs(g['losses3']).max() < 1e-5
     w_last = net.w[-1].detach().numpy()
     assert np.abs(w_last - g['w3_last']).max() / np.abs(g['w3_last']).max() < 5e-4
+
+
+DENSE_SPEC = [(4, (1, 3, 3), (1, 2, 2), 'relu'), (6, (3, 3, 3), (2, 1, 1), 'relu'),
+              (2, (1, 1, 1), (1, 1, 1), 'lin')]
+
+
+def test_predict_dense_tiling_equals_per_voxel_evaluation():
+    """oracle self-check for the dense-prediction row (node_basic.py:805-1012): the
+    tiled, stride-offset-interleaved prediction equals the net evaluated on the
+    field-of-view patch of every voxel (independent of tiling, strides, end blocks)."""
+    spec = DENSE_SPEC
+    params = O.init_net(spec, 1, seed=3)
+    strides, fov, offset = O.net_geometry(spec)
+    assert tuple(strides) == (2, 2, 2) and tuple(fov) == (4, 8, 8)
+    rng = np.random.RandomState(0)
+    raw = rng.rand(1, 11, 23, 25).astype(np.float32)
+    dense = O.predict_dense(spec, params, raw, (6, 16, 16))
+    assert dense.shape == (2, 11 - 2 * offset[0], 23 - 2 * offset[1], 25 - 2 * offset[2])
+    for z, x, y in [(0, 0, 0), (1, 2, 3), (6, 14, 16), (3, 14, 0), (5, 7, 9), (6, 0, 16)]:
+        ref = O.predict_voxel(spec, params, raw, (z, x, y))
+        assert np.abs(dense[:, z, x, y] - ref).max() < 1e-6, (z, x, y)
+    # integer input is scaled by 1/255; uint8 output is floor(255 p); mirror padding
+    raw8 = (raw * 255).astype(np.uint8)
+    d8 = O.predict_dense(spec, params, raw8, (6, 16, 16), as_uint8=True)
+    assert d8.dtype == np.uint8 and np.abs(d8.astype(np.float32) - 255 * dense).max() < 3.0
+    dp = O.predict_dense(spec, params, raw, (6, 16, 16), pad_raw=True)
+    assert dp.shape == (2, 11, 23, 25)
+    assert np.abs(dp[:, offset[0]:-offset[0], offset[1]:-offset[1], offset[2]:-offset[2]]
+                  - dense).max() < 1e-6

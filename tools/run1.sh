@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 400 python -m pytest tests/test_model_gpu.py -x -q 2>&1 | tail -6
+timeout -k 10 300 python bench.py --workload dense183 --steps 3 --warmup 1 2>&1 | tail -1
