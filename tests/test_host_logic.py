@@ -128,5 +128,6 @@ def test_choose_name_and_call_arity():
     assert nm.choose_name('conv', ['conv']) == 'conv1'
     assert nm.choose_name('conv', ['conv', 'conv1', 'conv2']) == 'conv3'
     m = nets.neuro3d_lite((None, 1, 7, 47, 47))
+    x = np.zeros((1, 1, 7, 47, 47), np.float32)
     with pytest.raises(TypeError, match="inputs required"):
-        m.prediction_node()
+        m.prediction_node(x, x)          # (a call without arguments only compiles)
