@@ -107,6 +107,69 @@ def dense_prediction_bench(args, rank, world):
         print(json.dumps(out))
 
 
+def warp_bench(args, rank, world):
+    """SURVEY 8(f)-1 (not the headline metric): PatchSampler.getbatch at the BASELINE patch
+    size -- random warp + perspective, image (23,183,183) trilinear + label target
+    (19,145,145) nearest, grey augmentation -- from a (1,80,400,400) volume resident in HBM.
+    One "step" = one patch.  roofline: HBM; algorithmic bytes = 8 B per voxel and channel
+    (source read once + patch written) over the GPU time per patch (HIP events)."""
+    from elektronn2_amd.data import PatchSampler
+    from elektronn2_amd.neuromancer.plan import get_ctx
+    rng = np.random.RandomState(0)
+    vol = rng.rand(1, 80, 400, 400).astype(np.float32)
+    lab = rng.randint(0, 2, (1, 80, 400, 400)).astype(np.float32)
+    ps, strides, offsets = (23, 183, 183), (2, 4, 4), (2, 19, 19)
+    np.random.seed(0)
+    smp = PatchSampler([vol], [lab], ps, strides, offsets, seed=0)
+    kw = dict(grey_augment_channels=[0], warp=True, warp_args={'sample_aniso': True,
+                                                               'perspective': True})
+    for _ in range(max(args.warmup, 3)):
+        smp.getbatch(1, 'train', **kw)
+    ctx = get_ctx()
+    steps = max(args.steps, 20)
+    torch.cuda.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    t0 = time.perf_counter()
+    ctx.record(e0)
+    for _ in range(steps):
+        d, t = smp.getbatch(1, 'train', **kw)
+    ctx.record(e1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dev_ms = ctx.elapsed_ms(e0, e1) / steps
+    vox = float(np.prod(ps)) + float(np.prod(smp.target_ps))
+    out = {"metric": "augmented_patches_per_sec", "value": 1.0 / dt, "unit": "patches/s",
+           "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": "PatchSampler.getbatch patch (23,183,183) + target (19,145,145), "
+                                  "warp + perspective + grey augment, volume (1,80,400,400) in HBM",
+                      "input_voxels_per_sec": float(np.prod(ps)) / dt,
+                      "oob_retries": smp.n_failed_warp},
+           "roofline": {"bound": "hbm", "achieved": 8.0 * vox / (dev_ms * 1e-3) / 1e9, "peak": 8000.0,
+                        "unit": "GB/s", "frac": 8.0 * vox / (dev_ms * 1e-3) / 1e9 / 8000.0,
+                        "traffic": None, "device_ms_per_patch": dev_ms}}
+    if not args.no_cpu_baseline:
+        from oracle import warp_oracle as WO
+        g = np.random.RandomState(1)
+        ts = []
+        while len(ts) < 3:
+            M = WO.random_warp_matrix(vol.shape[1:], ps, 2, True, 1.0, True, False, True,
+                                      lab.shape[1:], smp.target_ps, g)
+            try:
+                c0 = time.perf_counter()
+                dd, tt = WO.warp_slice(vol, ps, M, target=lab, target_ps=smp.target_ps)
+                WO.grey_augment(dd, [0], g)
+                ts.append(time.perf_counter() - c0)
+            except WO.WarpingOOBError:
+                continue
+        out["cpu_baseline"] = {"value": 1.0 / float(np.median(ts)), "unit": "patches/s", "cores": 1,
+                               "kind": "port", "sample": "3 patches (median), NumPy restatement of "
+                               "warp_slice + greyAugment (the reference uses numba-parallel gathers)"}
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def _fwd_layers(spec, sp):
     cin = 1
     for nf, k, p, _ in spec:
@@ -121,7 +184,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183"])
+    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "warp183"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -140,6 +203,8 @@ def main():
 
     if args.workload == "dense183":
         return dense_prediction_bench(args, rank, world)
+    if args.workload == "warp183":
+        return warp_bench(args, rank, world)
     builder, sp, gf_table = WORKLOADS[args.workload]
     if builder == "unet3d_lite":
         spec = params = None

@@ -14,6 +14,7 @@ import ctypes as C
 import os
 from typing import Optional, Sequence
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -68,6 +69,9 @@ def _load():
         "e2_head_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
         "e2_head_bwd": (C.c_int, [vp, P5, fp, P5, P5, fp, P5, i, fp, fp, fp, C.c_void_p,
                                   C.c_size_t]),
+        "e2_warp_slice": (C.c_int, [vp, P5, C.POINTER(C.c_float), i, C.c_uint,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_float), P5]),
+        "e2_grey_augment": (C.c_int, [vp, fp, C.c_size_t, C.c_float, C.c_float, C.c_float]),
         "e2_stream_fork": (C.c_int, [vp, C.c_void_p]),
         "e2_stream_join": (C.c_int, [vp, C.c_void_p]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
@@ -226,6 +230,23 @@ class Context:
     def bias_act_bwd_out(self, dout, out, act, dy, dbias):
         _chk(_lib.e2_bias_act_bwd_out(self.h, C.byref(t5(dout)), C.byref(t5(out)), ACT[act],
                                       C.byref(t5(dy)), _fp(dbias)), "e2_bias_act_bwd_out")
+
+    # ---- patch extraction / augmentation ---------------------------------------
+    def warp_slice(self, src, minv, perspective, nearest_mask, dest_off, src_off, dst):
+        """src (F,Z,X,Y) view, dst (F,pz,px,py) dense device tensors; minv 4x4 host array"""
+        m = (C.c_float * 16)(*[float(v) for v in np.asarray(minv, np.float32).ravel()])
+        do = (C.c_int * 3)(*[int(v) for v in dest_off])
+        so = (C.c_float * 3)(*[float(v) for v in src_off])
+        _chk(_lib.e2_warp_slice(self.h, C.byref(t5(src[None])), m, 1 if perspective else 0,
+                                int(nearest_mask), do, so, C.byref(t5(dst[None]))),
+             "e2_warp_slice")
+
+    def grey_augment(self, chan, alpha, c, gamma):
+        """in place on one dense channel tensor"""
+        if not chan.is_contiguous():
+            raise TypeError("grey_augment needs a dense channel")
+        _chk(_lib.e2_grey_augment(self.h, _fp(chan), chan.numel(), float(alpha), float(c),
+                                  float(gamma)), "e2_grey_augment")
 
     # ---- fused classifier head -------------------------------------------------
     @staticmethod

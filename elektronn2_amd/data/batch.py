@@ -1,0 +1,109 @@
+"""Batch creation from volumes resident on the GPU: the part of
+``BatchCreatorImage.getbatch`` (data/cnndata.py:214-402) that is on the training path --
+draw a cube, cut a (warped) patch and its centred target, grey-augment the image,
+sub-sample the target by the net's output strides -- without the file / HDF5 / KNOSSOS
+plumbing, lazy labels, affinities and non-geometric blob augmentations."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import transformations
+from .transformations import WarpingOOBError
+
+
+def grey_augment(d, channels, rng, ctx=None):
+    """cnndata.py:42-60 on a device tensor (f, z, x, y):
+    ``d[ch] = clip(d[ch] * alpha + c, 0, 1) ** gamma`` with alpha ~ 1 +- 0.15,
+    c ~ +- 0.15, gamma ~ 2**U(-1, 1), one triple per listed channel; returns a new
+    tensor (the patch is a fresh buffer anyway, so it is modified in place)."""
+    if not channels:
+        return d
+    if ctx is None:
+        from ..neuromancer.plan import get_ctx
+        ctx = get_ctx()
+    k = len(channels)
+    alpha = 1 + (rng.rand(k) - 0.5) * 0.3
+    c = (rng.rand(k) - 0.5) * 0.3
+    gamma = 2.0 ** (rng.rand(k) * 2 - 1)
+    for i, ch in enumerate(channels):
+        ctx.grey_augment(d[ch], alpha[i], c[i], gamma[i])
+    return d
+
+
+class PatchSampler(object):
+    """``getbatch(batch_size, source, grey_augment_channels, warp, warp_args)`` ->
+    ``(data (b, f, z, x, y), target (b, f_t, z', x', y'))`` device tensors.
+
+    data / targets: lists of (f, z, x, y) arrays (uploaded once); targets must be
+    centred in their images.  ``patch_size`` = the input node's spatial shape,
+    ``strides`` / ``offsets`` = the target node's (cnndata.py:134-140)."""
+
+    def __init__(self, data, targets, patch_size, strides, offsets, aniso_factor=2,
+                 target_discrete_ix=None, seed=None, valid=()):
+        from ..neuromancer.plan import get_ctx
+        self.ctx = get_ctx()
+        dev = self.ctx.device
+        self.d = [torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev) for a in data]
+        self.t = [torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev) for a in targets]
+        self.valid = list(valid)
+        self.train = [i for i in range(len(self.d)) if i not in self.valid]
+        self.patch_size = tuple(int(p) for p in patch_size)
+        self.strides = tuple(int(s) for s in strides)
+        self.offsets = tuple(int(o) for o in offsets)
+        self.target_ps = tuple(p - 2 * o for p, o in zip(self.patch_size, self.offsets))
+        self.aniso_factor = aniso_factor
+        self.target_discrete_ix = target_discrete_ix
+        self.rng = np.random.RandomState(seed)
+        w = np.array([self.t[i][0].numel() for i in self.train], np.float64)
+        self._sampling_weight = np.hstack((0, np.cumsum(w / w.sum())))   # cnndata.py:576-583
+        self.n_failed_warp = 0
+        self.n_successful_warp = 0
+
+    def _getcube(self, source):
+        if source == 'train':
+            p = self.rng.rand()
+            i = self.train[int(np.flatnonzero(self._sampling_weight <= p)[-1])]
+        elif source == 'valid':
+            if not self.valid:
+                raise ValueError("No validation set")
+            i = self.valid[self.rng.randint(0, len(self.valid))]
+        else:
+            raise ValueError("Unknown data source")
+        return self.d[i], self.t[i]
+
+    def getbatch(self, batch_size=1, source='train', grey_augment_channels=None, warp=False,
+                 warp_args=None, force_dense=False):
+        grey_augment_channels = grey_augment_channels or []
+        warp_args = dict(warp_args or {})
+        n_f, n_t = self.d[0].shape[0], self.t[0].shape[0]
+        dev = self.ctx.device
+        images = torch.empty((batch_size, n_f) + self.patch_size, dtype=torch.float32, device=dev)
+        target = torch.empty((batch_size, n_t) + self.target_ps, dtype=torch.float32, device=dev)
+        count = 0
+        while count < batch_size:
+            d, t = self._getcube(source)
+            if warp is True or warp == 1:
+                do_warp = True
+            elif 0 < warp < 1:
+                do_warp = bool(self.rng.rand() < warp)
+            else:
+                do_warp = False
+            args = dict(warp_args)
+            if not do_warp:
+                args['warp_amount'] = 0
+            try:
+                transformations.get_warped_slice(
+                    d, self.patch_size, aniso_factor=self.aniso_factor, target=t,
+                    target_ps=self.target_ps, target_discrete_ix=self.target_discrete_ix,
+                    rng=self.rng, out=images[count], target_out=target[count], **args)
+                self.n_successful_warp += 1
+            except WarpingOOBError:
+                self.n_failed_warp += 1
+                continue
+            if source == 'train':
+                grey_augment(images[count], grey_augment_channels, self.rng, self.ctx)
+            count += 1
+        if not (force_dense or all(s == 1 for s in self.strides)):
+            target = target[:, :, ::self.strides[0], ::self.strides[1], ::self.strides[2]]
+        return images, target

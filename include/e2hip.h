@@ -241,6 +241,20 @@ int e2_graph_launch(e2_ctx*, e2_graph*);     /* hipGraphLaunch on the stream*/
 int e2_graph_destroy(e2_graph*);
 
 /* ---- timing helpers (HIP events on the context's stream) -------------- */
+/* ---- patch extraction with warp + grey augmentation on the device (SURVEY 8f-1;
+ *      data/transformations.py:337-492, :42-76; data/cnndata.py:42-60).
+ *      dst[f][z][x][y] = interp(src[f], Minv . (z + dest_off[0], x + dest_off[1],
+ *      y + dest_off[2], 1) - src_off): trilinear, or nearest (np.round) for the
+ *      channels whose bit is set in nearest_mask.  src: (1, F <= 32, Z, X, Y) view of
+ *      the resident volume; dst: dense (1, F, pz, px, py); Minv, dest_off (3 ints),
+ *      src_off (3 floats) in HOST memory (NULL offsets = 0).  The caller checks the
+ *      patch corners against the volume first (WarpingOOBError on the host side). */
+int e2_warp_slice(e2_ctx*, const e2_tensor5* src, const float* minv, int perspective,
+                  unsigned nearest_mask, const int* dest_off, const float* src_off,
+                  const e2_tensor5* dst);
+/* d = clip(d * alpha + c, 0, 1) ** gamma on one dense channel of n floats, in place */
+int e2_grey_augment(e2_ctx*, float* d, size_t n, float alpha, float c, float gamma);
+
 typedef struct e2_event e2_event;
 int e2_event_create(e2_event** out);
 int e2_event_record(e2_ctx*, e2_event*);
