@@ -153,6 +153,41 @@ def test_patch_sampler_batches(ctx):
         k += 1
 
 
+@pytest.mark.gpu
+def test_training_fed_by_the_device_sampler(ctx):
+    """the intended pipeline: volumes in HBM -> PatchSampler (device tensors) ->
+    Model.trainingstep, no host copy of the patch; the loss on a learnable synthetic
+    task (label = bright voxel) must fall."""
+    from elektronn2_amd import nets, neuromancer as nm
+    from elektronn2_amd.data import PatchSampler
+    nm.model_manager.reset()
+    np.random.seed(0)
+    model = nets.neuro3d_lite((None, 1, 13, 47, 47))
+    model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    rng = np.random.RandomState(0)
+    vol = rng.rand(1, 40, 120, 120).astype(np.float32)
+    import scipy.ndimage as ndi
+    vol[0] = ndi.gaussian_filter(vol[0], 2.0)
+    vol = (vol - vol.min()) / (vol.max() - vol.min())
+    lab = (vol > np.median(vol)).astype(np.float32)
+    tn = model.target_node
+    smp = PatchSampler([vol], [lab], model.input_node.shape.spatial_shape, tn.shape.strides,
+                       tn.shape.offsets, seed=3)
+    val = [smp.getbatch(1, 'train') for _ in range(6)]           # fixed evaluation patches
+
+    def val_loss():
+        return float(np.mean([float(model.loss(d, t)) for d, t in val]))
+    before = val_loss()
+    losses = []
+    for i in range(150):
+        d, t = smp.getbatch(1, 'train', grey_augment_channels=[0], warp=0.5)
+        assert d.is_cuda and t.is_cuda
+        losses.append(float(model.trainingstep(d, t, optimiser='Adam')[0]))
+    after = val_loss()
+    assert np.all(np.isfinite(losses))
+    assert after < 0.9 * before, (before, after)
+
+
 def torch_eq(a, b):
     import torch
     return bool(torch.equal(a, b))
