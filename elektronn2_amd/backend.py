@@ -69,6 +69,10 @@ def _load():
         "e2_head_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
         "e2_head_bwd": (C.c_int, [vp, P5, fp, P5, P5, fp, P5, i, fp, fp, fp, C.c_void_p,
                                   C.c_size_t]),
+        "e2_malis_loss_weights": (C.c_int, [i, C.c_void_p, i, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, i, C.c_void_p]),
+        "e2_malis_connected_components": (C.c_int, [i, i, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    i, C.c_void_p]),
         "e2_warp_slice": (C.c_int, [vp, P5, C.POINTER(C.c_float), i, C.c_uint,
                                     C.POINTER(C.c_int), C.POINTER(C.c_float), P5]),
         "e2_grey_augment": (C.c_int, [vp, fp, C.c_size_t, C.c_float, C.c_float, C.c_float]),

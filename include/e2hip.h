@@ -255,6 +255,20 @@ int e2_warp_slice(e2_ctx*, const e2_tensor5* src, const float* minv, int perspec
 /* d = clip(d * alpha + c, 0, 1) ** gamma on one dense channel of n floats, in place */
 int e2_grey_augment(e2_ctx*, float* d, size_t n, float alpha, float c, float gamma);
 
+/* ---- MALIS (host code, no GPU involved; malis/_malis_lib.cpp:38-167 via
+ *      malis/_malis.pyx:42-123).  e2_malis_loss_weights: counts[e] = number of voxel
+ *      pairs whose maximin edge in the affinity graph is e and whose ground-truth ids are
+ *      equal (pos != 0) or different (pos == 0); seg ids 0 = unlabelled; node indices out
+ *      of [0, n_vert) mark absent edges.  e2_malis_connected_components: seg[v] = 1 +
+ *      representative under edges with |weight| > 1e-5, components of <= size_thresh
+ *      voxels -> 0.  Return 0 on success, 2 on bad arguments. ------------------------- */
+int e2_malis_loss_weights(int n_vert, const int32_t* seg, int n_edge, const int32_t* node1,
+                          const int32_t* node2, const float* edge_weight, int pos,
+                          uint64_t* counts);
+int e2_malis_connected_components(int n_vert, int n_edge, const int32_t* node1,
+                                  const int32_t* node2, const float* edge_weight,
+                                  int size_thresh, int32_t* seg);
+
 typedef struct e2_event e2_event;
 int e2_event_create(e2_event** out);
 int e2_event_record(e2_ctx*, e2_event*);
