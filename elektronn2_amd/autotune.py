@@ -5,7 +5,8 @@ refines the choice per problem by timing a short list of candidates on the GPU
 (HIP events on the context's stream) the first time a problem is seen -- the
 moral equivalent of the seconds Theano spent in ``theano.function`` compile
 (graphutils.py:376-387), here it is ~20 ms per layer.  Results are cached in
-the process and in ``$E2HIP_TUNE_CACHE`` (default ~/.cache/e2hip_tune.json);
+the process and in ``$E2HIP_TUNE_CACHE`` (default: ``.tune_cache.json`` next to this
+file, git-ignored);
 ``elektronn2_amd/tuned.json`` ships the choices for the BASELINE workloads.
 
 Tilings are passed to the library through the E2_IGEMM_FORCE / E2_WGRAD_FORCE
@@ -28,8 +29,7 @@ WGRAD_MTS = [1, 2, 3, 4, 5, 7]
 
 
 def _cache_path():
-    return os.environ.get("E2HIP_TUNE_CACHE",
-                          os.path.join(os.path.expanduser("~"), ".cache", "e2hip_tune.json"))
+    return os.environ.get("E2HIP_TUNE_CACHE", os.path.join(_HERE, ".tune_cache.json"))
 
 
 def _load():
