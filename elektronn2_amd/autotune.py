@@ -83,7 +83,9 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     # channel-chunk sizes: fewest barriers first, but several so that LDS limits
     # and the number of work-groups per CU can trade off
     opts = (8, 16, 24, 32, 48, 64, cinp) if fast else (4, 8, 16, 32, cinp)
-    ccs = sorted(set(c for c in opts if c <= max(cinp, 4) and c <= (64 if fast else 32)))
+    # ... plus the chunk sizes that split Cin into n EQUAL chunks (balanced split-K ranges)
+    even = tuple(-(-(-(-cin // n)) // 4) * 4 for n in range(1, 9)) if fast else ()
+    ccs = sorted(set(c for c in opts + even if 4 <= c <= max(cinp, 4) and c <= (64 if fast else 32)))
     for mt in _best_mts(mblocks, IGEMM_MTS, keep=4):
         nmt = -(-mblocks // mt)
         for nt in (1, 2, 4):

@@ -1,2 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python -m pytest tests/test_warp.py -x -q -k sampler 2>&1 | tail -12
+export E2HIP_TUNE_CACHE=$PWD/gpurun_out/tuned_v11.json
+rm -f $E2HIP_TUNE_CACHE
+for w in lite183 full185 unet_lite140; do
+timeout -k 10 400 python bench.py --no-cpu-baseline --workload $w > gpurun_out/bench_${w}_v11.json 2> gpurun_out/bench_${w}_v11.err || { tail -5 gpurun_out/bench_${w}_v11.err; exit 1; }
+cut -c1-200 gpurun_out/bench_${w}_v11.json
+done
+cp $E2HIP_TUNE_CACHE gpurun_out/tuned_v11_bench.json
