@@ -74,6 +74,13 @@ def _best_mts(mblocks, options, keep=3):
     return [s[2] for s in scored[:keep]]
 
 
+def _near_divisors(n, target):
+    """the divisors of n just below and just above target (balanced position splits)"""
+    lo = [d for d in range(1, target + 1) if n % d == 0]
+    hi = [d for d in range(target, min(n, 2 * target) + 1) if n % d == 0]
+    return ([lo[-1]] if lo else []) + ([hi[0]] if hi else [])
+
+
 def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     mblocks = -(-cout // 16)
     q = out_sp[1] * out_sp[2]
@@ -121,9 +128,11 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
             nnt = -(-nblocks // (nt * wn))
             for bp in ((128, 256) if wk in (1, 14) else (64, 128)):
                 tiles = out_sp[0] * (-(-(qpad if wk in (1, 14) else q) // bp))
-                for fill in (1, 2, 4):
-                    ps = max(1, min(tiles, (n_cu * fill) // max(1, nmt * nnt)))
-                    cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, ps))
+                for fill in (1, 1.5, 2, 3, 4):
+                    ps = max(1, min(tiles, int(n_cu * fill) // max(1, nmt * nnt)))
+                    # ... and the nearest split counts that divide the tiles evenly
+                    for q in {ps} | set(_near_divisors(tiles, ps)):
+                        cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, q))
     return sorted(set(cands))
 
 
