@@ -243,6 +243,11 @@ class Model(GraphManager):
         from ..parallel import allreduce_mean_
         allreduce_mean_(self.G, self._dp_group)
 
+    def grad_exchange(self):
+        """sliced exchange of the gradient arena (parallel.BucketedMean)"""
+        from ..parallel import BucketedMean
+        return BucketedMean(self.G, self._dp_group)
+
     # ------------------------------------------------------------------ functions
     def save(self, file_name):
         """Parameter values + optimiser state as .npz."""

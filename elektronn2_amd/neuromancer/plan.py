@@ -17,6 +17,8 @@ step over the single flat buffer (3.5 MB for neuro3d_lite, 11 MB for neuro3d).
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -65,6 +67,7 @@ class Plan(object):
         self._loss_anc = (set(id(n) for n in self.loss_node.all_parents.values())
                           if self.training else set())
         self._ng_cache = {}
+        self._dp_cut_cache = False
 
     # ---- allocation helpers ---------------------------------------------------
     def empty(self, shape):
@@ -208,13 +211,52 @@ class Plan(object):
             n._plan_fwd(self)
         self.join_side()
 
-    def _emit_backward(self):
-        self.ctx.fill(self.model.G, 0.0)
-        self._grad_written = set()
-        for n in reversed(self.nodes):
-            if id(n) in self._loss_anc and (self.needs_grad(n) or n is self.loss_node):
-                n._plan_bwd(self)
+    def _bwd_nodes(self):
+        return [n for n in reversed(self.nodes)
+                if id(n) in self._loss_anc and (self.needs_grad(n) or n is self.loss_node)]
+
+    def _emit_backward(self, part=None):
+        """part None: the whole backward pass; 0 / 1: the nodes before / after the
+        data-parallel cut (see _dp_cut)"""
+        nodes = self._bwd_nodes()
+        if part is not None:
+            k = self._dp_cut()[0]
+            nodes = nodes[:k] if part == 0 else nodes[k:]
+        if part in (None, 0):
+            self.ctx.fill(self.model.G, 0.0)
+            self._grad_written = set()
+        for n in nodes:
+            n._plan_bwd(self)
         self.join_side()
+
+    def _dp_cut(self):
+        """(k, lo) or None: after the first k nodes of the backward pass every gradient
+        in G[lo:] is final, so that slice can be exchanged while the other nodes run.
+        The arena is laid out in node order, so the late layers (most of the parameters,
+        least of the backward time) form its tail."""
+        if self._dp_cut_cache is not False:
+            return self._dp_cut_cache
+        self._dp_cut_cache = None
+        m = self.model
+        if os.environ.get('E2_DP_OVERLAP', '1') == '0' or m.n_train < (1 << 16):
+            return None
+        nodes = self._bwd_nodes()
+        last = {}                                  # id(param) -> last backward index using it
+        for i, n in enumerate(nodes):
+            for p in n.params.values():
+                if getattr(p, 'apply_train', False) and id(p) in m._slots:
+                    last[id(p)] = i
+        slots = sorted(((m._slots[q][0], q) for q in last), reverse=True)
+        for k in range(1, len(nodes) - 1):
+            lo = m.n_train
+            for off, q in slots:
+                if last[q] >= k:
+                    break
+                lo = off
+            if m.n_train - lo >= 0.75 * m.n_train:
+                self._dp_cut_cache = (k, lo)
+                break
+        return self._dp_cut_cache
 
     def _emit_update(self):
         if self.step in ('Adam', 'SGD'):
@@ -225,16 +267,21 @@ class Plan(object):
         ctx = self.ctx
         dp = self.training and self.step in ('Adam', 'SGD') and self.model.dp_world() > 1
         capture = self.use_graph and self._calls >= 1
+        cut = self._dp_cut() if dp else None
         if capture and self._graphs is None:
             graphs = []
             self._capturing = True
             ctx.graph_begin()
             self._emit_forward()
             if self.training:
-                self._emit_backward()
+                self._emit_backward(0 if cut else None)
                 if not dp:
                     self._emit_update()
             graphs.append(ctx.graph_end())
+            if cut:
+                ctx.graph_begin()
+                self._emit_backward(1)
+                graphs.append(ctx.graph_end())
             if dp:
                 ctx.graph_begin()
                 self._emit_update()
@@ -244,7 +291,27 @@ class Plan(object):
             from .. import autotune
             autotune.save()
         ctx.record(self._ev0)
-        if capture:
+        if cut:
+            # the late layers' gradients travel while the early layers' are computed
+            ex = self.model.grad_exchange()
+            n_train = self.model.G.numel()
+            if capture:
+                ctx.graph_launch(self._graphs[0])
+            else:
+                self._emit_forward()
+                self._emit_backward(0)
+            ex.start(cut[1], n_train)
+            if capture:
+                ctx.graph_launch(self._graphs[1])
+            else:
+                self._emit_backward(1)
+            ex.start(0, cut[1])
+            ex.finish()
+            if capture:
+                ctx.graph_launch(self._graphs[2])
+            else:
+                self._emit_update()
+        elif capture:
             ctx.graph_launch(self._graphs[0])
             if dp:
                 self.model.allreduce_grads()

@@ -40,6 +40,45 @@ def allreduce_mean_(flat, group=None):
     return flat
 
 
+class BucketedMean:
+    """Mean over ranks of one flat tensor, exchanged as contiguous slices that are
+    handed over as soon as they are final, so that the exchange of the gradients of the
+    late layers runs under the backward pass of the early ones.
+
+        bm = BucketedMean(G, group)
+        ... backward of the late layers ...      bm.start(lo, n)   # G[lo:n] is final
+        ... backward of the early layers ...     bm.start(0, lo)
+        bm.finish()                              # waits, then scales by 1 / world
+
+    start() enqueues an asynchronous all-reduce behind the work already queued on the
+    current stream (RCCL runs it on its own stream); finish() makes the current stream
+    wait for every slice."""
+
+    def __init__(self, flat, group=None):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._work, self._covered = [], 0
+
+    def start(self, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM,
+                                          group=self.group, async_op=True))
+        self._covered += hi - lo
+
+    def finish(self):
+        if self.world == 1:
+            return self.flat
+        for w in self._work:
+            w.wait()
+        if self._covered != self.flat.numel():
+            raise RuntimeError("BucketedMean: slices cover %d of %d elements"
+                               % (self._covered, self.flat.numel()))
+        self._work, self._covered = [], 0
+        self.flat.mul_(1.0 / self.world)
+        return self.flat
+
+
 def rank_seed(base_seed, rank=None):
     """independent data stream per rank (cnndata.py:193-204 reseeds per PID)."""
     if rank is None:

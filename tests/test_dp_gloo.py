@@ -48,7 +48,21 @@ def _worker(rank, world, port, q):
     for _ in range(3):
         net.loss_and_grads(x, t)
         flat = _flat_grads(net)
+        # the sliced exchange the launch plan uses (late layers first) gives the same mean
+        sliced = flat.clone()
+        bm = parallel.BucketedMean(sliced)
+        lo = sliced.numel() // 3 // 4 * 4
+        bm.start(lo, sliced.numel())
+        bm.start(0, lo)
+        bm.finish()
         parallel.allreduce_mean_(flat)
+        assert torch.equal(sliced, flat)
+        bm.start(lo, sliced.numel())
+        try:
+            bm.finish()
+            raise AssertionError("partial coverage must raise")
+        except RuntimeError as e:
+            assert "cover" in str(e)
         _set_flat_grads(net, flat)
         net.adam()
     q.put((rank, torch.cat([p.detach().reshape(-1) for p in net.w + net.b]).numpy()))

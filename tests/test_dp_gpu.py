@@ -1,0 +1,97 @@
+"""GPU, world_size 2 on ONE card (gloo carries the exchange -- RCCL wants one GPU per
+rank): the data-parallel training step of the launch plan.
+
+  * replicas stay bit-identical over Adam steps,
+  * the sliced exchange overlapped with the backward pass (plan._dp_cut, on by default)
+    and the single all-reduce (E2_DP_OVERLAP=0) give the same parameters,
+  * both equal the torch-CPU port of the oracle stepping on the hand-averaged gradients
+    of the two ranks' batches.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import e2_oracle as O
+from oracle import torch_step as TS
+
+pytestmark = pytest.mark.gpu
+SP = (7, 47, 47)
+STEPS = 3
+
+
+def _data(rank):
+    from elektronn2_amd import parallel
+    rng = np.random.RandomState(parallel.rank_seed(3, rank))
+    x = rng.rand(1, 1, *SP).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(O.NEURO3D_LITE, SP)).astype(np.float32)
+    return x, t
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LOCAL_RANK="0")
+    from elektronn2_amd import nets, neuromancer as nm, parallel
+    assert parallel.init_from_env("gloo") == world
+    x, t = _data(rank)
+    out = {}
+    for overlap in ("1", "0"):
+        os.environ["E2_DP_OVERLAP"] = overlap
+        nm.model_manager.reset()
+        m = nets.neuro3d_lite((None, 1) + SP, params=O.init_net(O.NEURO3D_LITE, 1, seed=5))
+        m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        m.loss(x, t)                              # builds the arena
+        m.enable_data_parallel()
+        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(STEPS)]
+        plan = m.optimisers['Adam'].step.func
+        out[overlap] = dict(P=m.P.cpu().numpy().copy(), losses=losses,
+                            cut=plan._dp_cut(), n_graphs=len(plan._graphs or []))
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_overlapped_exchange():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=500) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for mode in ("1", "0"):
+        assert np.array_equal(res[0][mode]["P"], res[1][mode]["P"]), "replicas diverged"
+    # the overlapped path really was taken: a cut, and three graphs (fwd+bwd | bwd | update)
+    k, lo = res[0]["1"]["cut"]
+    assert k >= 1 and 0 < lo < res[0]["1"]["P"].size
+    assert res[0]["1"]["n_graphs"] == 3 and res[0]["0"]["n_graphs"] == 2
+    assert res[0]["0"]["cut"] is None
+    a, b = res[0]["1"]["P"], res[0]["0"]["P"]
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+
+    # oracle: two replicas stepping on the mean of their gradients
+    torch.set_num_threads(8)
+    nets_ = [TS.TorchNet(O.NEURO3D_LITE, O.init_net(O.NEURO3D_LITE, 1, seed=5))
+             for _ in range(2)]
+    data = [tuple(torch.tensor(v) for v in _data(r)) for r in range(2)]
+    for _ in range(STEPS):
+        for n, (x, t) in zip(nets_, data):
+            n.loss_and_grads(x, t)
+        for pa, pb in zip(nets_[0].w + nets_[0].b, nets_[1].w + nets_[1].b):
+            g = (pa.grad + pb.grad) * 0.5
+            pa.grad = g.clone(); pb.grad = g.clone()
+        [n.adam() for n in nets_]
+    want = [p.detach().numpy() for p in nets_[0].w + nets_[0].b]
+    # arena layout: parameters in node order, w then b per node, 16-byte aligned slots
+    nw = len(nets_[0].w)
+    off = 0
+    for i in range(nw):
+        for ref in (want[i], want[nw + i]):
+            got = a[off:off + ref.size].reshape(ref.shape)
+            err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+            assert err < 5e-4, (i, ref.shape, err)
+            off += (ref.size + 3) // 4 * 4
