@@ -96,6 +96,7 @@ def _load():
         "e2_fill": (C.c_int, [vp, fp, sz, C.c_float]),
         "e2_softmax_nll_fwd": (C.c_int, [vp, P5, P5, P5, fp]),
         "e2_softmax_nll_bwd": (C.c_int, [vp, P5, P5, fp, P5, fp]),
+        "e2_malis_nll": (C.c_int, [vp, P5, fp, fp, fp, P5, fp]),
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_graph_begin": (C.c_int, [vp]),
@@ -408,6 +409,12 @@ class Context:
         _chk(_lib.e2_softmax_nll_bwd(self.h, C.byref(t5(probs)), C.byref(t5(target)),
                                      _fp(stats), C.byref(t5(dlogits)), _fp(loss_out)),
              "e2_softmax_nll_bwd")
+
+    def malis_nll(self, probs, pos, neg, norm, dlogits, loss_sum):
+        """MALIS NLL of a (1, 2E, z, x, y) pair-softmax; dlogits None = loss only"""
+        _chk(_lib.e2_malis_nll(self.h, C.byref(t5(probs)), _fp(pos), _fp(neg), _fp(norm),
+                               C.byref(t5(dlogits)) if dlogits is not None else None,
+                               _fp(loss_sum)), "e2_malis_nll")
 
     def adam_step(self, p, g, m, s, seg_off, seg_reg, hyper):
         _chk(_lib.e2_adam_step(self.h, _fp(p), _fp(g), _fp(m), _fp(s), p.numel(),

@@ -372,6 +372,47 @@ __global__ void softmax_nll_bwd_kernel(View5 pr, View5 tg, const float* __restri
 }
 
 // ---------------------------------------------------------------------------
+// MALIS NLL (loss.py:560-690): probs (1, 2E, d,h,w) holds E independent 2-class
+// softmaxes (channel 2e = "disconnected", 2e+1 = affinity).  With the MALIS counts
+// P (pairs this edge should connect) and N (pairs it should keep apart):
+//   loss = -sum(P log(p1+eps) + N log(p0+eps)) * norm[0],  norm[0] = 1/(n_tot+eps)
+// and, the counts being constants (malisop.py:114-120: zero gradient),
+//   dlogit_c = p_c (g_c - (p0 g0 + p1 g1)),  g1 = -P norm/(p1+eps), g0 = -N norm/(p0+eps)
+// thread per (edge, position); loss_sum accumulates the normalised loss.
+// ---------------------------------------------------------------------------
+__global__ void malis_nll_kernel(View5 pr, const float* __restrict__ pos,
+                                 const float* __restrict__ neg,
+                                 const float* __restrict__ norm, View5 dl, int want_grad,
+                                 float* __restrict__ loss_sum) {
+  __shared__ float red[4];
+  const long S = (long)pr.d * pr.h * pr.w;
+  const long s = blockIdx.x * 256L + threadIdx.x;
+  const int e = blockIdx.y;
+  const float inv = norm[0];
+  float l = 0.f;
+  if (s < S) {
+    const int x = (int)(s % pr.w);
+    const long t = s / pr.w;
+    const int y = (int)(t % pr.h), z = (int)(t / pr.h);
+    const float* pp = pr.p + vidx(pr, 0, 2 * e, z, y, x);
+    const float p0 = pp[0], p1 = pp[pr.sc];
+    const float P = pos[(long)e * S + s], N = neg[(long)e * S + s];
+    // xlogy0 (loss.py:26-28): 0 where the count is 0, whatever the logarithm
+    if (P != 0.f) l -= P * logf(p1 + E2_EPS_NLL);
+    if (N != 0.f) l -= N * logf(p0 + E2_EPS_NLL);
+    if (want_grad) {
+      const float g1 = -P * inv / (p1 + E2_EPS_NLL), g0 = -N * inv / (p0 + E2_EPS_NLL);
+      const float m = p0 * g0 + p1 * g1;
+      float* dp = dl.p + vidx(dl, 0, 2 * e, z, y, x);
+      dp[0] = p0 * (g0 - m);
+      dp[dl.sc] = p1 * (g1 - m);
+    }
+  }
+  const float a = block_sum256(l * inv, red);
+  if (threadIdx.x == 0 && a != 0.f) unsafeAtomicAdd(loss_sum, a);
+}
+
+// ---------------------------------------------------------------------------
 // optimisers on a flat arena (hyper = {lr, mom, beta2, wd, t, factor})
 // ---------------------------------------------------------------------------
 __global__ void adam_tick_kernel(float* hyper) {
@@ -668,6 +709,29 @@ extern "C" int e2_softmax_nll_bwd(e2_ctx* ctx, const e2_tensor5* probs,
   dim3 grid((unsigned)((S + 255) / 256), 1, (unsigned)p.n);
   hipLaunchKernelGGL(softmax_nll_bwd_kernel, grid, dim3(256), 0, ctx->stream, p, t, stats, d,
                      loss_out);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_malis_nll(e2_ctx* ctx, const e2_tensor5* probs, const float* pos,
+                            const float* neg, const float* norm, const e2_tensor5* dlogits,
+                            float* loss_sum) {
+  E2_REQUIRE(ctx && pos && neg && norm && loss_sum, "malis_nll: null argument");
+  if (int rc = check_view(probs, "malis_nll probs")) return rc;
+  E2_REQUIRE(probs->n == 1 && probs->c >= 2 && probs->c % 2 == 0 && probs->c <= 2 * 65535,
+             "malis_nll: probs must be (1, 2E, d, h, w)");
+  View5 p = mk(probs), d = p;
+  if (dlogits) {
+    if (int rc = check_view(dlogits, "malis_nll dlogits")) return rc;
+    E2_REQUIRE(dlogits->n == 1 && dlogits->c == probs->c && dlogits->d == probs->d &&
+                   dlogits->h == probs->h && dlogits->w == probs->w,
+               "malis_nll: dlogits/probs shape mismatch");
+    d = mk(dlogits);
+  }
+  const long S = (long)p.d * p.h * p.w;
+  dim3 grid((unsigned)((S + 255) / 256), (unsigned)(p.c / 2), 1);
+  hipLaunchKernelGGL(malis_nll_kernel, grid, dim3(256), 0, ctx->stream, p, pos, neg, norm, d,
+                     dlogits ? 1 : 0, loss_sum);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -73,7 +73,11 @@ class PatchSampler(object):
         return self.d[i], self.t[i]
 
     def getbatch(self, batch_size=1, source='train', grey_augment_channels=None, warp=False,
-                 warp_args=None, force_dense=False):
+                 warp_args=None, force_dense=False, affinities=False, nhood=None):
+        """cnndata.py:214-402.  ``affinities='malis'``: the batch is
+        ``(images, aff, seg)`` for a MalisNLL loss -- affinity graph and relabelled IDs of
+        the first target channel (cnndata.py:377-382; computed on the host, the ID
+        volumes are small); ``'affinity'``: ``(images, aff)``."""
         grey_augment_channels = grey_augment_channels or []
         warp_args = dict(warp_args or {})
         n_f, n_t = self.d[0].shape[0], self.t[0].shape[0]
@@ -106,4 +110,12 @@ class PatchSampler(object):
             count += 1
         if not (force_dense or all(s == 1 for s in self.strides)):
             target = target[:, :, ::self.strides[0], ::self.strides[1], ::self.strides[2]]
+        if affinities in ('malis', 'affinity'):
+            from .image import make_affinities
+            ids = np.rint(target[:, 0].cpu().numpy()).astype(np.int32)
+            aff, seg = make_affinities(ids, nhood)
+            aff = torch.from_numpy(aff.astype(np.float32)).to(dev)
+            if affinities == 'affinity':
+                return images, aff
+            return images, aff, torch.from_numpy(seg[:, None].astype(np.float32)).to(dev)
         return images, target

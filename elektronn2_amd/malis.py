@@ -32,8 +32,9 @@ def mknhood2d(radius=1):
 
 
 def mknhood3d(radius=1):
-    """malis_utils.py:87-109: for radius 1 the three unit steps
-    [[1,0,0],[0,1,0],[0,0,1]] (z, x, y)."""
+    """malis_utils.py:87-109: the first half (centre INCLUDED: the reference computes
+    ``ceil(len / 2)`` under true division) of the 3-d offsets within ``radius``,
+    reversed; for radius 1: [[0,0,0],[-1,0,0],[0,-1,0],[0,0,-1]] (z, x, y)."""
     r = int(np.ceil(radius))
     ax = np.arange(-r, r + 1)
     i, j, k = np.meshgrid(ax, ax, ax)

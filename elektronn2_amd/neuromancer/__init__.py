@@ -5,6 +5,7 @@ from .variables import VariableParam, VariableWeight, ConstantParam, initweights
 from .node_basic import (Node, Input, Input_like, Concat, Add, model_manager,
                          choose_name)
 from .neural import Conv, UpConv, Pool, Crop, AutoMerge, UpConvMerge
-from .loss import Softmax, MultinoulliNLL, AggregateLoss, Classification, Errors
+from .loss import (Softmax, MultinoulliNLL, MalisNLL, AggregateLoss, Classification,
+                   Errors)
 from .optimiser import Optimiser, SGD, Adam
 from .model import Model, modelload, params_from_model_file

@@ -6,8 +6,11 @@ HIP execution covers the pattern every BASELINE config uses:
 ``AggregateLoss(MultinoulliNLL(Softmax(lin-Conv), target, target_is_sparse=True))``
 which reduces to  loss = sum_labelled -log(p_target + 1e-5) / (n_labelled + 1e-5)
 (the pred.size / n_class / mean factors of loss.py:342-346,1357-1363 cancel).
-Class / example weights, masks, weakness, dense targets and n_indep > 1 are
-outside the hot path and raise NotImplementedError.
+Class / example weights, masks, weakness and dense targets are outside the hot path
+and raise NotImplementedError.  ``Softmax(n_indep > 1)`` (independent softmaxes over
+consecutive feature groups, loss.py:82-92) exists for ``MalisNLL`` (loss.py:560-690,
+SURVEY.md 8f-4): forward and gradient on the device, the MALIS counts by the host C++
+of csrc/malis.cpp between the forward and the backward segment of the step.
 """
 from __future__ import annotations
 
@@ -17,7 +20,8 @@ from .graphutils import TaggedShape, floatX
 from .node_basic import Node, Sym
 from .variables import VariableParam
 
-__all__ = ['Softmax', 'MultinoulliNLL', 'AggregateLoss', 'Classification', 'Errors']
+__all__ = ['Softmax', 'MultinoulliNLL', 'MalisNLL', 'AggregateLoss', 'Classification',
+           'Errors']
 
 EPS = 1e-5     # loss.py:30
 
@@ -38,8 +42,6 @@ class Softmax(Node):
                                  % (n_indep, n_f // n_indep, n_f))
         elif n_class * n_indep != n_f:
             raise ValueError("Cannot create %i-fold %i-class softmax " % (n_indep, n_class))
-        if n_indep != 1:
-            raise NotImplementedError("n_indep > 1 is outside the HIP hot path")
         self.n_class = n_class
         self.n_indep = n_indep
 
@@ -67,8 +69,10 @@ class Softmax(Node):
             sh[1] = 1
             t = plan.full(tuple(sh), -1.0)
             plan.scratch[self, 'dummy_t'] = t
-        plan.ctx.softmax_nll_fwd(plan.out[self.parent], t, plan.out[self],
-                                 plan.scratch[self, 'stats'])
+        lg, pr, k = plan.out[self.parent], plan.out[self], self.n_class
+        for i in range(self.n_indep):            # loss.py:82-92: one softmax per group
+            sl = slice(i * k, (i + 1) * k)
+            plan.ctx.softmax_nll_fwd(lg[:, sl], t, pr[:, sl], plan.scratch[self, 'stats'])
 
     def _head(self, plan):
         """the parent Conv when it runs as a fused classifier head (csrc/head.hip)"""
@@ -77,8 +81,8 @@ class Softmax(Node):
         return p if (f is not None and f(plan) is self) else None
 
     def _plan_bwd(self, plan):
-        if plan.scratch.get((self, 'fused_nll')):
-            return            # MultinoulliNLL wrote d(loss)/d(logits) directly
+        if plan.scratch.get((self, 'fused_nll')) or plan.scratch.get((self, 'loss_writes_dlogits')):
+            return            # the NLL node wrote d(loss)/d(logits) directly
         raise NotImplementedError("gradient through a bare Softmax node")
 
 
@@ -90,6 +94,9 @@ class MultinoulliNLL(Node):
         if not isinstance(pred, Softmax):
             raise ValueError("The prob input to a MultinoulliNLL-node must be "
                              "a Softmax-Node.")
+        if pred.n_indep != 1:
+            raise NotImplementedError("MultinoulliNLL over n_indep > 1 is outside the "
+                                      "HIP hot path")
         if (class_weights is not None or example_weights is not None or weakness or
                 mask_class_labeled is not None or mask_class_not_present is not None):
             raise NotImplementedError("class/example weights, masks and weak training "
@@ -156,6 +163,108 @@ class MultinoulliNLL(Node):
         return s[0] / (s[1] + EPS)
 
 
+class MalisNLL(Node):
+    """loss.py:560-690.  ``pred``: Softmax with ``n_indep`` = #edges and 2 classes
+    (feature 2e = "disconnected", 2e+1 = affinity of edge e), ``aff_gt`` (1, E, z, x, y)
+    and ``seg_gt`` (1, 1, z, x, y) Input nodes, ``nhood`` (E, 3).
+
+    total loss (after AggregateLoss's mean; the nll.size factors cancel, loss.py:664-670)
+        = -sum(pos * log(p_aff + EPS) + neg * log(p_dis + EPS)) / (n_pos + n_neg + EPS)
+    with the MALIS counts as constants of the gradient (malisop.py:114-120).  The counts
+    come from the host (csrc/malis.cpp, Kruskal is sequential): the step is cut after
+    the forward pass, the affinities go to the host, the counts come back, the loss
+    kernel and the backward pass follow as a second captured segment.  After each step
+    ``rand_index``, ``false_splits``, ``false_merges``, ``pos_count``, ``neg_count``
+    hold the values of the reference's inspection outputs (loss.py:672-682)."""
+
+    def __init__(self, pred, aff_gt, seg_gt, nhood, unrestrict_neg=True, class_weights=None,
+                 example_weights=None, name="nll", print_repr=True):
+        super(MalisNLL, self).__init__([pred, aff_gt, seg_gt], name, print_repr)
+        if not isinstance(pred, Softmax):
+            raise ValueError("The prob input to a MultinoulliNLL-node must be "
+                             "a Softmax-Node.")
+        if pred.shape['b'] != 1:
+            raise NotImplementedError("Malis can only be used with batch size 1.")
+        if class_weights is not None or example_weights is not None:
+            raise NotImplementedError("class / example weights are outside the HIP hot path")
+        if pred.n_class != 2:
+            raise NotImplementedError("MalisNLL needs 2-class softmaxes (one per edge)")
+        self.aff_gt = aff_gt
+        self.seg_gt = seg_gt
+        self.pred = pred
+        self.nhood = np.asarray(nhood, dtype=np.int32)
+        if self.nhood.shape != (pred.n_indep, 3):
+            raise ValueError("nhood must be (%i, 3) for this prediction" % pred.n_indep)
+        self.unrestrict_neg = unrestrict_neg
+        self.axis = pred.shape.tag2index('f')
+        self.n_class = pred.n_class
+        self.n_indep = pred.n_indep
+        self.class_weights = None
+        self.example_weights = None
+        self.rand_index = self.false_splits = self.false_merges = None
+        self.pos_count = self.neg_count = None
+
+    def _calc_shape(self):
+        self.shape = self.parent[0].shape.updateshape(self.axis, 1)
+
+    def _calc_comp_cost(self):
+        self.computational_cost = self.parent[0].shape.stripnone_prod
+
+    def _plan_alloc(self, plan):
+        plan.scratch[self.pred, 'loss_writes_dlogits'] = True
+        sh = plan.out_shape(self.pred)
+        n = self.n_indep * int(np.prod(sh[2:]))
+        plan.scratch[self, 'pos'] = plan.zeros_flat(n)
+        plan.scratch[self, 'neg'] = plan.zeros_flat(n)
+        plan.scratch[self, 'norm'] = plan.zeros_flat(4)
+        plan.scratch[self, 'loss'] = plan.zeros_flat(1)
+        plan.out[self] = None
+
+    def _plan_fwd(self, plan):
+        pass                   # everything happens after the host step
+
+    def _plan_host(self, plan):
+        """affinities -> host, MALIS counts (two Kruskal passes) -> device"""
+        import torch
+        from .. import malis
+        plan.stream.synchronize()
+        probs = plan.out[self.pred]
+        aff = probs[0, 1::2].cpu().numpy()
+        aff_gt = plan.out[self.aff_gt][0].cpu().numpy().astype(np.int16)
+        seg_gt = plan.out[self.seg_gt][0, 0].cpu().numpy().astype(np.int32)
+        pos, neg = malis.malis_weights(aff, aff_gt, seg_gt, self.nhood, self.unrestrict_neg)
+        n_pos, n_neg = float(pos.sum(dtype=np.float64)), float(neg.sum(dtype=np.float64))
+        n_tot = n_pos + n_neg
+        norm = np.array([1.0 / (n_tot + EPS), n_tot, n_pos, n_neg], np.float32)
+        plan.scratch[self, 'pos'].copy_(torch.from_numpy(pos.astype(np.float32).ravel()))
+        plan.scratch[self, 'neg'].copy_(torch.from_numpy(neg.astype(np.float32).ravel()))
+        plan.scratch[self, 'norm'].copy_(torch.from_numpy(norm))
+        self.pos_count, self.neg_count = pos, neg
+        self.false_splits = int(pos[aff < 0.5].sum(dtype=np.uint64))
+        self.false_merges = int(neg[aff > 0.5].sum(dtype=np.uint64))
+        self.rand_index = np.float32((self.false_splits + self.false_merges) / (n_tot + EPS))
+
+    def _launch(self, plan, dlogits):
+        plan.ctx.fill(plan.scratch[self, 'loss'], 0.0)
+        plan.ctx.malis_nll(plan.out[self.pred], plan.scratch[self, 'pos'],
+                           plan.scratch[self, 'neg'], plan.scratch[self, 'norm'], dlogits,
+                           plan.scratch[self, 'loss'])
+
+    def _plan_fwd_post(self, plan):
+        if not plan.training:
+            self._launch(plan, None)
+
+    def _plan_bwd(self, plan):
+        logits = self.pred.parent
+        dst, first = plan.grad_slot(logits)
+        if not first:
+            raise NotImplementedError("logits consumed by several nodes")
+        self._launch(plan, dst)          # loss and d(loss)/d(logits) in one launch
+
+    def loss_value(self, plan):
+        return plan.scratch[self, 'loss'][0]
+
+
 class AggregateLoss(Node):
     def __init__(self, parent_nodes, mixing_weights=None, name="total_loss", print_repr=True):
         if not isinstance(parent_nodes, (tuple, list)):
@@ -174,9 +283,9 @@ class AggregateLoss(Node):
             raise ValueError("Unsupported weight format")
         self.params['mixing_weights'] = mixing_weights
         self.mixing_weights = mixing_weights
-        if len(parent_nodes) != 1 or not isinstance(parent_nodes[0], MultinoulliNLL):
+        if len(parent_nodes) != 1 or not isinstance(parent_nodes[0], (MultinoulliNLL, MalisNLL)):
             raise NotImplementedError("the HIP hot path aggregates exactly one "
-                                      "MultinoulliNLL loss")
+                                      "MultinoulliNLL / MalisNLL loss")
 
     def _calc_shape(self):
         self.shape = TaggedShape([1, ], ['f', ])

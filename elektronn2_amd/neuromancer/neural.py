@@ -266,6 +266,7 @@ class Conv(NeuralLayer):
             if (type(self) is Conv and tuple(self.filter_shape) == (1, 1, 1)
                     and all(p == 1 for p in self.pool_shape) and self.activation_func == 'lin'
                     and len(kids) == 1 and type(kids[0]).__name__ == 'Softmax'
+                    and kids[0].n_indep == 1
                     and any(n is kids[0] for n in plan.nodes)
                     and not any(n is self for n in plan.outputs)
                     and plan.ctx.head_supported(self.parent.shape['f'], self.n_f)

@@ -197,6 +197,7 @@ class Plan(object):
                 jobs = [(self.param(w), wp, mode) for (w, wp, mode) in self.pack_jobs]
                 self._pack_dev = self.ctx.make_pack_jobs(jobs)
         self._graphs = None
+        self._segs = None
         self._capturing = False
         self._calls = 0
         self._grad_written = set()
@@ -262,67 +263,97 @@ class Plan(object):
         if self.step in ('Adam', 'SGD'):
             self.model.optimisers[self.step].device_update(self)
 
-    def _run_device(self):
-        """fwd (+ bwd + all-reduce + update) on self.stream, graph-replayed."""
-        ctx = self.ctx
+    def _segments(self):
+        """The step as a list of (emit, after): ``emit`` issues launches on the plan's
+        stream (each segment is captured into its own hipGraph), ``after`` is host code
+        run between two segments -- the gradient exchange of the data-parallel step, or
+        the host part of a node (MALIS: Kruskal on the CPU between forward and loss)."""
         dp = self.training and self.step in ('Adam', 'SGD') and self.model.dp_world() > 1
-        capture = self.use_graph and self._calls >= 1
-        cut = self._dp_cut() if dp else None
-        if capture and self._graphs is None:
-            graphs = []
-            self._capturing = True
-            ctx.graph_begin()
-            self._emit_forward()
-            if self.training:
-                self._emit_backward(0 if cut else None)
-                if not dp:
-                    self._emit_update()
-            graphs.append(ctx.graph_end())
-            if cut:
-                ctx.graph_begin()
-                self._emit_backward(1)
-                graphs.append(ctx.graph_end())
+        host = [n for n in self.nodes if hasattr(n, '_plan_host')]
+        upd = self.training and self.step in ('Adam', 'SGD')
+        segs = []
+        if host:
+            def host_steps():
+                for n in host:
+                    n._plan_host(self)
+
+            def rest():
+                for n in host:
+                    n._plan_fwd_post(self)
+                if self.training:
+                    self._emit_backward()
+                    if upd and not dp:
+                        self._emit_update()
+            segs.append((self._emit_forward, host_steps))
+            segs.append((rest, self.model.allreduce_grads if dp else None))
             if dp:
-                ctx.graph_begin()
-                self._emit_update()
-                graphs.append(ctx.graph_end())
-            self._capturing = False
-            self._graphs = graphs
-            from .. import autotune
-            autotune.save()
-        ctx.record(self._ev0)
+                segs.append((self._emit_update, None))
+            return segs
+        cut = self._dp_cut() if dp else None
         if cut:
             # the late layers' gradients travel while the early layers' are computed
-            ex = self.model.grad_exchange()
             n_train = self.model.G.numel()
-            if capture:
-                ctx.graph_launch(self._graphs[0])
-            else:
+
+            def seg0():
                 self._emit_forward()
                 self._emit_backward(0)
-            ex.start(cut[1], n_train)
-            if capture:
-                ctx.graph_launch(self._graphs[1])
-            else:
-                self._emit_backward(1)
-            ex.start(0, cut[1])
-            ex.finish()
-            if capture:
-                ctx.graph_launch(self._graphs[2])
-            else:
-                self._emit_update()
-        elif capture:
-            ctx.graph_launch(self._graphs[0])
-            if dp:
-                self.model.allreduce_grads()
-                ctx.graph_launch(self._graphs[1])
-        else:
+
+            def start_tail():
+                self._ex = self.model.grad_exchange()
+                self._ex.start(cut[1], n_train)
+
+            def finish():
+                self._ex.start(0, cut[1])
+                self._ex.finish()
+            return [(seg0, start_tail), (lambda: self._emit_backward(1), finish),
+                    (self._emit_update, None)]
+
+        def whole():
             self._emit_forward()
             if self.training:
                 self._emit_backward()
-                if dp:
-                    self.model.allreduce_grads()
-                self._emit_update()
+                if upd and not dp:
+                    self._emit_update()
+        segs.append((whole, self.model.allreduce_grads if dp else None))
+        if dp:
+            segs.append((self._emit_update, None))
+        return segs
+
+    def _run_device(self):
+        """fwd (+ bwd + all-reduce + update) on self.stream, graph-replayed."""
+        ctx = self.ctx
+        if self._segs is None:
+            self._segs = self._segments()
+        capture = self.use_graph and self._calls >= 1
+        if capture and self._graphs is None:
+            # the first captured call runs segment by segment: a host step between two
+            # segments needs the results of the one before it
+            graphs = []
+            ctx.record(self._ev0)
+            for emit, after in self._segs:
+                self._capturing = True
+                ctx.graph_begin()
+                emit()
+                g = ctx.graph_end()
+                self._capturing = False
+                graphs.append(g)
+                ctx.graph_launch(g)
+                if after is not None:
+                    after()
+            self._graphs = graphs
+            from .. import autotune
+            autotune.save()
+            ctx.record(self._ev1)
+            self._calls += 1
+            return
+        ctx.record(self._ev0)
+        for i, (emit, after) in enumerate(self._segs):
+            if capture:
+                ctx.graph_launch(self._graphs[i])
+            else:
+                emit()
+            if after is not None:
+                after()
         ctx.record(self._ev1)
         self._calls += 1
 

@@ -222,6 +222,16 @@ int e2_softmax_nll_bwd(e2_ctx*, const e2_tensor5* probs,
                        const e2_tensor5* target, const float* stats,
                        const e2_tensor5* dlogits, float* loss_out);
 
+/* MALIS NLL (neuromancer/loss.py:560-690 MalisNLL; malis/malisop.py:19-123): probs is
+ * (1, 2E, d, h, w) -- E independent 2-class softmaxes, channel 2e = "disconnected",
+ * 2e+1 = affinity of edge e; pos / neg: dense (E, d, h, w) float MALIS counts (from
+ * e2_malis_loss_weights, constants for the gradient); norm[0] = 1/(n_tot + 1e-5) on
+ * the device.  loss_sum[0] += -sum(pos*log(p_aff+1e-5) + neg*log(p_dis+1e-5))*norm[0]
+ * (terms with a zero count contribute 0: xlogy0, loss.py:26-28); dlogits (nullable):
+ * d(loss)/d(logits) through the pair softmax, same shape as probs. */
+int e2_malis_nll(e2_ctx*, const e2_tensor5* probs, const float* pos, const float* neg,
+                 const float* norm, const e2_tensor5* dlogits, float* loss_sum);
+
 /* ---- optimiser (optimiser.py:273-334 Adam; 135-165 SGD) on one flat
  *      parameter arena.  wd_mult[i] = weight-decay multiplier per element
  *      segment is given by seg tables: for segment s, elements

@@ -71,3 +71,47 @@ def maximin_pair_counts(seg, node1, node2, edge_weight, pos):
                     counts[e] += 1
         comp = [a if c == b else c for c in comp]
     return counts
+
+
+def edge_nodes(shape, nhood):
+    """malis_utils.py:127-166: flat (node1, node2) of every (edge, voxel); node2 = -1
+    where voxel + nhood[edge] leaves the volume"""
+    nhood = np.asarray(nhood)
+    nodes = np.arange(int(np.prod(shape))).reshape(shape)
+    n1 = np.tile(nodes, (nhood.shape[0],) + (1,) * len(shape))
+    n2 = np.full(n1.shape, -1, dtype=np.int64)
+    for e, off in enumerate(nhood):
+        src = tuple(slice(max(0, -int(o)), min(s, s - int(o))) for s, o in zip(shape, off))
+        dst = tuple(slice(max(0, int(o)), min(s, s + int(o))) for s, o in zip(shape, off))
+        n2[(e,) + src] = nodes[dst]
+    return n1.ravel(), n2.ravel()
+
+
+def malis_weights(aff_pred, aff_gt, seg_gt, nhood, unrestrict_neg=False):
+    """malis_utils.py:377-459: pos pass on min(pred, gt), neg pass on pred (unrestricted)
+    or max(pred, gt); (pos, neg) uint64 of aff_pred's shape"""
+    sh = aff_pred.shape
+    n1, n2 = edge_nodes(sh[1:], nhood)
+    pred = np.asarray(aff_pred, np.float32).ravel()
+    gt = np.asarray(aff_gt).ravel().astype(np.float32)
+    seg = np.asarray(seg_gt).ravel()
+    pos = malis_loss_weights(seg, n1, n2, np.minimum(pred, gt), 1)
+    neg = malis_loss_weights(seg, n1, n2, pred if unrestrict_neg else np.maximum(pred, gt), 0)
+    return pos.reshape(sh), neg.reshape(sh)
+
+
+def malis_nll(probs, pos, neg, eps=1e-5):
+    """loss.py:642-670 followed by AggregateLoss's mean (loss.py:1357-1363), float64:
+    probs (2E, z, x, y) pair-softmax output (2e = disconnected, 2e+1 = affinity);
+    returns (loss, dloss/dprobs).  nll.size cancels between the two nodes."""
+    p = np.asarray(probs, np.float64)
+    P, N = np.asarray(pos, np.float64), np.asarray(neg, np.float64)
+    p0, p1 = p[0::2], p[1::2]
+    n_tot = P.sum() + N.sum()
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = np.where(P != 0, P * np.log(p1 + eps), 0.0) + np.where(N != 0, N * np.log(p0 + eps), 0.0)
+    loss = -t.sum() / (n_tot + eps)
+    dp = np.zeros_like(p)
+    dp[1::2] = -P / (p1 + eps) / (n_tot + eps)
+    dp[0::2] = -N / (p0 + eps) / (n_tot + eps)
+    return loss, dp

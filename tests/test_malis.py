@@ -94,3 +94,29 @@ def test_neg_pass_restriction_and_errors():
     with pytest.raises(ValueError):
         M.malis_weights(z['aff_pred'][:, :, :3], aff_gt, seg, nhood)
     assert M.mknhood3d(1).shape == (4, 3) and M.mknhood2d(1).shape == (3, 2)
+
+
+def test_make_affinities_relabels_components():
+    """data/image.py:30-77: same-ID neighbours connected, 0 = background, the returned
+    segmentation = connected components of the affinity graph (an ID used by two
+    separate blobs becomes two IDs)"""
+    from elektronn2_amd.data import make_affinities
+    lab = np.zeros((1, 3, 6, 6), np.int32)
+    lab[0, :, :2, :] = 5
+    lab[0, :, 4:, :] = 5          # same ID, not touching the first blob
+    lab[0, :, 2:4, :3] = 9
+    aff, seg = make_affinities(lab)
+    assert aff.shape == (1, 3, 3, 6, 6) and aff.dtype == np.int16 and seg.dtype == np.int16
+    nh = np.eye(3, dtype=np.int32)
+    for e in range(3):
+        for idx in np.ndindex(3, 6, 6):
+            j = tuple(np.add(idx, nh[e]))
+            inside = all(0 <= a < s for a, s in zip(j, (3, 6, 6)))
+            want = int(inside and lab[0][idx] != 0 and lab[0][idx] == lab[0][j])
+            assert aff[0, e][idx] == want
+    assert (seg[0] == 0).sum() == (lab[0] == 0).sum() and np.all((seg[0] == 0) == (lab[0] == 0))
+    ids = set(np.unique(seg[0])) - {0}
+    assert len(ids) == 3                                   # 5 split into two components
+    for i in ids:
+        assert len(np.unique(lab[0][seg[0] == i])) == 1
+    assert seg[0, 0, 0, 0] != seg[0, 0, 5, 0]
