@@ -37,6 +37,7 @@ WORKLOADS = {
     "unet_lite140": ("unet3d_lite", (22, 140, 140), 397.8),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (--mfma bf16 only)
 # HBM-side bytes per step from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
 # --pmc WRITE_SIZE runs of this script, profiles/r01_d_pmc_traffic.csv):
 # 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
@@ -187,6 +188,10 @@ def main():
     ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "warp183"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mfma", default=os.environ.get("E2_MFMA_DTYPE", "f32"), choices=["f32", "bf16"],
+                    help="arithmetic of the conv GEMMs: f32 (default, the BASELINE metric) or "
+                         "bf16 operands with f32 sums (SURVEY.md 8f-3; a separate, looser-"
+                         "tolerance path -- never the headline number)")
     args = ap.parse_args()
 
     from elektronn2_amd import parallel, nets
@@ -206,6 +211,10 @@ def main():
     if args.workload == "warp183":
         return warp_bench(args, rank, world)
     builder, sp, gf_table = WORKLOADS[args.workload]
+    bf16 = args.mfma == "bf16"
+    if bf16:
+        import elektronn2_amd
+        elektronn2_amd.set_mfma_dtype("bf16")
     if builder == "unet3d_lite":
         spec = params = None
         gflop = gf_table
@@ -281,6 +290,7 @@ def main():
     vox_per_step = float(np.prod((1, 1) + sp)) * world
     value = vox_per_step * args.steps / dt
     achieved = gflop / (dev_ms * 1e-3) / 1e3            # TFLOP/s per GPU
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
     out = {
         "metric": "training_input_voxels_per_sec",
         "value": value,
@@ -292,20 +302,23 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16" if bf16 else "f32",
         "data": "synthetic",
-        "config": {"workload": "%s (1,1,%d,%d,%d)->(1,2,%d,%d,%d) fwd+bwd+Adam, 1 sample/GPU"
-                               % ((builder,) + tuple(sp) + tuple(osp)),
+        "config": {"workload": "%s (1,1,%d,%d,%d)->(1,2,%d,%d,%d) fwd+bwd+Adam, 1 sample/GPU%s"
+                               % ((builder,) + tuple(sp) + tuple(osp) +
+                                  ((", conv GEMM operands rounded to bf16, f32 sums, f32 tensors",)
+                                   if bf16 else ("",))),
                    "parallelism": "dp%d" % world,
                    "output_voxels_per_sec": float(np.prod(osp)) * world * args.steps / dt,
                    "hipgraph": bool(plan.use_graph), "final_loss": loss},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "traffic": PMC_TRAFFIC_BYTES.get(args.workload),
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
+                     "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None if bf16 else PMC_TRAFFIC_BYTES.get(args.workload),
                      "traffic_unit": "B/step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
                                      "profiles/r01_d_pmc_traffic.csv)",
                      "kernel": "training step (hipGraph): conv3d igemm fwd/dgrad/wgrad on "
-                               "v_mfma_f32_16x16x4_f32 + pointwise + Adam",
+                               + ("v_mfma_f32_16x16x16_bf16 / 16x16x32_bf16" if bf16 else
+                                  "v_mfma_f32_16x16x4_f32") + " + pointwise + Adam",
                      "algorithmic_gflop_per_step": gflop,
                      "device_ms_per_step": dev_ms},
     }

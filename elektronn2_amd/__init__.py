@@ -2,3 +2,9 @@
 Conv / Pool / UpConv node API.  HIP-only: importing
 ``elektronn2_amd.backend`` without ``libe2hip.so`` raises."""
 __version__ = "0.1.0"
+
+
+def set_mfma_dtype(dtype):
+    """'f32' (default) | 'bf16' -- see neuromancer.plan.set_mfma_dtype"""
+    from .neuromancer.plan import set_mfma_dtype as _set
+    _set(dtype)

@@ -154,7 +154,9 @@ def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None):
     ``fn_tune`` call instead of ``fn``.  Returns the tiling string used."""
     global _dirty
     env = "E2_IGEMM_FORCE" if kind == "igemm" else "E2_WGRAD_FORCE"
-    key = "%s|%s" % (kind, ",".join(str(int(v)) for v in sig))
+    # the bf16 operand form of a kernel has its own best tiling
+    suffix = "_bf16" if getattr(ctx, "mfma_dtype", "f32") == "bf16" else ""
+    key = "%s%s|%s" % (kind, suffix, ",".join(str(int(v)) for v in sig))
     cache = _load()
     best = cache.get(key)
     tuned_now = False

@@ -97,6 +97,8 @@ def _load():
         "e2_softmax_nll_fwd": (C.c_int, [vp, P5, P5, P5, fp]),
         "e2_softmax_nll_bwd": (C.c_int, [vp, P5, P5, fp, P5, fp]),
         "e2_malis_nll": (C.c_int, [vp, P5, fp, fp, fp, P5, fp]),
+        "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
+        "e2_get_mfma_dtype": (C.c_int, [vp]),
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_graph_begin": (C.c_int, [vp]),
@@ -409,6 +411,21 @@ class Context:
         _chk(_lib.e2_softmax_nll_bwd(self.h, C.byref(t5(probs)), C.byref(t5(target)),
                                      _fp(stats), C.byref(t5(dlogits)), _fp(loss_out)),
              "e2_softmax_nll_bwd")
+
+    def set_mfma_dtype(self, dtype):
+        """'f32' (default) or 'bf16': operand rounding of the conv GEMMs (f32 sums)"""
+        code = {'f32': 0, 'float32': 0, 'bf16': 1, 'bfloat16': 1}.get(dtype)
+        if code is None:
+            raise ValueError("mfma dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+        _chk(_lib.e2_set_mfma_dtype(self.h, code), "e2_set_mfma_dtype")
+        self._mfma = 'bf16' if code else 'f32'
+
+    @property
+    def mfma_dtype(self):
+        m = getattr(self, '_mfma', None)
+        if m is None:
+            m = self._mfma = 'bf16' if _lib.e2_get_mfma_dtype(self.h) == 1 else 'f32'
+        return m
 
     def malis_nll(self, probs, pos, neg, norm, dlogits, loss_sum):
         """MALIS NLL of a (1, 2E, z, x, y) pair-softmax; dlogits None = loss only"""

@@ -15,6 +15,19 @@ void e2_set_error(const char* fmt, ...) {
 extern "C" const char* e2_last_error(void) { return g_err; }
 extern "C" int e2_version(void) { return 1; }
 
+/* 0 = f32 operands (exact f32 MFMA, the default), 1 = operands of the conv GEMMs rounded
+ * to bf16 on their way into the matrix core, f32 accumulation */
+extern "C" int e2_set_mfma_dtype(e2_ctx* ctx, int dtype) {
+  E2_REQUIRE(ctx, "e2_set_mfma_dtype: null context");
+  E2_REQUIRE(dtype == E2_MFMA_F32 || dtype == E2_MFMA_BF16, "e2_set_mfma_dtype: unknown dtype %d", dtype);
+  E2_REQUIRE(!ctx->capturing, "e2_set_mfma_dtype: not while capturing a graph");
+  ctx->mfma_bf16 = (dtype == E2_MFMA_BF16) ? 1 : 0;
+  return 0;
+}
+extern "C" int e2_get_mfma_dtype(const e2_ctx* ctx) {
+  return (ctx && ctx->mfma_bf16) ? E2_MFMA_BF16 : E2_MFMA_F32;
+}
+
 extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   E2_REQUIRE(out, "e2_ctx_create: null out");
   int ndev = 0;
@@ -33,6 +46,7 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->capturing = false;
   c->zeros = nullptr;
   c->fork_next = 0;
+  c->mfma_bf16 = 0;
   for (int i = 0; i < 32; ++i) c->fork_ev[i] = nullptr;
   if (hipMalloc(&c->zeros, 1024) != hipSuccess || hipMemset(c->zeros, 0, 1024) != hipSuccess) {
     delete c;

@@ -14,6 +14,7 @@ struct e2_ctx {
   float* zeros;        // 1 KiB of zeros in device memory (masked-lane DMA source)
   hipEvent_t fork_ev[32];   // dependency events of e2_stream_fork / e2_stream_join
   int fork_next;
+  int mfma_bf16;       // e2_set_mfma_dtype: 1 = conv GEMMs round their operands to bf16
 };
 
 void e2_set_error(const char* fmt, ...);

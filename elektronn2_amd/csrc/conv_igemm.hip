@@ -317,9 +317,18 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   // 1x1 taps: four channel groups per pipeline step when the chunk allows it
   const int GU = (fast && p.THW == 1 && c.CC % 16 == 0) ? 4 : 1;
   if (getenv("E2_VERBOSE"))
-    fprintf(stderr, "[e2] igemm Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d CC=%d SK=%d GU=%d grid=%ld lds=%zu\n",
-            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, GU, grid, lds);
+    fprintf(stderr, "[e2] igemm%s Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d CC=%d SK=%d GU=%d grid=%ld lds=%zu\n",
+            (ctx->mfma_bf16 && fast) ? "(bf16)" : "", a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, GU, grid, lds);
   int rc;
+  p.bf16 = (ctx->mfma_bf16 && fast) ? 1 : 0;     // the generic-width kernel stays f32
+  if (p.bf16) {
+    switch (a.kw) {
+      case 1: rc = e2i_igemm_launch_k1_bf(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+      case 3: rc = e2i_igemm_launch_k3_bf(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+      case 4: rc = e2i_igemm_launch_k4_bf(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+      default: rc = e2i_igemm_launch_k5_bf(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
+    }
+  } else
   switch (a.kw) {
     case 1: rc = e2i_igemm_launch_k1(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;
     case 3: rc = e2i_igemm_launch_k3(ctx, p, c.MT, c.NT, GU, (int)grid, lds); break;

@@ -4,6 +4,6 @@
 #include "igemm_core.hpp"
 
 int e2i_igemm_launch_k1(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int GU, int grid, size_t lds) {
-  if (GU == 4) return igemm_dispatch<1, 4>(ctx, p, MT, NT, grid, lds);
-  return igemm_dispatch<1, 1>(ctx, p, MT, NT, grid, lds);
+  if (GU == 4) return igemm_dispatch<1, 4, false>(ctx, p, MT, NT, grid, lds);
+  return igemm_dispatch<1, 1, false>(ctx, p, MT, NT, grid, lds);
 }

@@ -3,5 +3,5 @@
 
 int e2i_igemm_launch_k5(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int GU, int grid, size_t lds) {
   (void)GU;
-  return igemm_dispatch<5, 1>(ctx, p, MT, NT, grid, lds);
+  return igemm_dispatch<5, 1, false>(ctx, p, MT, NT, grid, lds);
 }

@@ -435,8 +435,8 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
       for (int NT = 1; NT <= 4; NT *= 2) {
         if (16 * NT * 4 > 16 * nblocks && NT > 1) continue;
         const int nNT = e2_cdiv(nblocks, NT * 4);
-        for (int BP = 128; BP <= 256; BP *= 2) {
-          if (BP == 256 && S <= 128) continue;
+        for (int BP = ctx->mfma_bf16 ? 256 : 128; BP <= 256; BP *= 2) {   // bf16 form: BP 256 only
+          if (BP == 256 && S <= 128 && !ctx->mfma_bf16) continue;
           const size_t lds = 2 * e2i_wgrad_direct_buf_floats(a, NT, BP, 1) * 4;
           if (lds > 160 * 1024) continue;
           const int slots = ctx->num_cu;

@@ -29,6 +29,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* gbl_vp;
 
@@ -181,12 +182,55 @@ __device__ __forceinline__ void dquad_steps(const DQuad<MT, NT>& cur, DQuad<MT, 
   if constexpr (I + 1 < M) dquad_steps<MT, NT, PF, I + 1>(cur, nxt, acc, ad, nio);
 }
 
+// ---- bf16 operand form (e2_set_mfma_dtype) --------------------------
+// A quad is 16 span positions; lane (l15, qd) holds positions 4*qd + j, j = 0..3, of its
+// dy row and of its input column -- exactly the k = 4*qd + j layout of
+// v_mfma_f32_16x16x16_bf16.  Operands are rounded to bf16 (round to nearest even) on
+// the way into the matrix core, sums stay f32: ONE MFMA per (row block, column block)
+// and quad instead of four.  The MFMA phase is then far shorter than a round trip to
+// L2, so all loads of the next quad are issued first.
+// (plain conversions -> v_cvt_pk_bf16_f32; not inline asm, so that the compiler places the
+// wait states between the VALU write and the MFMA that reads it)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 d_pack_bf16(float a, float b, float c, float d) {
+  union { bf16x4 h; s16x4 v; } r;
+  r.h = (bf16x4){(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};   // two v_cvt_pk_bf16_f32
+  return r.v;
+}
+template <int MT, int NT, bool PF>
+__device__ __forceinline__ void dquad_steps_bf(const DQuad<MT, NT>& cur, DQuad<MT, NT>& nxt,
+                                               f32x4 (&acc)[MT][NT], const DAddr<MT, NT>& ad,
+                                               const i32x4& nio) {
+  if constexpr (PF) dquad_reads<MT, NT, 0, MT + 1 + 4 * NT>(nxt, ad, nio);
+  __builtin_amdgcn_sched_barrier(0);
+  s16x4 bb[NT];
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb)
+    bb[nb] = d_pack_bf16(cur.b[0][nb], cur.b[1][nb], cur.b[2][nb], cur.b[3][nb]);
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) {
+    const s16x4 aa = d_pack_bf16(cur.a[mb][0], cur.a[mb][1], cur.a[mb][2], cur.a[mb][3]);
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb)
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aa, bb[nb], acc[mb][nb], 0, 0, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int MT, int NT, bool PF, bool BF>
+__device__ __forceinline__ void dquad_go(const DQuad<MT, NT>& cur, DQuad<MT, NT>& nxt,
+                                         f32x4 (&acc)[MT][NT], const DAddr<MT, NT>& ad,
+                                         const i32x4& nio) {
+  if constexpr (BF) dquad_steps_bf<MT, NT, PF>(cur, nxt, acc, ad, nio);
+  else dquad_steps<MT, NT, PF, 0>(cur, nxt, acc, ad, nio);
+}
+
 // WK = 4: the four compute waves share ONE 16*NT-wide n-tile and split the quads of
 // every position tile among them (wave w takes quads w, w+4, ...): for small or
 // awkward Cin*T (L1: 540) this keeps NT large -- enough MFMAs per pipeline step to
 // hide the operand loads -- without padding N up to 64*NT; the staged spans serve all
 // four waves.  Each wave flushes its own partial sums (4x the atomics of a small dw).
-template <int MT, int NT, int BP, int WK>
+template <int MT, int NT, int BP, int WK, bool BF>
 __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = 16 * MT;
@@ -359,20 +403,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     for (; q + 2 < nQ; q += 2) {
       E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
-      dquad_steps<MT, NT, true, 0>(g0, g1, acc, ad, g0.io);   // compute q, fetch q+1
+      dquad_go<MT, NT, true, BF>(g0, g1, acc, ad, g0.io);   // compute q, fetch q+1
       E2_WAIT()
       g1.touch();
       E2_MASK(g1, q + 1)
       E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
-      dquad_steps<MT, NT, true, 0>(g1, g0, acc, ad, g1.io);   // compute q+1, fetch q+2
+      dquad_go<MT, NT, true, BF>(g1, g0, acc, ad, g1.io);   // compute q+1, fetch q+2
       E2_WAIT()
       g0.touch();
       E2_MASK(g0, q + 2)
     }
     E2_ADV()
     __builtin_amdgcn_sched_barrier(0);
-    dquad_steps<MT, NT, true, 0>(g0, g1, acc, ad, g0.io);     // quad nQ-2, fetch the last one
+    dquad_go<MT, NT, true, BF>(g0, g1, acc, ad, g0.io);     // quad nQ-2, fetch the last one
     E2_WAIT()
     g1.touch();
     E2_MASK(g1, q + 1)
@@ -389,12 +433,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" : "+v"(io0));
       ad.addrT += 64u * WK;
-      dquad_steps<MT, NT, true, 0>(g1, g0, acc, ad, io0);
+      dquad_go<MT, NT, true, BF>(g1, g0, acc, ad, io0);
       E2_WAIT()
       g0.touch();
       E2_MASK(g0, 0)
     } else {
-      dquad_steps<MT, NT, false, 0>(g1, g0, acc, ad, g1.io);
+      dquad_go<MT, NT, false, BF>(g1, g0, acc, ad, g1.io);
     }
   }
 #undef E2_ADV
@@ -441,19 +485,30 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   }
 }
 
-template <int MT, int NT, int BP, int WK>
-static int launch_d(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
+template <int MT, int NT, int BP, int WK, bool BF>
+static int launch_d2(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_direct_kernel<MT, NT, BP, WK>),
+        reinterpret_cast<const void*>(&wgrad_direct_kernel<MT, NT, BP, WK, BF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_direct_kernel<MT, NT, BP, WK>), dim3(grid), dim3(512), lds, ctx->stream, p);
+  hipLaunchKernelGGL((wgrad_direct_kernel<MT, NT, BP, WK, BF>), dim3(grid), dim3(512), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// the bf16 form exists for the larger position tile only (BP = 256)
+template <int MT, int NT, int BP, int WK>
+static int launch_d(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
+  if (ctx->mfma_bf16) {
+    if constexpr (BP == 256) return launch_d2<MT, NT, BP, WK, true>(ctx, p, grid, lds);
+    e2_set_error("wgrad(direct, bf16): BP must be 256");
+    return 2;
+  }
+  return launch_d2<MT, NT, BP, WK, false>(ctx, p, grid, lds);
 }
 
 template <int MT>
@@ -542,8 +597,8 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   if (!a.accumulate)
     if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.NTOT, 0.f)) return rc;
   if (getenv("E2_VERBOSE"))
-    fprintf(stderr, "[e2] wgrad(direct) Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d BP=%d WK=%d PS=%d grid=%ld lds=%zu\n",
-            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, MT, NT, BP, WK, p.nPS, grid, lds);
+    fprintf(stderr, "[e2] wgrad(direct%s) Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d BP=%d WK=%d PS=%d grid=%ld lds=%zu\n",
+            ctx->mfma_bf16 ? ", bf16" : "", a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, MT, NT, BP, WK, p.nPS, grid, lds);
   int rc = 2;
   switch (MT) {
     case 1: rc = dispatch_d2<1>(ctx, p, NT, BP, WK, (int)grid, lds); break;

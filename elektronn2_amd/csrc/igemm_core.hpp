@@ -6,6 +6,8 @@
 #include <utility>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* gbl_vp;
 
@@ -27,6 +29,7 @@ struct IgemmP {
   unsigned long long* stamps;   // debug (E2_IGEMM_STAMPS): 8 s_memtime stamps per work-group
   const float* bias;      // fused bias (+ act) in the wide epilogue, or nullptr
   int act;
+  int bf16;               // 1: operands rounded to bf16 for the matrix core (f32 sums)
   int wide;               // 1: epilogue transposes the tile through LDS and stores 16 B per lane
                           //    (dense output rows, no split-K, no UpConv scatter)
 };
@@ -137,6 +140,93 @@ __device__ __forceinline__ void group_mfma(const GRegs<MT, NT, TPG>& cur, f32x4 
   if constexpr (I + 1 < TPG * MT * NT) group_mfma<MT, NT, TPG, I + 1>(cur, acc);
 }
 
+// ---- bf16 operand form (IgemmP::bf16) ---------------------------------
+// Operands are rounded to bf16 (v_cvt_pk_bf16_f32, round to nearest even) on their way
+// into the matrix core, sums stay f32.  Lane (l15, qd) of a group holds, for tap j of
+// the group, the element of channel 4*cg + qd: with k = 4*qd + j (16x16x16, <= 4 taps)
+// or k = 8*qd + j (16x16x32, <= 8 taps) ONE bf16 MFMA per (weight block, position
+// block) covers what the f32 form spends TPG MFMAs on; unused k slots carry zeros.
+// (a plain conversion, not inline asm: the compiler must see the VALU write to place the
+// wait states an MFMA needs before it reads the register -- an asm cvt fed stale data)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  union { bf16x2 v; unsigned u; } r;
+  r.v = (bf16x2){(__bf16)lo, (__bf16)hi};                    // one v_cvt_pk_bf16_f32
+  return r.u;
+}
+template <int W>
+__device__ __forceinline__ f32x4 bf_mfma(const unsigned (&a)[W], const unsigned (&b)[W], f32x4 c) {
+  if constexpr (W == 2) {
+    union { unsigned u[2]; s16x4 v; } A, B;
+    A.u[0] = a[0]; A.u[1] = a[1]; B.u[0] = b[0]; B.u[1] = b[1];
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A.v, B.v, c, 0, 0, 0);
+  } else {
+    union { unsigned u[4]; bf16x8 v; } A, B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { A.u[i] = a[i]; B.u[i] = b[i]; }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(A.v, B.v, c, 0, 0, 0);
+  }
+}
+// all MFMAs of one group, bf16 form.  Every register index is a template constant, as
+// in the f32 form: an operand array indexed by a loop variable is kept in scratch memory
+// by the compiler, i.e. copied while the asm loads that fill it are still in flight.
+template <int TPG, int H, int IDX, int N>
+__device__ __forceinline__ unsigned bf_pair(const float (&arr)[TPG][N]) {
+  if constexpr (2 * H >= TPG) return 0u;
+  else if constexpr (2 * H + 1 < TPG) return cvt_pk_bf16(arr[2 * H][IDX], arr[2 * H + 1][IDX]);
+  else return cvt_pk_bf16(arr[2 * H][IDX], 0.f);
+}
+template <int TPG, int IDX, int N, int W>
+__device__ __forceinline__ void bf_frag(const float (&arr)[TPG][N], unsigned (&f)[W]) {
+  f[0] = bf_pair<TPG, 0, IDX, N>(arr);
+  f[1] = bf_pair<TPG, 1, IDX, N>(arr);
+  if constexpr (W == 4) {
+    f[2] = bf_pair<TPG, 2, IDX, N>(arr);
+    f[3] = bf_pair<TPG, 3, IDX, N>(arr);
+  }
+}
+template <int MT, int NT, int TPG, int W, int NB>
+__device__ __forceinline__ void bf_pack_b(const GRegs<MT, NT, TPG>& cur, unsigned (&bu)[NT][W]) {
+  bf_frag<TPG, NB, NT, W>(cur.b, bu[NB]);
+  if constexpr (NB + 1 < NT) bf_pack_b<MT, NT, TPG, W, NB + 1>(cur, bu);
+}
+template <int MT, int NT, int W, int MB, int NB>
+__device__ __forceinline__ void bf_row(const unsigned (&au)[W], const unsigned (&bu)[NT][W],
+                                       f32x4 (&acc)[MT][NT]) {
+  acc[MB][NB] = bf_mfma<W>(au, bu[NB], acc[MB][NB]);
+  if constexpr (NB + 1 < NT) bf_row<MT, NT, W, MB, NB + 1>(au, bu, acc);
+}
+template <int MT, int NT, int TPG, int W, int MB>
+__device__ __forceinline__ void bf_rows(const GRegs<MT, NT, TPG>& cur, const unsigned (&bu)[NT][W],
+                                        f32x4 (&acc)[MT][NT]) {
+  unsigned au[W];
+  bf_frag<TPG, MB, MT, W>(cur.a, au);
+  bf_row<MT, NT, W, MB, 0>(au, bu, acc);
+  if constexpr (MB + 1 < MT) bf_rows<MT, NT, TPG, W, MB + 1>(cur, bu, acc);
+}
+template <int MT, int NT, int TPG>
+__device__ __forceinline__ void group_mfma_bf(const GRegs<MT, NT, TPG>& cur, f32x4 (&acc)[MT][NT]) {
+  static_assert(TPG <= 8, "a group holds at most 8 taps");
+  constexpr int W = TPG <= 4 ? 2 : 4;        // dwords per fragment
+  unsigned bu[NT][W];
+  bf_pack_b<MT, NT, TPG, W, 0>(cur, bu);
+  bf_rows<MT, NT, TPG, W, 0>(cur, bu, acc);
+}
+// One group step, bf16 form: the MFMA phase is a few hundred cycles, far less than an
+// L2 round trip, so ALL reads of the next group are issued first and the arithmetic
+// runs underneath them.
+template <int MT, int NT, int KW, int GU>
+__device__ __forceinline__ void group_steps_bf(const GRegs<MT, NT, KW * GU>& cur,
+                                               GRegs<MT, NT, KW * GU>& nxt, f32x4 (&acc)[MT][NT],
+                                               const GAddr<NT, KW, GU>& ad) {
+  constexpr int TPG = KW * GU;
+  group_reads<MT, NT, KW, GU, 0, TPG * (MT + NT)>(nxt, ad);
+  __builtin_amdgcn_sched_barrier(0);
+  group_mfma_bf<MT, NT, TPG>(cur, acc);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---------------------------------------------------------------------------
 // The kernel.  Eight waves: 0-3 compute (side by side along the positions),
 // 4-7 are PRODUCERS that only issue the LDS-DMA of the next chunk's input spans
@@ -150,7 +240,7 @@ __device__ __forceinline__ void group_mfma(const GRegs<MT, NT, TPG>& cur, f32x4 
 // Group g+1's operands are fetched while group g computes; the first group of a
 // chunk is fetched in the open (its weights before the chunk's barrier), which
 // costs ~1k cycles per chunk -- chunks are made as large as LDS allows.
-template <int MT, int NT, int KW, int GU>
+template <int MT, int NT, int KW, int GU, bool BF>
 __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = 16 * MT, BN = 64 * NT;
@@ -298,16 +388,21 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
     for (; g + 1 < nG; g += 2) {
       E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
-      group_steps<MT, NT, KW, GU, 0>(g0, g1, acc, ad);   // compute g, fetch g+1
+      if constexpr (BF) group_steps_bf<MT, NT, KW, GU>(g0, g1, acc, ad);
+      else group_steps<MT, NT, KW, GU, 0>(g0, g1, acc, ad);   // compute g, fetch g+1
       E2_WAIT()
       g1.touch();
       E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
-      group_steps<MT, NT, KW, GU, 0>(g1, g0, acc, ad);   // past the end: slack rows
+      if constexpr (BF) group_steps_bf<MT, NT, KW, GU>(g1, g0, acc, ad);
+      else group_steps<MT, NT, KW, GU, 0>(g1, g0, acc, ad);   // past the end: slack rows
       E2_WAIT()
       g0.touch();
     }
-    if (g < nG) group_mfma<MT, NT, TPG, 0>(g0, acc);
+    if (g < nG) {
+      if constexpr (BF) group_mfma_bf<MT, NT, TPG>(g0, acc);
+      else group_mfma<MT, NT, TPG, 0>(g0, acc);
+    }
   }
 #undef E2_WAIT
 #undef E2_ADV
@@ -409,34 +504,34 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
 }
 
 // ---- launch helpers ----------------------------------------------------------
-template <int MT, int NT, int KW, int GU>
+template <int MT, int NT, int KW, int GU, bool BF>
 static int igemm_launch(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<MT, NT, KW, GU>),
+        reinterpret_cast<const void*>(&igemm_kernel<MT, NT, KW, GU, BF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((igemm_kernel<MT, NT, KW, GU>), dim3(grid), dim3(512), lds, ctx->stream, p);
+  hipLaunchKernelGGL((igemm_kernel<MT, NT, KW, GU, BF>), dim3(grid), dim3(512), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 // all (MT, NT) instances of one kernel width
-template <int KW, int GU>
+template <int KW, int GU, bool BF>
 static int igemm_dispatch(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int grid, size_t lds) {
 #define E2_CASE(M)                                                              \
   case M:                                                                       \
-    if (NT == 1) return igemm_launch<M, 1, KW, GU>(ctx, p, grid, lds);          \
-    if (NT == 2) return igemm_launch<M, 2, KW, GU>(ctx, p, grid, lds);          \
+    if (NT == 1) return igemm_launch<M, 1, KW, GU, BF>(ctx, p, grid, lds);          \
+    if (NT == 2) return igemm_launch<M, 2, KW, GU, BF>(ctx, p, grid, lds);          \
     break;
 #define E2_CASE4(M)                                                             \
   case M:                                                                       \
-    if (NT == 1) return igemm_launch<M, 1, KW, GU>(ctx, p, grid, lds);          \
-    if (NT == 2) return igemm_launch<M, 2, KW, GU>(ctx, p, grid, lds);          \
-    if (NT == 4) return igemm_launch<M, 4, KW, GU>(ctx, p, grid, lds);          \
+    if (NT == 1) return igemm_launch<M, 1, KW, GU, BF>(ctx, p, grid, lds);          \
+    if (NT == 2) return igemm_launch<M, 2, KW, GU, BF>(ctx, p, grid, lds);          \
+    if (NT == 4) return igemm_launch<M, 4, KW, GU, BF>(ctx, p, grid, lds);          \
     break;
   switch (MT) {
     E2_CASE4(1) E2_CASE4(2) E2_CASE4(3) E2_CASE4(4) E2_CASE4(5) E2_CASE(6)
@@ -453,4 +548,8 @@ int e2i_igemm_launch_k1(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid
 int e2i_igemm_launch_k3(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
 int e2i_igemm_launch_k4(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
 int e2i_igemm_launch_k5(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k1_bf(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k3_bf(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k4_bf(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
+int e2i_igemm_launch_k5_bf(e2_ctx*, const IgemmP&, int MT, int NT, int GU, int grid, size_t lds);
 int e2i_igemm_launch_generic(e2_ctx*, const IgemmP&, int MT, int NT, int grid, size_t lds);

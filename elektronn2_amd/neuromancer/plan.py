@@ -36,7 +36,18 @@ def get_ctx():
         if torch.cuda.is_available() and dev >= torch.cuda.device_count():
             dev = 0
         _ctx = backend.Context(dev)
+        if os.environ.get("E2_MFMA_DTYPE", "f32") not in ("f32", "float32"):
+            _ctx.set_mfma_dtype(os.environ["E2_MFMA_DTYPE"])
     return _ctx
+
+
+def set_mfma_dtype(dtype):
+    """'f32' (default; exact f32 MFMA) or 'bf16': the convolution GEMMs round their
+    operands to bf16 on the way into the matrix core and accumulate in f32 (SURVEY.md
+    8f-3; the reference has no counterpart -- Theano computes in float32).  Process-wide;
+    plans captured earlier keep the arithmetic they were captured with, so set it before
+    the first call of a model.  Also: environment ``E2_MFMA_DTYPE=bf16``."""
+    get_ctx().set_mfma_dtype(dtype)
 
 
 class Plan(object):

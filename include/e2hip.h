@@ -43,6 +43,7 @@ typedef struct e2_tensor5 {
 } e2_tensor5;
 
 enum { E2_ACT_LIN = 0, E2_ACT_RELU = 1 };
+enum { E2_MFMA_F32 = 0, E2_MFMA_BF16 = 1 };
 
 /* ---- context / stream / errors --------------------------------------- */
 int  e2_ctx_create(int device, e2_ctx** out);
@@ -51,6 +52,15 @@ int  e2_ctx_destroy(e2_ctx* ctx);
 int  e2_ctx_set_stream(e2_ctx* ctx, void* stream);
 const char* e2_last_error(void);
 int  e2_version(void);
+/* Arithmetic of the convolution GEMMs (no reference counterpart: Theano computes in
+ * float32 throughout).  E2_MFMA_F32 (default): f32 operands, exact f32
+ * products and sums.  E2_MFMA_BF16: the operands of the packed-weight forward / data-
+ * gradient kernels (tap rows of 1, 3, 4 or 5) and of e2_conv3d_wgrad_pad are rounded
+ * to bf16 (nearest even) on their way into the matrix core; products and sums stay f32;
+ * tensors in memory stay f32.  The first-layer, head, generic-width and unpadded-wgrad
+ * kernels always compute in f32.  Not to be changed while a graph is being captured. */
+int  e2_set_mfma_dtype(e2_ctx* ctx, int dtype);
+int  e2_get_mfma_dtype(const e2_ctx* ctx);
 
 /* ---- conv  (computations.py:364-428 conv(), 3-D branch; F1: true
  *      convolution, kernel flipped in every spatial dim, 'valid') --------- */

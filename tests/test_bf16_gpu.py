@@ -1,0 +1,166 @@
+"""bf16 operand form of the conv GEMMs (e2_set_mfma_dtype): operands
+rounded to bf16 (nearest even) on their way into the matrix core, f32 accumulation,
+tensors in memory stay f32.
+
+The checker is the f64 oracle fed with operands that were rounded to bf16 beforehand:
+against it the kernels are held to the same 2e-5 as the f32 path (only the summation
+order differs).  Against the unrounded oracle the error must be of bf16 size -- above
+1e-4 (the bf16 form really ran) and below 2e-2.  Separate, looser end-to-end tolerance
+for a training step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import e2_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def bf16_round(a):
+    return torch.tensor(np.asarray(a, np.float32)).bfloat16().float().numpy()
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a, np.float32), device="cuda")
+
+
+def relerr(got, ref):
+    got = got.detach().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.fixture()
+def bctx(ctx):
+    ctx.set_mfma_dtype('bf16')
+    assert ctx.mfma_dtype == 'bf16'
+    yield ctx
+    ctx.set_mfma_dtype('f32')
+
+
+CASES = [
+    # Cin, Cout, k, in spatial, igemm force, wgrad force
+    (20, 40, (3, 3, 3), (5, 14, 19), None, None),
+    (40, 150, (2, 4, 4), (3, 12, 13), None, None),
+    (150, 200, (1, 3, 3), (2, 11, 12), "7,2,32,1", "7,2,1,256,4"),
+    (200, 200, (1, 1, 1), (2, 9, 10), "13,1,16,1", None),          # GU = 4
+    (200, 200, (1, 1, 1), (2, 9, 10), "7,2,8,2", "4,1,1,256,2"),   # GU = 1, split-K
+    (20, 30, (1, 5, 5), (2, 17, 18), None, "2,2,14,256,3"),        # 16x16x32 form, waves split quads
+    (30, 40, (1, 5, 5), (1, 47, 47), "3,4,16,1", None),
+    (24, 200, (3, 2, 3), (5, 13, 37), "4,4,24,1", "5,4,1,256,6"),
+    (6, 17, (1, 1, 3), (1, 1, 70), None, None),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%d-%d_k%s_%s_%s" % (
+    c[0], c[1], "x".join(map(str, c[2])), c[4], c[5]))
+def test_fwd_dgrad_wgrad_bf16(bctx, case):
+    Ci, Co, k, sp, fi, fw = case
+    rng = np.random.RandomState(abs(hash(case[:4])) % (2 ** 31))
+    x = rng.rand(1, Ci, *sp).astype(np.float32)
+    w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k))).astype(np.float32)
+    xb, wb = bf16_round(x), bf16_round(w)
+    y_ref, y_f32 = O.conv3d_fwd(xb, wb), O.conv3d_fwd(x, w)
+    xd, wd = dev(x), dev(w)
+    ws = torch.empty(bctx.conv_ws_bytes(Co, Ci, k) // 4 + 64, device="cuda")
+    env = {}
+    if fi:
+        env["E2_IGEMM_FORCE"] = fi
+    os.environ.update(env)
+    try:
+        bctx.conv3d_pack(wd, 0, ws)
+        y = torch.full(y_ref.shape, float("nan"), device="cuda")
+        bctx.conv3d_fwd_packed(xd, ws, Co, k, y)
+        e_b, e_f = relerr(y, y_ref), relerr(y, y_f32)
+        assert e_b < TOL, e_b
+        assert 1e-4 < e_f < 2e-2, e_f
+
+        dy = rng.randn(*y_ref.shape).astype(np.float32)
+        osp = y_ref.shape[2:]
+        pshape = (1, Co) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+        flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
+        dyp = flat[:int(np.prod(pshape))].view(pshape)
+        inner = dyp[:, :, k[0] - 1:k[0] - 1 + osp[0], k[1] - 1:k[1] - 1 + osp[1],
+                    k[2] - 1:k[2] - 1 + osp[2]]
+        inner.copy_(dev(dy))
+        bctx.conv3d_pack(wd, 1, ws)
+        dx = torch.full(x.shape, float("nan"), device="cuda")
+        bctx.conv3d_dgrad_packed(dyp, ws, Ci, k, dx)
+        dyb = bf16_round(dy)
+        assert relerr(dx, O.conv3d_dgrad(dyb, wb, x.shape)) < TOL
+        assert 1e-4 < relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < 2e-2
+    finally:
+        for key in env:
+            del os.environ[key]
+    if fw:
+        os.environ["E2_WGRAD_FORCE"] = fw
+    try:
+        dw = torch.full(w.shape, float("nan"), device="cuda")
+        bctx.conv3d_wgrad_pad(xd, dyp, dw)
+    finally:
+        os.environ.pop("E2_WGRAD_FORCE", None)
+    if Ci * int(np.prod(k)) <= 32:
+        # fewer than three 16-column blocks of (Cin x taps): the LDS-staged kernel runs,
+        # which always computes in f32 (include/e2hip.h, e2_set_mfma_dtype)
+        assert relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < TOL
+        return
+    assert relerr(dw, O.conv3d_wgrad(dyb, xb, w.shape)) < TOL
+    assert 1e-4 < relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < 2e-2
+
+
+def test_fused_bias_act_epilogue_bf16(bctx):
+    rng = np.random.RandomState(3)
+    x = rng.rand(1, 12, 3, 12, 22).astype(np.float32)
+    w = (rng.randn(37, 12, 1, 3, 3) / 6).astype(np.float32)
+    b = (rng.randn(37) / 4).astype(np.float32)
+    ref, _ = O.conv_node_fwd(bf16_round(x), bf16_round(w), b, (1, 1, 1), 'relu')
+    ws = torch.empty(bctx.conv_ws_bytes(37, 12, (1, 3, 3)) // 4 + 64, device="cuda")
+    bctx.conv3d_pack(dev(w), 0, ws)
+    y = torch.full(ref.shape, float("nan"), device="cuda")
+    bctx.conv3d_fwd_packed_act(dev(x), ws, 37, (1, 3, 3), dev(b), 'relu', y)
+    assert relerr(y, ref) < TOL
+
+
+@pytest.fixture()
+def process_bf16():
+    """the launch plans run on the process-wide context"""
+    import elektronn2_amd
+    elektronn2_amd.set_mfma_dtype('bf16')
+    yield
+    elektronn2_amd.set_mfma_dtype('f32')
+
+
+def test_training_step_bf16_close_to_f32_oracle(process_bf16):
+    """neuro3d_lite, one step of gradients in bf16 arithmetic against the f64 oracle of
+    the f32 net: loss within 1e-2, every gradient tensor within 1e-1 of its max (bf16
+    keeps 8 bits; the first layer's gradient has passed seven rounded layers twice) and
+    pointing the same way (cosine > 0.995); then Adam steps stay finite and learn."""
+    from elektronn2_amd import nets, neuromancer as nm
+    nm.model_manager.reset()
+    spec, sp = O.NEURO3D_LITE, (7, 47, 47)
+    params = O.init_net(spec, 1, seed=1)
+    rng = np.random.RandomState(0)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    m = nets.neuro3d_lite((None, 1) + sp, params=params)
+    m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    loss_ref, grads_ref, _ = O.net_loss_and_grads(spec, params, x, t)
+    loss = float(m.loss(x, t))
+    assert abs(loss - loss_ref) < 1e-2 * abs(loss_ref)
+    assert abs(loss - loss_ref) > 1e-7 * abs(loss_ref)        # not the f32 path
+    got = m.gradients(x, t)
+    flat_ref = []
+    for gw, gb in grads_ref:
+        flat_ref += [gw, gb]
+    for g in got:
+        cands = [r for r in flat_ref if r.shape == g.shape]
+        best = min(cands, key=lambda r: np.abs(g - r).max())
+        assert np.abs(g - best).max() < 1e-1 * np.abs(best).max()
+        cos = float((g * best).sum() / np.sqrt((g * g).sum() * (best * best).sum() + 1e-30))
+        assert cos > 0.995, cos
+    losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(30)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
