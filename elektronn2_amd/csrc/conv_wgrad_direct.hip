@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BM = 16 * MT;
   constexpr int BNn = 16 * NT * (4 / WK);
-  constexpr int TBF = BP + 64;           // + the offsets fetched past the end of a tile
+  constexpr int TBF = BP + 256;          // + the offsets fetched past the end of a tile (zeros)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -310,7 +310,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     // the quad pipeline reads one quad of offsets past the table: keep them in range
     if (pw < 2) {
       int* t = reinterpret_cast<int*>(smem + pw * p.bufFloats);
-      t[BP + lane] = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[BP + 64 * i + lane] = 0;
     }
     if (tb < te) stage(tb, 0);
     for (int tt = tb; tt < te; ++tt) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  DQuad<MT, NT> g0, g1;
+  DQuad<MT, NT> g0, g1, g2;      // g2: third set of the bf16 form's rotation
 #define E2_WAIT()                                                        \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            \
   __builtin_amdgcn_sched_barrier(0);
@@ -379,6 +380,70 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
 #define E2_MASK(G, j)                                                    \
   { const int qi_ = wk + WK * (j);                                       \
     if (16 * (qi_ + 1) > len) G.mask(len - 16 * qi_ - 1 - 4 * qd); }
+  if constexpr (BF) {
+    // bf16 form: a quad's arithmetic (MT*NT short MFMAs) is far shorter than a round trip
+    // to L2, so TWO quads are kept in flight -- three register sets in rotation; the
+    // offsets a quad's gathers need are fetched two quads ahead (with quad q: those of
+    // q+2).  Every tile starts from an empty pipeline (one barrier per tile, as the
+    // producers expect); the quads per wave are padded to 3m+2 with masked quads, whose
+    // offsets come from the zeroed slack of the table.
+    constexpr int NA = MT;                             // dy loads per quad
+    if (st) st[2] = __builtin_amdgcn_s_memtime();
+    for (int tt = tb; tt < te; ++tt) {
+      tile_geom(tt);
+      {
+        const int nQreal = (len + 15) >> 4;
+        const int per = (nQreal + WK - 1) / WK;
+        nQ = per <= 2 ? 2 : 3 * ((per - 2 + 2) / 3) + 2;
+      }
+      __syncthreads();                                 // tile tt landed; the other buffer is free
+      const float* bufp = smem + ((tt - tb) & 1) * p.bufFloats;
+      ad.xbase = d_lds_addr(bufp + TBF);
+      ad.addrT = d_lds_addr(bufp + 4 * qd) + 64u * (unsigned)wk;
+      i32x4 io0 = d_lds_ld128(ad.addrT);
+      i32x4 io1 = d_lds_ld128(ad.addrT + 64u * WK);
+      ad.addrT += 128u * WK;                           // offsets of quad 2
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" : "+v"(io0));
+      asm volatile("" : "+v"(io1));
+#define E2_ISSUE(G, IO)                                                  \
+      ad.abase = tbase + min(aoff, amax);                                \
+      __builtin_amdgcn_sched_barrier(0);                                 \
+      dquad_reads<MT, NT, 0, MT + 1 + 4 * NT>(G, ad, IO);                \
+      __builtin_amdgcn_sched_barrier(0);                                 \
+      aoff += 16 * WK; ad.addrT += 64u * WK;
+#define E2_WAITN()                                                       \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NA) : "memory"); \
+      __builtin_amdgcn_sched_barrier(0);
+#define E2_BF_STEP(CUR, NXT, TGT, J)                                     \
+      E2_ISSUE(TGT, CUR.io)                                              \
+      dquad_steps_bf<MT, NT, false>(CUR, TGT, acc, ad, CUR.io);          \
+      E2_WAITN()                                                         \
+      NXT.touch();                                                       \
+      E2_MASK(NXT, (J) + 1)
+      E2_ISSUE(g0, io0)
+      E2_ISSUE(g1, io1)
+      E2_WAITN()
+      g0.touch();
+      E2_MASK(g0, 0)
+      int q = 0;
+      for (; q + 2 < nQ; q += 3) {
+        E2_BF_STEP(g0, g1, g2, q)
+        E2_BF_STEP(g1, g2, g0, q + 1)
+        E2_BF_STEP(g2, g0, g1, q + 2)
+      }
+      // quads nQ-2 (g0, ready) and nQ-1 (g1, in flight)
+      dquad_steps_bf<MT, NT, false>(g0, g2, acc, ad, g0.io);
+      E2_WAIT()
+      g1.touch();
+      E2_MASK(g1, q + 1)
+      dquad_steps_bf<MT, NT, false>(g1, g2, acc, ad, g1.io);
+#undef E2_BF_STEP
+#undef E2_WAITN
+#undef E2_ISSUE
+    }
+  } else {
   if (tb < te) {
     // first quad of the first tile, fetched in the open
     tile_geom(tb);
@@ -440,6 +505,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     } else {
       dquad_go<MT, NT, false, BF>(g1, g0, acc, ad, g1.io);
     }
+  }
   }
 #undef E2_ADV
 #undef E2_MASK
@@ -504,8 +570,9 @@ static int launch_d2(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
 template <int MT, int NT, int BP, int WK>
 static int launch_d(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
   if (ctx->mfma_bf16) {
-    if constexpr (BP == 256) return launch_d2<MT, NT, BP, WK, true>(ctx, p, grid, lds);
-    e2_set_error("wgrad(direct, bf16): BP must be 256");
+    // (7 x 4 blocks: the three operand sets of the bf16 form do not fit the registers)
+    if constexpr (BP == 256 && MT * NT < 28) return launch_d2<MT, NT, BP, WK, true>(ctx, p, grid, lds);
+    e2_set_error("wgrad(direct, bf16): no instance MT=%d NT=%d BP=%d", MT, NT, BP);
     return 2;
   }
   return launch_d2<MT, NT, BP, WK, false>(ctx, p, grid, lds);
@@ -548,7 +615,7 @@ static int d_maxspans(const WgradArgs& a, int BNn) {
   return cis * a.kd;
 }
 size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP, int WK) {
-  return (size_t)(BP + 64) + (size_t)d_maxspans(a, 16 * NT * (4 / WK)) * e2i_wgrad_direct_lpad(a, BP) + 64;
+  return (size_t)(BP + 256) + (size_t)d_maxspans(a, 16 * NT * (4 / WK)) * e2i_wgrad_direct_lpad(a, BP) + 64;
 }
 
 int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, int PS, int WK) {

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   const unsigned stepY = 4u * (unsigned)isY;
   const unsigned stepCg = 16u * (unsigned)Lpad;       // bytes between channel groups in LDS
 
-  GRegs<MT, NT, TPG> g0, g1;
+  GRegs<MT, NT, TPG> g0, g1, g2;            // g2: third set of the bf16 form's rotation
 #define E2_WAIT()                                                         \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
   __builtin_amdgcn_sched_barrier(0);
@@ -385,23 +385,58 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
     g0.touch();
     int ty = 0;
     int g = 0;
+    if constexpr (BF) {
+      // bf16 form: a group's arithmetic (a few hundred cycles) is far shorter than a
+      // round trip to L2, so TWO groups are kept in flight: while group g computes,
+      // g+1 is landing and g+2 is being requested (three register sets in rotation).
+      // The counted wait lets the newest group's weight loads stay outstanding; reads
+      // past the last group of a chunk hit slack rows / LDS beyond the spans, unused.
+      constexpr int NA = TPG * MT < 63 ? TPG * MT : 63;
+#define E2_WAIT1()                                                        \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NA) : "memory"); \
+      __builtin_amdgcn_sched_barrier(0);
+#define E2_BF_STEP(CUR, NXT, TGT)                                         \
+      E2_ADV()                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                  \
+      group_reads<MT, NT, KW, GU, 0, TPG*(MT + NT)>(TGT, ad);             \
+      __builtin_amdgcn_sched_barrier(0);                                  \
+      group_mfma_bf<MT, NT, TPG>(CUR, acc);                               \
+      __builtin_amdgcn_sched_barrier(0);                                  \
+      E2_WAIT1()                                                          \
+      NXT.touch();
+      // g0 is ready; request g1
+      E2_ADV()
+      __builtin_amdgcn_sched_barrier(0);
+      group_reads<MT, NT, KW, GU, 0, TPG*(MT + NT)>(g1, ad);
+      __builtin_amdgcn_sched_barrier(0);
+      for (; g + 3 <= nG; g += 3) {
+        E2_BF_STEP(g0, g1, g2)
+        E2_BF_STEP(g1, g2, g0)
+        E2_BF_STEP(g2, g0, g1)
+      }
+      // 0, 1 or 2 groups are left: g0 is ready, g1 in flight, nothing more to request
+      if (g < nG) group_mfma_bf<MT, NT, TPG>(g0, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      g0.touch(); g1.touch(); g2.touch();
+      if (g + 1 < nG) group_mfma_bf<MT, NT, TPG>(g1, acc);
+#undef E2_BF_STEP
+#undef E2_WAIT1
+    } else {
     for (; g + 1 < nG; g += 2) {
       E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BF) group_steps_bf<MT, NT, KW, GU>(g0, g1, acc, ad);
-      else group_steps<MT, NT, KW, GU, 0>(g0, g1, acc, ad);   // compute g, fetch g+1
+      group_steps<MT, NT, KW, GU, 0>(g0, g1, acc, ad);   // compute g, fetch g+1
       E2_WAIT()
       g1.touch();
       E2_ADV()
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BF) group_steps_bf<MT, NT, KW, GU>(g1, g0, acc, ad);
-      else group_steps<MT, NT, KW, GU, 0>(g1, g0, acc, ad);   // past the end: slack rows
+      group_steps<MT, NT, KW, GU, 0>(g1, g0, acc, ad);   // past the end: slack rows
       E2_WAIT()
       g0.touch();
     }
-    if (g < nG) {
-      if constexpr (BF) group_mfma_bf<MT, NT, TPG>(g0, acc);
-      else group_mfma<MT, NT, TPG, 0>(g0, acc);
+    if (g < nG) group_mfma<MT, NT, TPG, 0>(g0, acc);
     }
   }
 #undef E2_WAIT
@@ -504,8 +539,19 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
 }
 
 // ---- launch helpers ----------------------------------------------------------
+// The bf16 form rotates three operand sets; tilings whose registers would not fit (the
+// compiler would spill operands whose loads are still in flight) have no instance.
+template <int MT, int NT, int KW, int GU>
+constexpr bool igemm_bf_fits() {
+  return 3 * KW * GU * (MT + NT) + 4 * MT * NT + 40 + (NT == 4 ? 20 : 0) <= 245;
+}
+
 template <int MT, int NT, int KW, int GU, bool BF>
 static int igemm_launch(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
+  if constexpr (BF && !igemm_bf_fits<MT, NT, KW, GU>()) {
+    e2_set_error("igemm(bf16): no instance MT=%d NT=%d for %d-wide tap rows", MT, NT, KW);
+    return 2;
+  } else {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
@@ -517,6 +563,7 @@ static int igemm_launch(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
   hipLaunchKernelGGL((igemm_kernel<MT, NT, KW, GU, BF>), dim3(grid), dim3(512), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
+  }
 }
 
 // all (MT, NT) instances of one kernel width

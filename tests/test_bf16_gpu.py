@@ -47,7 +47,7 @@ CASES = [
     (20, 40, (3, 3, 3), (5, 14, 19), None, None),
     (40, 150, (2, 4, 4), (3, 12, 13), None, None),
     (150, 200, (1, 3, 3), (2, 11, 12), "7,2,32,1", "7,2,1,256,4"),
-    (200, 200, (1, 1, 1), (2, 9, 10), "13,1,16,1", None),          # GU = 4
+    (200, 200, (1, 1, 1), (2, 9, 10), "10,1,16,1", None),          # GU = 4
     (200, 200, (1, 1, 1), (2, 9, 10), "7,2,8,2", "4,1,1,256,2"),   # GU = 1, split-K
     (20, 30, (1, 5, 5), (2, 17, 18), None, "2,2,14,256,3"),        # 16x16x32 form, waves split quads
     (30, 40, (1, 5, 5), (1, 47, 47), "3,4,16,1", None),

@@ -9,6 +9,8 @@ op = sys.argv[1]
 cin, cout, kd, kh, kw, D, H, W = map(int, sys.argv[2:10])
 iters = int(sys.argv[10]) if len(sys.argv) > 10 else 10
 ctx = backend.Context(0)
+if os.environ.get('E2_MFMA_DTYPE'):
+    ctx.set_mfma_dtype(os.environ['E2_MFMA_DTYPE'])
 k = (kd, kh, kw)
 osp = (D - kd + 1, H - kh + 1, W - kw + 1)
 x = torch.rand(1, cin, D, H, W, device="cuda")

@@ -1,6 +1,8 @@
 #!/bin/bash
 cd /root/repo
-timeout -k 10 1100 python -m pytest tests -m gpu -q -x > gpurun_out/all8.log 2>&1; echo "tests rc=$?"
-tail -4 gpurun_out/all8.log
-timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/bench_f32_now.json 2>gpurun_out/bench_f32_now.err; echo "bench rc=$?"; tail -c 700 gpurun_out/bench_f32_now.json
-timeout -k 10 300 python bench.py --no-cpu-baseline --mfma bf16 > gpurun_out/bench_bf16_now.json 2>gpurun_out/bench_bf16_now.err; echo "bench rc=$?"; tail -c 900 gpurun_out/bench_bf16_now.json
+export E2_WGRAD_STAMPS=1
+for f in 7,2,1,256,8 4,4,1,256,8; do
+E2_MFMA_DTYPE=bf16 E2_WGRAD_FORCE=$f timeout -k 10 120 python tools/one_layer.py wgradp 200 200 1 3 3 10 39 39 3 2>&1 | tail -2 | cut -c1-330
+done
+E2_WGRAD_FORCE=7,2,1,128,8 timeout -k 10 120 python tools/one_layer.py wgradp 200 200 1 3 3 10 39 39 3 2>&1 | tail -2 | cut -c1-330
+E2_WGRAD_FORCE=3,2,14,256,30 timeout -k 10 120 python tools/one_layer.py wgradp 20 40 3 3 3 23 90 90 3 2>&1 | tail -2 | cut -c1-330
