@@ -81,7 +81,13 @@ def dense_prediction_bench(args, rank, world):
     from elektronn2_amd import nets
     from oracle import e2_oracle as O
     spec, sp = O.NEURO3D_LITE, (23, 183, 183)
-    model = nets.neuro3d_lite((None, 1) + sp, params=O.init_net(spec, 1, seed=1))
+    mfp = args.workload == "dense183mfp"
+    if mfp:
+        # the prediction-time rewrite with max-fragment pooling: the same (24,186,186) input
+        # block, ONE pass with 32 fragments on the batch axis instead of 32 shifted passes
+        model = nets.neuro3d_lite((1, 1, 24, 186, 186), params=O.init_net(spec, 1, seed=1), mfp=True)
+    else:
+        model = nets.neuro3d_lite((None, 1) + sp, params=O.init_net(spec, 1, seed=1))
     rng = np.random.RandomState(0)
     raw = rng.rand(1, 43, 331, 331).astype(np.float32)
     for _ in range(max(1, min(args.warmup, 2))):
@@ -93,17 +99,26 @@ def dense_prediction_bench(args, rank, world):
         pred = model.predict_dense(raw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    fwd_gf = sum(2.0 * nf * ci * np.prod(k) * np.prod(o) for nf, ci, k, o in _fwd_layers(spec, sp)) / 1e9
-    passes = 8 * 32
+    peak = PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    if mfp:
+        fwd_gf = sum(2.0 * n.computational_cost for n in model.nodes.values()
+                     if type(n).__name__ == 'Conv') / 1e9
+        passes = 8
+    else:
+        fwd_gf = sum(2.0 * nf * ci * np.prod(k) * np.prod(o) for nf, ci, k, o in _fwd_layers(spec, sp)) / 1e9
+        passes = 8 * 32
     out = {"metric": "dense_prediction_voxels_per_sec", "value": float(np.prod(pred.shape[1:])) / dt,
            "unit": "voxels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
            "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
            "config": {"workload": "neuro3d_lite predict_dense (1,43,331,331)->(2,39,293,293), "
-                                  "8 blocks x 32 stride offsets, host volume in / host prediction out"},
+                                  + ("8 blocks, max-fragment pooling (32 fragments per pass), "
+                                     if mfp else "8 blocks x 32 stride offsets, ")
+                                  + "host volume in / host prediction out",
+                      "algorithmic_gflop_per_pass": fwd_gf},
            "roofline": {"bound": "mfma", "achieved": passes * fwd_gf / dt / 1e3,
-                        "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": passes * fwd_gf / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, "traffic": None}}
+                        "peak": peak, "unit": "TFLOP/s",
+                        "frac": passes * fwd_gf / dt / 1e3 / peak, "traffic": None}}
     if rank == 0:
         print(json.dumps(out))
 
@@ -185,7 +200,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "warp183"])
+    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "warp183"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mfma", default=os.environ.get("E2_MFMA_DTYPE", "f32"), choices=["f32", "bf16"],
@@ -206,15 +221,15 @@ def main():
         parallel.init_from_env(os.environ.get("E2_DIST_BACKEND", "nccl"))
     assert world == args.gpus or world == 1, "launch with torchrun for --gpus > 1"
 
-    if args.workload == "dense183":
-        return dense_prediction_bench(args, rank, world)
-    if args.workload == "warp183":
-        return warp_bench(args, rank, world)
-    builder, sp, gf_table = WORKLOADS[args.workload]
     bf16 = args.mfma == "bf16"
     if bf16:
         import elektronn2_amd
         elektronn2_amd.set_mfma_dtype("bf16")
+    if args.workload in ("dense183", "dense183mfp"):
+        return dense_prediction_bench(args, rank, world)
+    if args.workload == "warp183":
+        return warp_bench(args, rank, world)
+    builder, sp, gf_table = WORKLOADS[args.workload]
     if builder == "unet3d_lite":
         spec = params = None
         gflop = gf_table

@@ -7,40 +7,43 @@ from __future__ import annotations
 import numpy as np
 
 
-def neuro3d_lite(in_sh=(None, 1, 23, 183, 183), params=None, name=None):
+def neuro3d_lite(in_sh=(None, 1, 23, 183, 183), params=None, name=None, mfp=False):
+    """``mfp=True``: the prediction-time rewrite with max-fragment pooling (batch 1, input
+    extents shifted so that every pooled axis satisfies the MFP rule) ending in
+    ``FragmentsToDense`` -- one pass predicts a DENSE block."""
     from . import neuromancer as nm
     if name is not None:
         nm.model_manager.newmodel(name)
     P = _pget(params)
     inp = nm.Input(in_sh, 'b,f,z,x,y', name='raw')
-    out = nm.Conv(inp, 20, (1, 4, 4), (1, 2, 2), **P(0))
-    out = nm.Conv(out, 40, (3, 3, 3), (1, 2, 2), **P(1))
-    out = nm.Conv(out, 150, (2, 4, 4), (2, 1, 1), **P(2))
-    out = nm.Conv(out, 200, (1, 3, 3), **P(3))
-    out = nm.Conv(out, 200, (1, 3, 3), **P(4))
-    out = nm.Conv(out, 200, (1, 1, 1), **P(5))
-    out = nm.Conv(out, 2, (1, 1, 1), activation_func='lin', **P(6))
-    return _finish(nm, inp, out, name)
+    out = nm.Conv(inp, 20, (1, 4, 4), (1, 2, 2), mfp=mfp, **P(0))
+    out = nm.Conv(out, 40, (3, 3, 3), (1, 2, 2), mfp=mfp, **P(1))
+    out = nm.Conv(out, 150, (2, 4, 4), (2, 1, 1), mfp=mfp, **P(2))
+    out = nm.Conv(out, 200, (1, 3, 3), mfp=mfp, **P(3))
+    out = nm.Conv(out, 200, (1, 3, 3), mfp=mfp, **P(4))
+    out = nm.Conv(out, 200, (1, 1, 1), mfp=mfp, **P(5))
+    out = nm.Conv(out, 2, (1, 1, 1), activation_func='lin', mfp=mfp, **P(6))
+    return _finish(nm, inp, out, name, mfp)
 
 
-def neuro3d(in_sh=(None, 1, 23, 185, 185), params=None, name=None):
+def neuro3d(in_sh=(None, 1, 23, 185, 185), params=None, name=None, mfp=False):
     from . import neuromancer as nm
     if name is not None:
         nm.model_manager.newmodel(name)
     P = _pget(params)
     inp = nm.Input(in_sh, 'b,f,z,x,y', name='raw')
-    out = nm.Conv(inp, 20, (1, 6, 6), (1, 2, 2), **P(0))
-    out = nm.Conv(out, 30, (1, 5, 5), (1, 2, 2), **P(1))
-    out = nm.Conv(out, 40, (1, 5, 5), **P(2))
-    out = nm.Conv(out, 80, (4, 4, 4), (2, 1, 1), **P(3))
-    out = nm.Conv(out, 100, (3, 4, 4), **P(4))
-    out = nm.Conv(out, 100, (3, 4, 4), **P(5))
-    out = nm.Conv(out, 150, (2, 4, 4), **P(6))
-    out = nm.Conv(out, 200, (1, 4, 4), **P(7))
-    out = nm.Conv(out, 200, (1, 4, 4), **P(8))
-    out = nm.Conv(out, 200, (1, 1, 1), **P(9))
-    out = nm.Conv(out, 2, (1, 1, 1), activation_func='lin', **P(10))
-    return _finish(nm, inp, out, name)
+    out = nm.Conv(inp, 20, (1, 6, 6), (1, 2, 2), mfp=mfp, **P(0))
+    out = nm.Conv(out, 30, (1, 5, 5), (1, 2, 2), mfp=mfp, **P(1))
+    out = nm.Conv(out, 40, (1, 5, 5), mfp=mfp, **P(2))
+    out = nm.Conv(out, 80, (4, 4, 4), (2, 1, 1), mfp=mfp, **P(3))
+    out = nm.Conv(out, 100, (3, 4, 4), mfp=mfp, **P(4))
+    out = nm.Conv(out, 100, (3, 4, 4), mfp=mfp, **P(5))
+    out = nm.Conv(out, 150, (2, 4, 4), mfp=mfp, **P(6))
+    out = nm.Conv(out, 200, (1, 4, 4), mfp=mfp, **P(7))
+    out = nm.Conv(out, 200, (1, 4, 4), mfp=mfp, **P(8))
+    out = nm.Conv(out, 200, (1, 1, 1), mfp=mfp, **P(9))
+    out = nm.Conv(out, 2, (1, 1, 1), activation_func='lin', mfp=mfp, **P(10))
+    return _finish(nm, inp, out, name, mfp)
 
 
 def unet3d_lite(in_sh=(None, 1, 22, 140, 140), name=None):
@@ -87,8 +90,13 @@ def _pget(params):
     return P
 
 
-def _finish(nm, inp, out, name):
+def _finish(nm, inp, out, name, mfp=False):
     probs = nm.Softmax(out)
+    if mfp:
+        dense = nm.FragmentsToDense(probs)
+        model = nm.model_manager.current if name is not None else nm.model_manager.getmodel()
+        model.designate_nodes(input_node=inp, prediction_node=dense)
+        return model
     target = nm.Input_like(probs, override_f=1, name='target')
     loss_pix = nm.MultinoulliNLL(probs, target, target_is_sparse=True)
     loss = nm.AggregateLoss(loss_pix, name='loss')

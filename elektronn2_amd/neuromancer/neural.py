@@ -18,14 +18,15 @@ import logging
 
 import numpy as np
 
-from .graphutils import floatX
+from .graphutils import floatX, TaggedShape
 from .. import autotune
 from .node_basic import Node, Concat, Add, Sym
 from .variables import VariableWeight, ConstantParam, VariableParam
 
 logger = logging.getLogger('elektronn2log')
 
-__all__ = ['Conv', 'UpConv', 'Pool', 'Crop', 'AutoMerge', 'UpConvMerge', 'NeuralLayer']
+__all__ = ['Conv', 'UpConv', 'Pool', 'Crop', 'AutoMerge', 'UpConvMerge', 'NeuralLayer',
+           'FragmentsToDense']
 
 _HIP_ACTS = ('relu', 'lin')
 
@@ -185,8 +186,6 @@ class Conv(NeuralLayer):
         if activation_func not in _HIP_ACTS:
             raise NotImplementedError("activation_func=%r: only %s are on the HIP hot path"
                                       % (activation_func, _HIP_ACTS))
-        if mfp:
-            raise NotImplementedError("MFP is a 'next' row (SURVEY.md §8f-3)")
         self.conv_dim = conv_dim
         self.w_sh = w_sh
         self._setup_params(w_sh, w, b, gamma, mean, std, dropout_rate, self.pool_shape,
@@ -194,6 +193,18 @@ class Conv(NeuralLayer):
 
     def _make_output(self):
         self.output = Sym(self, floatX)
+        if self.mfp and not all(p == 1 for p in self.pool_shape):
+            # max-fragment pooling (neural.py:666-675, computations.py:652-680): pool at
+            # every offset inside the pooling window; the fragments go to the batch axis
+            if self.input_nodes[0].shape['b'] != 1:
+                raise ValueError("For MFP the batchsize of the raw image input must be 1.")
+            from itertools import product
+            strides = np.array(self.strides, np.int64)
+            offsets_new = []
+            for ix in product(*[range(p) for p in self.pool_shape]):
+                for off in np.array(self.mfp_offsets, np.int64):
+                    offsets_new.append(off + np.multiply(ix, strides))
+            self.mfp_offsets = np.array(offsets_new)
         self.strides = np.multiply(self.pool_shape, self.strides)
 
     def _calc_shape(self):
@@ -203,7 +214,13 @@ class Conv(NeuralLayer):
                                           self.pool_shape)):
             k = 1 - f
             s = (sh[i] + k) // p
-            if (sh[i] + k) % p != 0:
+            if self.mfp:
+                if (sh[i] + k - p + 1) % p != 0:
+                    raise ValueError("Cannot pool spatial axis '%s' of length %i "
+                                     "by factor %i after convolving with "
+                                     "kernel of size %i and using MFP."
+                                     % (sh.tags[i], sh[i], p, f))
+            elif (sh[i] + k) % p != 0:
                 raise ValueError("Cannot pool spatial axis '%s' of length %i "
                                  "by factor %i after convolving with "
                                  "kernel of size %i." % (sh.tags[i], sh[i], p, f))
@@ -216,6 +233,9 @@ class Conv(NeuralLayer):
             else:
                 fov = -1
             sh = sh.updatefov(j, fov)
+        if self.mfp:
+            sh = sh.updatemfp_offsets(self.mfp_offsets)
+            sh = sh.updateshape('b', int(np.prod(self.pool_shape)), mode='mult')
         sh = sh.updatestrides(self.strides)
         sh = sh.updateshape('f', self.n_f)
         self.shape = sh
@@ -253,7 +273,10 @@ class Conv(NeuralLayer):
         kernels that never materialise the conv output (csrc/conv_first.hip)."""
         return (self.parent.is_source and self.parent.shape['f'] == 1 and
                 plan.ctx.conv1_supported(1, self.filter_shape, self.pool_shape) and
-                not plan.needs_grad(self.parent))
+                not plan.needs_grad(self.parent) and not self._mfp_pool())
+
+    def _mfp_pool(self):
+        return bool(self.mfp) and not all(p == 1 for p in self.pool_shape)
 
     def _fused_head(self, plan):
         """classifier head: this (1,1,1) 'lin' conv to <= 4 features feeds nothing but a
@@ -288,9 +311,12 @@ class Conv(NeuralLayer):
         return tiles >= 160
 
     def _plan_alloc(self, plan):
-        N = plan.batch
+        N = plan.out_shape(self.parent)[0]     # (the fragments of MFP sit on the batch axis)
         psp = self.parent.shape.spatial_shape
         k = self.filter_shape
+        if self.mfp and plan.training:
+            raise NotImplementedError("MFP is a prediction-time rewrite of the net "
+                                      "(neural.py:531-533); train without it")
         if self._fused_head(plan) is not None:
             plan.out[self] = None             # the logits are never materialised
             return
@@ -351,6 +377,18 @@ class Conv(NeuralLayer):
         plan.tuned('igemm', sig,
                    autotune.igemm_candidates(self.n_f, cin, self.filter_shape, y.shape[2:]),
                    lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y))
+        if self._mfp_pool():
+            # fragment i = max-pool of the conv output shifted by the i-th offset inside the
+            # pooling window (border ignored), stacked fragment-major on the batch axis
+            from itertools import product
+            out, n_in = plan.out[self], y.shape[0]
+            pz, px, py = self.pool_shape
+            D, H, W = y.shape[2:]
+            for i, (iz, ix, iy) in enumerate(product(range(pz), range(px), range(py))):
+                src = y[:, :, iz:iz + D - pz + 1, ix:ix + H - px + 1, iy:iy + W - py + 1]
+                ctx.pool_bias_act_fwd(src, plan.param(self.b), self.pool_shape,
+                                      self.activation_func, out[i * n_in:(i + 1) * n_in])
+            return
         ctx.pool_bias_act_fwd(y, plan.param(self.b), self.pool_shape, self.activation_func,
                               plan.out[self])
 
@@ -395,6 +433,48 @@ class Conv(NeuralLayer):
                        lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self.filter_shape, out))
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
+
+
+class FragmentsToDense(Node):
+    """neural.py:862-903: interleave the MFP fragments on the batch axis into ONE dense
+    prediction: ``dense[..., off_i[k]::strides[k]] = fragment_i``."""
+
+    def __init__(self, parent, name="to_dense", print_repr=True):
+        super(FragmentsToDense, self).__init__(parent, name, print_repr)
+
+    def _make_output(self):
+        sh = self.parent.shape
+        if sh['b'] != len(sh.mfp_offsets) or sh['b'] != np.prod(sh.strides):
+            raise ValueError("Need %i fragments on the batch axis. "
+                             "Is MFP active at all?" % np.prod(sh.strides))
+        self.output = Sym(self, floatX)
+
+    def _calc_shape(self):
+        sh = self.parent.shape
+        for ax, st in zip(sh.spatial_axes, sh.strides):
+            sh = sh.updateshape(ax, int(st), mode='mult')
+        sh = sh.updateshape('b', 1)
+        n_sp = len(sh.spatial_axes)
+        self.shape = TaggedShape(sh.shape, sh.tags, np.ones(n_sp, np.int64),
+                                 np.zeros((1, n_sp), np.int64), sh.fov)
+
+    def _calc_comp_cost(self):
+        self.computational_cost = 0
+
+    def _plan_alloc(self, plan):
+        if plan.training:
+            raise NotImplementedError("FragmentsToDense is a prediction-time node")
+        plan.alloc_out(self)
+
+    def _plan_fwd(self, plan):
+        frag, dense = plan.out[self.parent], plan.out[self]
+        sz, sx, sy = (int(v) for v in self.parent.shape.strides)
+        for i, off in enumerate(np.asarray(self.parent.shape.mfp_offsets)):
+            # strided scatter on the plan's stream (torch; captured with the graph)
+            dense[0, :, int(off[0])::sz, int(off[1])::sx, int(off[2])::sy] = frag[i]
+
+    def _plan_bwd(self, plan):
+        raise NotImplementedError("FragmentsToDense is a prediction-time node")
 
 
 class UpConv(Conv):
