@@ -181,6 +181,121 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(View5 dout, View5 y,
   }
 }
 
+// Fixed-window forms of the two kernels above for the pool shapes of the BASELINE nets
+// ((1,2,2), (2,1,1), (2,2,2)): the window lives in registers (read once), the loops are
+// compile-time, and with V2 (x-window of 2, 8-byte aligned rows) a thread moves its two
+// neighbours with one 8-byte access.
+template <int PX, bool V2>
+__device__ __forceinline__ void pw_load_row(const float* row, float (&w)[PX]) {
+  if constexpr (V2) {
+    const float2 v = *reinterpret_cast<const float2*>(row);
+    w[0] = v.x; w[1] = v.y;
+  } else {
+#pragma unroll
+    for (int e = 0; e < PX; ++e) w[e] = row[e];
+  }
+}
+template <int PZ, int PY, int PX, bool V2, bool HAS_BIAS>
+__global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const float* __restrict__ bias,
+                                                             int act, View5 out, FastDiv dw,
+                                                             FastDiv dh, unsigned chunk) {
+  const unsigned S = (unsigned)out.d * out.h * out.w;
+  const unsigned s0 = blockIdx.x * chunk;
+  const unsigned s1 = min(s0 + chunk, S);
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float bv = HAS_BIAS ? bias[c] : 0.f;
+  const float* __restrict__ ybase = y.p + (long)n * y.sn + (long)c * y.sc;
+  float* __restrict__ obase = out.p + (long)n * out.sn + (long)c * out.sc;
+  // (restrict + unroll: the loads of four iterations are in flight together)
+#pragma unroll 4
+  for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
+    const unsigned t = fdiv(s, dw);
+    const unsigned xo = s - t * out.w;
+    const unsigned zo = fdiv(t, dh);
+    const unsigned yo = t - zo * out.h;
+    const float* src = ybase + (long)(zo * PZ) * y.sd + (long)(yo * PY) * y.sh + xo * PX;
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < PZ; ++a)
+#pragma unroll
+      for (int b = 0; b < PY; ++b) {
+        float w[PX];
+        pw_load_row<PX, V2>(src + a * y.sd + b * y.sh, w);
+#pragma unroll
+        for (int e = 0; e < PX; ++e) m = fmaxf(m, w[e]);
+      }
+    float v = m + bv;
+    if (act == E2_ACT_RELU) v = fmaxf(v, 0.f);
+    obase[(long)zo * out.sd + (long)yo * out.sh + xo] = v;
+  }
+}
+template <int PZ, int PY, int PX, bool V2, bool HAS_BIAS>
+__global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y,
+                                                             const float* __restrict__ bias,
+                                                             int act, View5 dy,
+                                                             float* __restrict__ dbias,
+                                                             int accumulate, FastDiv dw,
+                                                             FastDiv dh, unsigned chunk) {
+  __shared__ float red[4];
+  const unsigned S = (unsigned)dout.d * dout.h * dout.w;
+  const unsigned s0 = blockIdx.x * chunk;
+  const unsigned s1 = min(s0 + chunk, S);
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float bv = HAS_BIAS ? bias[c] : 0.f;
+  const float* __restrict__ ybase = y.p + (long)n * y.sn + (long)c * y.sc;
+  const float* __restrict__ gbase = dout.p + (long)n * dout.sn + (long)c * dout.sc;
+  float* __restrict__ dbase = dy.p + (long)n * dy.sn + (long)c * dy.sc;
+  float gsum = 0.f;
+  // (restrict + unroll: the loads of four iterations are in flight together)
+#pragma unroll 4
+  for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
+    const unsigned t = fdiv(s, dw);
+    const unsigned xo = s - t * dout.w;
+    const unsigned zo = fdiv(t, dh);
+    const unsigned yo = t - zo * dout.h;
+    const float* src = ybase + (long)(zo * PZ) * y.sd + (long)(yo * PY) * y.sh + xo * PX;
+    float w[PZ][PY][PX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < PZ; ++a)
+#pragma unroll
+      for (int b = 0; b < PY; ++b) {
+        pw_load_row<PX, V2>(src + a * y.sd + b * y.sh, w[a][b]);
+#pragma unroll
+        for (int e = 0; e < PX; ++e) m = fmaxf(m, w[a][b][e]);
+      }
+    float g = gbase[(long)zo * dout.sd + (long)yo * dout.sh + xo];
+    if (act == E2_ACT_RELU) {
+      const float pre = m + bv;
+      g *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
+    }
+    gsum += g;
+    float* dst = dbase + (long)(zo * PZ) * dy.sd + (long)(yo * PY) * dy.sh + xo * PX;
+#pragma unroll
+    for (int a = 0; a < PZ; ++a)
+#pragma unroll
+      for (int b = 0; b < PY; ++b) {
+        float* drow = dst + a * dy.sd + b * dy.sh;
+        float v[PX];
+#pragma unroll
+        for (int e = 0; e < PX; ++e) v[e] = (w[a][b][e] == m) ? g : 0.f;
+        if constexpr (V2) {
+          float2* d2 = reinterpret_cast<float2*>(drow);
+          float2 o = make_float2(v[0], v[1]);
+          if (accumulate) { const float2 old = *d2; o.x += old.x; o.y += old.y; }
+          *d2 = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < PX; ++e) drow[e] = accumulate ? (drow[e] + v[e]) : v[e];
+        }
+      }
+  }
+  if (dbias != nullptr) {
+    const float tot = block_sum256(gsum, red);
+    if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(dbias + c, tot);
+  }
+}
+
 // backward of the FUSED conv+bias+act forward (no pooling): dy = dout * act'(out),
 // relu' read off the activated output: > 0 -> 1, +0.0 -> 0.5 (pre-activation was
 // exactly 0), -0.0 -> 0 (it was negative; see e2_conv3d_fwd_packed_act); dbias += sum
@@ -498,6 +613,41 @@ static dim3 grid_chunked(const View5& v, unsigned chunk) {
   return dim3((unsigned)((S + chunk - 1) / chunk), (unsigned)v.c, (unsigned)v.n);
 }
 
+// 8-byte alignment of every row of a view (x-window of 2 read / written as float2)
+static bool rows_aligned8(const View5& v) {
+  return ((uintptr_t)v.p % 8 == 0) && (v.sn % 2 == 0) && (v.sc % 2 == 0) && (v.sd % 2 == 0) &&
+         (v.sh % 2 == 0);
+}
+template <int PZ, int PY, int PX>
+static void launch_pool_fwd_fixed(e2_ctx* ctx, const View5& vy, const float* bias, int act,
+                                  const View5& vo, FastDiv dw, FastDiv dh, unsigned chunk) {
+  const dim3 g = grid_chunked(vo, chunk);
+  const bool v2 = (PX == 2) && rows_aligned8(vy);
+#define E2_L(V2, HB)                                                                          \
+  hipLaunchKernelGGL((pool_fwd_fixed_kernel<PZ, PY, PX, V2, HB>), g, dim3(256), 0, ctx->stream, \
+                     vy, bias, act, vo, dw, dh, chunk)
+  if constexpr (PX == 2) {
+    if (v2) { if (bias) E2_L(true, true); else E2_L(true, false); return; }
+  }
+  if (bias) E2_L(false, true); else E2_L(false, false);
+#undef E2_L
+}
+template <int PZ, int PY, int PX>
+static void launch_pool_bwd_fixed(e2_ctx* ctx, const View5& vd, const View5& vy, const float* bias,
+                                  int act, const View5& vdy, float* dbias, int accumulate,
+                                  FastDiv dw, FastDiv dh, unsigned chunk) {
+  const dim3 g = grid_chunked(vd, chunk);
+  const bool v2 = (PX == 2) && rows_aligned8(vy) && rows_aligned8(vdy);
+#define E2_L(V2, HB)                                                                          \
+  hipLaunchKernelGGL((pool_bwd_fixed_kernel<PZ, PY, PX, V2, HB>), g, dim3(256), 0, ctx->stream, \
+                     vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk)
+  if constexpr (PX == 2) {
+    if (v2) { if (bias) E2_L(true, true); else E2_L(true, false); return; }
+  }
+  if (bias) E2_L(false, true); else E2_L(false, false);
+#undef E2_L
+}
+
 int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
   if (int rc = check_view(t, "fill_view")) return rc;
   View5 v = mk(t);
@@ -560,7 +710,11 @@ extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const floa
   E2_REQUIRE((long)vo.d * vo.h * vo.w < (1L << 31), "pool_bias_act_fwd: channel too large");
   const FastDiv dw = mk_div(vo.w), dh = mk_div(vo.h);
   const unsigned chunk = pw_chunk(vo);
-  if (bias)
+  const int pcode = pz * 100 + py * 10 + px;
+  if (pcode == 122) launch_pool_fwd_fixed<1, 2, 2>(ctx, vy, bias, act, vo, dw, dh, chunk);
+  else if (pcode == 211) launch_pool_fwd_fixed<2, 1, 1>(ctx, vy, bias, act, vo, dw, dh, chunk);
+  else if (pcode == 222) launch_pool_fwd_fixed<2, 2, 2>(ctx, vy, bias, act, vo, dw, dh, chunk);
+  else if (bias)
     hipLaunchKernelGGL((pool_fwd_kernel<true>), grid_chunked(vo, chunk), dim3(256), 0,
                        ctx->stream, vy, bias, pz, py, px, act, vo, dw, dh, chunk);
   else
@@ -587,7 +741,14 @@ static int pool_bwd_common(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5
   E2_REQUIRE((long)vd.d * vd.h * vd.w < (1L << 31), "pool_bwd: channel too large");
   const FastDiv dw = mk_div(vd.w), dh = mk_div(vd.h);
   const unsigned chunk = pw_chunk(vd);
-  if (bias)
+  const int pcode = pz * 100 + py * 10 + px;
+  if (pcode == 122)
+    launch_pool_bwd_fixed<1, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk);
+  else if (pcode == 211)
+    launch_pool_bwd_fixed<2, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk);
+  else if (pcode == 222)
+    launch_pool_bwd_fixed<2, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk);
+  else if (bias)
     hipLaunchKernelGGL((pool_bwd_kernel<true>), grid_chunked(vd, chunk), dim3(256), 0,
                        ctx->stream, vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate, dw,
                        dh, chunk);
