@@ -39,10 +39,10 @@ WORKLOADS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (--mfma bf16 only)
 # HBM-side bytes per step from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-# --pmc WRITE_SIZE runs of this script, profiles/r01_d_pmc_traffic.csv):
+# --pmc WRITE_SIZE runs of this script, profiles/r01_e_pmc_traffic.csv):
 # 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
 # It cannot be measured inside the timed run; null for workloads not profiled.
-PMC_TRAFFIC_BYTES = {"lite183": (2 * 822.1 + 417.7) * 1024 * 1024}
+PMC_TRAFFIC_BYTES = {"lite183": (2 * 830.9 + 420.7) * 1024 * 1024}
 
 
 def algorithmic_gflop(spec, sp):
@@ -330,7 +330,7 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None if bf16 else PMC_TRAFFIC_BYTES.get(args.workload),
                      "traffic_unit": "B/step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
-                                     "profiles/r01_d_pmc_traffic.csv)",
+                                     "profiles/r01_e_pmc_traffic.csv)",
                      "kernel": "training step (hipGraph): conv3d igemm fwd/dgrad/wgrad on "
                                + ("v_mfma_f32_16x16x16_bf16 / 16x16x32_bf16" if bf16 else
                                   "v_mfma_f32_16x16x4_f32") + " + pointwise + Adam",
