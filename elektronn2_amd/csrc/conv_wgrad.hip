@@ -89,6 +89,7 @@ struct WgradP {
   int bufFloats;
   int Din, N;
   int dbg;
+  int bf16;               // operands rounded to bf16 into the matrix core (padded-gradient entry only)
   FastDivW divWo;
 };
 
@@ -145,7 +146,19 @@ struct QuadRegs {
   }
 };
 
-template <int MT, int NT, int BP, int WK>
+// bf16 operand form (e2_set_mfma_dtype): the four k-steps a lane holds of a quad are
+// exactly the k = 4*qd + j layout of v_mfma_f32_16x16x16_bf16 -- operands rounded to
+// bf16 (nearest even) by plain casts (NOT inline asm: the compiler must see the VALU
+// write to place the wait states in front of the MFMA), f32 sums.
+typedef short w_s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 w_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w_s16x4 w_pack_bf16(float a, float b, float c, float d) {
+  union { w_bf16x4 h; w_s16x4 v; } r;
+  r.h = (w_bf16x4){(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+  return r.v;
+}
+
+template <int MT, int NT, int BP, int WK, bool BF>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int WN = 4 / WK;
@@ -265,10 +278,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 
     QuadRegs<MT, NT, DLPAD> g0, g1;
 #define E2_MFMA(G)                                                       \
+    if constexpr (BF) {                                                  \
+      w_s16x4 bb_[NT];                                                   \
+      _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                  \
+        bb_[nb] = w_pack_bf16(G.b[0][nb], G.b[1][nb], G.b[2][nb], G.b[3][nb]); \
+      _Pragma("unroll") for (int mb = 0; mb < MT; ++mb) {                \
+        const w_s16x4 aa_ = w_pack_bf16(G.a[mb][0], G.a[mb][1], G.a[mb][2], G.a[mb][3]); \
+        _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                \
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aa_, bb_[nb], acc[mb][nb], 0, 0, 0); \
+      }                                                                  \
+    } else {                                                             \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                        \
     _Pragma("unroll") for (int mb = 0; mb < MT; ++mb)                    \
     _Pragma("unroll") for (int nb = 0; nb < NT; ++nb)                    \
-      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[mb][j], G.b[j][nb], acc[mb][nb], 0, 0, 0);
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(G.a[mb][j], G.b[j][nb], acc[mb][nb], 0, 0, 0); \
+    }
 #define E2_WAIT()                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
     __builtin_amdgcn_sched_barrier(0);
@@ -335,19 +359,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradP p) {
 }
 
 // ---- host side ----------------------------------------------------------------
-template <int MT, int NT, int BP, int WK>
-static int launch_w(e2_ctx* ctx, const WgradP& p, int grid, size_t lds) {
+template <int MT, int NT, int BP, int WK, bool BF>
+static int launch_w2(e2_ctx* ctx, const WgradP& p, int grid, size_t lds) {
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&wgrad_kernel<MT, NT, BP, WK>),
+        reinterpret_cast<const void*>(&wgrad_kernel<MT, NT, BP, WK, BF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_kernel<MT, NT, BP, WK>), dim3(grid), dim3(256), lds, ctx->stream, p);
+  hipLaunchKernelGGL((wgrad_kernel<MT, NT, BP, WK, BF>), dim3(grid), dim3(256), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
+}
+// the bf16 form only where the padded-gradient entry point asked for it (the plain
+// e2_conv3d_wgrad / UpConv paths stay f32, include/e2hip.h)
+template <int MT, int NT, int BP, int WK>
+static int launch_w(e2_ctx* ctx, const WgradP& p, int grid, size_t lds) {
+  if (p.bf16) return launch_w2<MT, NT, BP, WK, true>(ctx, p, grid, lds);
+  return launch_w2<MT, NT, BP, WK, false>(ctx, p, grid, lds);
 }
 
 static const int kWMTs[] = {1, 2, 3, 4, 5, 7};
@@ -550,6 +581,7 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   p.N = a.N;
   p.divWo = mk_divw((unsigned)a.Wo);
   p.dbg = getenv("E2_WGRAD_DBG") ? atoi(getenv("E2_WGRAD_DBG")) : 0;
+  p.bf16 = (ctx->mfma_bf16 && a.dy_padded) ? 1 : 0;
   size_t lds = 2 * (size_t)p.bufFloats * 4;
   if (getenv("E2_WGRAD_LDSPAD")) lds += (size_t)atoi(getenv("E2_WGRAD_LDSPAD"));
   E2_REQUIRE(lds <= 160 * 1024, "wgrad: tiling needs %zu B of LDS", lds);
@@ -558,7 +590,7 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   if (!a.accumulate)
     if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.NTOT, 0.f)) return rc;
   if (getenv("E2_VERBOSE"))
-    fprintf(stderr, "[e2] wgrad Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d WK=%d BP=%d PS=%d grid=%ld lds=%zu\n",
-            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.WK, c.BP, p.nPS, grid, lds);
+    fprintf(stderr, "[e2] wgrad%s Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d WK=%d BP=%d PS=%d grid=%ld lds=%zu\n",
+            p.bf16 ? "(bf16)" : "", a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.WK, c.BP, p.nPS, grid, lds);
   return dispatch_w(ctx, p, c.MT, c.NT, c.BP, c.WK, (int)grid, lds);
 }

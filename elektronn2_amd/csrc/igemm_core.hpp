@@ -549,8 +549,8 @@ constexpr bool igemm_bf_fits() {
 template <int MT, int NT, int KW, int GU, bool BF>
 static int igemm_launch(e2_ctx* ctx, const IgemmP& p, int grid, size_t lds) {
   if constexpr (BF && !igemm_bf_fits<MT, NT, KW, GU>()) {
-    e2_set_error("igemm(bf16): no instance MT=%d NT=%d for %d-wide tap rows", MT, NT, KW);
-    return 2;
+    // this tiling runs in its f32 form (at least as exact; the tuner never prefers it)
+    return igemm_launch<MT, NT, KW, GU, false>(ctx, p, grid, lds);
   } else {
   static bool attr_done = false;
   if (!attr_done) {

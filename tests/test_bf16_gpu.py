@@ -52,6 +52,8 @@ CASES = [
     (20, 30, (1, 5, 5), (2, 17, 18), None, "2,2,14,256,3"),        # 16x16x32 form, waves split quads
     (30, 40, (1, 5, 5), (1, 47, 47), "3,4,16,1", None),
     (24, 200, (3, 2, 3), (5, 13, 37), "4,4,24,1", "5,4,1,256,6"),
+    (150, 200, (1, 3, 3), (2, 11, 12), None, "7,2,0,128,3"),        # LDS-staged wgrad kernel
+    (40, 150, (2, 4, 4), (3, 12, 13), None, "5,4,0,64,4"),
     (6, 17, (1, 1, 3), (1, 1, 70), None, None),
 ]
 
@@ -103,11 +105,6 @@ def test_fwd_dgrad_wgrad_bf16(bctx, case):
         bctx.conv3d_wgrad_pad(xd, dyp, dw)
     finally:
         os.environ.pop("E2_WGRAD_FORCE", None)
-    if Ci * int(np.prod(k)) <= 32:
-        # fewer than three 16-column blocks of (Cin x taps): the LDS-staged kernel runs,
-        # which always computes in f32 (include/e2hip.h, e2_set_mfma_dtype)
-        assert relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < TOL
-        return
     assert relerr(dw, O.conv3d_wgrad(dyb, xb, w.shape)) < TOL
     assert 1e-4 < relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < 2e-2
 
