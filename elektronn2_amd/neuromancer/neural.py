@@ -646,7 +646,8 @@ class Pool(Node):
                  name="pool", print_repr=True):
         super(Pool, self).__init__(parent, name, print_repr)
         if mfp:
-            raise NotImplementedError("MFP is a 'next' row (SURVEY.md §8f-3)")
+            # the reference refuses it as well (neural.py:1535-1536, in _calc_shape)
+            raise NotImplementedError("Check this first before use")
         if stride is not None and tuple(stride) != tuple(pool_shape):
             raise NotImplementedError("Stride!=Pool using 3d pooling")   # computations.py:612
         if mode != 'max':
