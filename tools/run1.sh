@@ -1,7 +1,12 @@
 #!/bin/bash
 cd /root/repo
-timeout -k 10 800 python -m pytest tests/test_bf16_gpu.py -q -x > gpurun_out/bf16_test.log 2>&1; echo "rc=$?"
-tail -3 gpurun_out/bf16_test.log
-E2HIP_TUNE_CACHE=/tmp/tune_bf16.json timeout -k 10 900 python bench.py --workload unet_lite140 --mfma bf16 --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_bf16_unet.json 2> gpurun_out/bench_bf16_unet.err; echo "bench rc=$?"
-tail -c 150 gpurun_out/bench_bf16_unet.json; tail -3 gpurun_out/bench_bf16_unet.err
-cp /tmp/tune_bf16.json gpurun_out/tuned_bf16_v5.json
+export E2_MFMA_DTYPE=bf16 E2_WGRAD_STAMPS=1
+cp elektronn2_amd/libe2hip.so /tmp/orig.so
+for v in orig abl1 abl2; do
+  if [ $v != orig ]; then cp elektronn2_amd/libe2hip_$v.so elektronn2_amd/libe2hip.so; fi
+  echo "== $v"
+  for f in 7,2,1,256,8 2,2,1,256,9; do
+  E2_WGRAD_FORCE=$f timeout -k 10 120 python tools/one_layer.py wgradp 200 200 1 3 3 10 39 39 3 2>&1 | tail -2 | head -1 | cut -c1-260
+  done
+done
+cp /tmp/orig.so elektronn2_amd/libe2hip.so
