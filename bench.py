@@ -45,16 +45,20 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak 
 PMC_TRAFFIC_BYTES = {"lite183": (2 * 830.9 + 420.7) * 1024 * 1024}
 
 
-def algorithmic_gflop(spec, sp):
-    """2*MAC; wgrad = dgrad = fwd; no dgrad for the first layer."""
-    cin, tot = 1, 0.0
-    for li, (nf, k, p, _) in enumerate(spec):
-        osp = [sp[i] - k[i] + 1 for i in range(3)]
-        f = 2.0 * nf * cin * np.prod(k) * np.prod(osp)
-        tot += f * (3 if li > 0 else 2)
-        sp = [osp[i] // p[i] for i in range(3)]
-        cin = nf
+def algorithmic_gflop(model):
+    """2*MAC per Conv node (``computational_cost`` = MACs, neural.py:767-778); wgrad = dgrad =
+    fwd; no dgrad for the layer that reads the raw input."""
+    tot = 0.0
+    for n in model.nodes.values():
+        if type(n).__name__ == 'Conv':
+            tot += 2.0 * n.computational_cost * (2 if n.parent.is_source else 3)
     return tot / 1e9
+
+
+def conv_params(model):
+    """[(w, b)] of the Conv nodes in graph order (the initial weights, for the CPU leg)"""
+    return [(n.w.get_value().copy(), n.b.get_value().copy()) for n in model.nodes.values()
+            if type(n).__name__ == 'Conv']
 
 
 def host_cores():
@@ -79,15 +83,15 @@ def dense_prediction_bench(args, rank, world):
     BASELINE patch size over a (1,43,331,331) volume = 2x2x2 blocks x 32 stride offsets
     = 256 forward passes per prediction; one "step" = one whole-volume prediction."""
     from elektronn2_amd import nets
-    from oracle import e2_oracle as O
-    spec, sp = O.NEURO3D_LITE, (23, 183, 183)
+    sp = (23, 183, 183)
     mfp = args.workload == "dense183mfp"
+    np.random.seed(1)
     if mfp:
         # the prediction-time rewrite with max-fragment pooling: the same (24,186,186) input
         # block, ONE pass with 32 fragments on the batch axis instead of 32 shifted passes
-        model = nets.neuro3d_lite((1, 1, 24, 186, 186), params=O.init_net(spec, 1, seed=1), mfp=True)
+        model = nets.neuro3d_lite((1, 1, 24, 186, 186), mfp=True)
     else:
-        model = nets.neuro3d_lite((None, 1) + sp, params=O.init_net(spec, 1, seed=1))
+        model = nets.neuro3d_lite((None, 1) + sp)
     rng = np.random.RandomState(0)
     raw = rng.rand(1, 43, 331, 331).astype(np.float32)
     for _ in range(max(1, min(args.warmup, 2))):
@@ -105,7 +109,8 @@ def dense_prediction_bench(args, rank, world):
                      if type(n).__name__ == 'Conv') / 1e9
         passes = 8
     else:
-        fwd_gf = sum(2.0 * nf * ci * np.prod(k) * np.prod(o) for nf, ci, k, o in _fwd_layers(spec, sp)) / 1e9
+        fwd_gf = sum(2.0 * n.computational_cost for n in model.nodes.values()
+                     if type(n).__name__ == 'Conv') / 1e9
         passes = 8 * 32
     out = {"metric": "dense_prediction_voxels_per_sec", "value": float(np.prod(pred.shape[1:])) / dt,
            "unit": "voxels/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
@@ -186,15 +191,6 @@ def warp_bench(args, rank, world):
         print(json.dumps(out))
 
 
-def _fwd_layers(spec, sp):
-    cin = 1
-    for nf, k, p, _ in spec:
-        osp = [sp[i] - k[i] + 1 for i in range(3)]
-        yield nf, cin, k, osp
-        sp = [osp[i] // p[i] for i in range(3)]
-        cin = nf
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,7 +207,6 @@ def main():
 
     from elektronn2_amd import parallel, nets
     from elektronn2_amd import neuromancer as nm
-    from oracle import e2_oracle as O        # spec tables + cpu_baseline leg only
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -230,20 +225,15 @@ def main():
     if args.workload == "warp183":
         return warp_bench(args, rank, world)
     builder, sp, gf_table = WORKLOADS[args.workload]
+    np.random.seed(1)                         # identical initial weights on every rank
+    model = getattr(nets, builder)((None, 1) + sp)
+    osp = tuple(model.prediction_node.shape.spatial_shape)
     if builder == "unet3d_lite":
-        spec = params = None
-        gflop = gf_table
-        np.random.seed(1)                     # identical initial weights on every rank
-        model = nets.unet3d_lite((None, 1) + sp)
-        osp = tuple(model.prediction_node.shape.spatial_shape)
+        gflop = gf_table                      # UpConv / merge net: SURVEY.md §8d's figure
         args.no_cpu_baseline = True           # the CPU leg is the sequential-net port
     else:
-        spec = O.NEURO3D_LITE if builder == "neuro3d_lite" else O.NEURO3D
-        gflop = algorithmic_gflop(spec, sp)
-        osp = O.net_out_shape(spec, sp)
-        # identical initial weights on every rank (seed 1), independent data per rank
-        params = O.init_net(spec, 1, seed=1)
-        model = getattr(nets, builder)((None, 1) + sp, params=params)
+        gflop = algorithmic_gflop(model)
+    params0 = conv_params(model)              # initial weights, for the CPU baseline leg
     model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
     opt = model.optimisers['Adam']
     opt.step.compile()
@@ -338,11 +328,14 @@ def main():
                      "device_ms_per_step": dev_ms},
     }
     if world == 1 and not args.no_cpu_baseline:
+        # the ONLY use of oracle/ in this script: the CPU port, timed as the baseline
+        from oracle import e2_oracle as O
         from oracle import torch_step as TS
+        spec = O.NEURO3D_LITE if builder == "neuro3d_lite" else O.NEURO3D
         cores = host_cores()
         x = xs[0].cpu().numpy()
         t = ts[0].cpu().numpy()
-        med, all_t = TS.time_cpu_step(spec, params, x, t, cores, warmup=1, steps=3)
+        med, all_t = TS.time_cpu_step(spec, params0, x, t, cores, warmup=1, steps=3)
         out["cpu_baseline"] = {
             "value": float(np.prod((1, 1) + sp)) / med, "unit": "voxels/s", "cores": cores,
             "kind": "port",

@@ -6,17 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import elektronn2_amd
 from elektronn2_amd import nets
-from oracle import e2_oracle as O       # spec table / seeded init only
 
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 shape = tuple(int(a) for a in args[:3]) if len(args) >= 3 else (512, 512, 512)
 if '--mfma' in sys.argv:
     elektronn2_amd.set_mfma_dtype(sys.argv[sys.argv.index('--mfma') + 1])
-params = O.init_net(O.NEURO3D_LITE, 1, seed=1)
+np.random.seed(1)
 if '--plain' in sys.argv:
-    model = nets.neuro3d_lite((None, 1, 23, 183, 183), params=params)
+    model = nets.neuro3d_lite((None, 1, 23, 183, 183))
 else:
-    model = nets.neuro3d_lite((1, 1, 24, 186, 186), params=params, mfp=True)
+    model = nets.neuro3d_lite((1, 1, 24, 186, 186), mfp=True)
 raw = np.random.RandomState(0).rand(1, *shape).astype(np.float32)
 model.predict_dense(raw[:, :48, :224, :224])          # compile + tune
 t0 = time.time()
