@@ -332,7 +332,7 @@ class Conv(NeuralLayer):
         plan.alloc_out(self)
         cin = self.parent.shape['f']
         nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
-        plan.scratch[self, 'wp_f'] = plan.empty_flat(nb // 4 + 64)
+        plan.scratch[self, 'wp_f'] = plan.zeros_flat(nb // 4 + 64)   # padding stays zero
         plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 0))
         if plan.training:
             pad = [kk - 1 for kk in k]
@@ -345,7 +345,7 @@ class Conv(NeuralLayer):
             plan.scratch[self, 'dy'] = dyp[:, :, pad[0]:pad[0] + osp[0],
                                            pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]]
             if plan.needs_grad(self.parent):
-                plan.scratch[self, 'wp_d'] = plan.empty_flat(nb // 4 + 64)
+                plan.scratch[self, 'wp_d'] = plan.zeros_flat(nb // 4 + 64)
                 plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_d'], 1))
 
     def _plan_fwd(self, plan):

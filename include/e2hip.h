@@ -126,7 +126,9 @@ int e2_conv3d_wgrad_pad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy_pad,
 
 /* Repack MANY weight tensors in one launch (after an optimiser step): fill one
  * record per (tensor, mode) with e2_pack_job_fill on the host, copy the records
- * (e2_pack_job_bytes() each) to the device, then call e2_conv3d_pack_multi. */
+ * (e2_pack_job_bytes() each) to the device, then call e2_conv3d_pack_multi.  It
+ * rewrites the weight-carrying part of every image only: the images must have been
+ * zero-filled (or packed by e2_conv3d_pack) once before the first call. */
 size_t e2_pack_job_bytes(void);
 int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin,
                      int kd, int kh, int kw, int mode);

@@ -445,3 +445,34 @@ def test_fused_classifier_head(ctx, ncls, cin):
     dx2 = torch.full(x.shape, float("nan"), device="cuda")
     ctx.head_bwd(xd, dev(w), probs, dev(t), stats, dx2, False, dw, db, None)
     assert relerr(dx2, dx_ref) < TOL
+
+
+def test_pack_multi_equals_single_pack(ctx):
+    """e2_conv3d_pack_multi rewrites only the weight-carrying part of the (zero-filled)
+    images; the result must equal e2_conv3d_pack's full image, in both modes, also after a
+    second call with changed weights (padding untouched)."""
+    rng = np.random.RandomState(5)
+    shapes = [(37, 10, 1, 3, 3), (200, 150, 1, 3, 3), (20, 1, 1, 4, 4), (40, 21, 3, 3, 3),
+              (2, 200, 1, 1, 1)]
+    ws = [dev(rng.randn(*s)) for s in shapes]
+    jobs, singles = [], []
+    for w in ws:
+        co, ci = w.shape[:2]
+        k = tuple(w.shape[2:])
+        n = ctx.conv_ws_bytes(co, ci, k) // 4 + 64
+        for mode in (0, 1):
+            img = torch.zeros(n, device="cuda")
+            ref = torch.full((n,), float("nan"), device="cuda")
+            jobs.append((w, img, mode))
+            singles.append((w, ref, mode))
+    jd, nj = ctx.make_pack_jobs(jobs)
+    for rep in range(2):
+        ctx.conv3d_pack_multi(jd, nj)
+        for (w, img, mode), (_, ref, _) in zip(jobs, singles):
+            ctx.conv3d_pack(w, mode, ref)
+            n_img = int(torch.isfinite(ref).sum().item())     # the part e2_conv3d_pack wrote
+            assert n_img > w.numel()
+            assert torch.equal(img[:n_img], ref[:n_img])
+            ref.fill_(float("nan"))
+        for w in ws:
+            w.mul_(-0.5)
