@@ -313,3 +313,28 @@ def test_unet3d_lite_native_size_parity():
         assert abs(float(model.loss(x, t)) - L0) / L0 < 1e-5
         for a, b in zip(g, g2):
             assert float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30)) < 2e-3
+
+
+@pytest.mark.parametrize("batch", [2, 3])
+def test_batch_larger_than_one(batch):
+    """the BASELINE configs train with one sample per step, but the node API takes any
+    batch (node_basic.py:1182-1243: batch axis None): loss, every gradient and three Adam
+    steps of neuro3d_lite with 2 / 3 samples against the oracle"""
+    spec, sp = O.NEURO3D_LITE, (7, 47, 47)
+    params = O.init_net(spec, 1, seed=1)
+    rng = np.random.RandomState(batch)
+    x = rng.rand(batch, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (batch, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    m = build('lite', sp, params)
+    loss_ref, grads_ref, _ = O.net_loss_and_grads(spec, params, x, t)
+    assert abs(float(m.loss(x, t)) - loss_ref) < TOL * abs(loss_ref)
+    flat = []
+    for gw, gb in grads_ref:
+        flat += [gw, gb]
+    for g in m.gradients(x, t):
+        cands = [r for r in flat if r.shape == g.shape]
+        assert min(rel(g, r) for r in cands) < TOL
+    ref_losses, _ = O.net_train_steps(spec, params, x, t, 3)
+    for i in range(3):
+        loss = float(m.trainingstep(x, t, optimiser='Adam')[0])
+        assert abs(loss - ref_losses[i]) < 5e-4 * abs(ref_losses[i])
