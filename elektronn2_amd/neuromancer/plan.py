@@ -209,6 +209,7 @@ class Plan(object):
                 self._pack_dev = self.ctx.make_pack_jobs(jobs)
         self._graphs = None
         self._segs = None
+        self._segs_world = None
         self._capturing = False
         self._calls = 0
         self._grad_written = set()
@@ -333,8 +334,14 @@ class Plan(object):
     def _run_device(self):
         """fwd (+ bwd + all-reduce + update) on self.stream, graph-replayed."""
         ctx = self.ctx
-        if self._segs is None:
-            self._segs = self._segments()
+        world = self.model.dp_world() if self.training else 1
+        if self._segs is None or self._segs_world != world:
+            # (data parallelism switched on after earlier steps: re-plan and re-capture)
+            self._segs, self._segs_world = self._segments(), world
+            for g in (self._graphs or []):
+                ctx.graph_destroy(g)
+            self._graphs = None
+            self._dp_cut_cache = False
         capture = self.use_graph and self._calls >= 1
         if capture and self._graphs is None:
             # the first captured call runs segment by segment: a host step between two
