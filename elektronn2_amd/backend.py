@@ -97,6 +97,9 @@ def _load():
         "e2_softmax_nll_fwd": (C.c_int, [vp, P5, P5, P5, fp]),
         "e2_softmax_nll_bwd": (C.c_int, [vp, P5, P5, fp, P5, fp]),
         "e2_malis_nll": (C.c_int, [vp, P5, fp, fp, fp, P5, fp]),
+        "e2_fill_multi": (C.c_int, [vp, vp, vp, C.c_int, C.c_float]),
+        "e2_set_skip_zero_fill": (C.c_int, [vp, C.c_int]),
+        "e2_conv_last_zero_fill": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
         "e2_get_mfma_dtype": (C.c_int, [vp]),
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
@@ -411,6 +414,21 @@ class Context:
         _chk(_lib.e2_softmax_nll_bwd(self.h, C.byref(t5(probs)), C.byref(t5(target)),
                                      _fp(stats), C.byref(t5(dlogits)), _fp(loss_out)),
              "e2_softmax_nll_bwd")
+
+    def fill_multi(self, ptrs_dev, counts_dev, n, value=0.0):
+        """one launch that fills n flat regions (int64 device tensors of pointers / counts)"""
+        _chk(_lib.e2_fill_multi(self.h, C.c_void_p(ptrs_dev.data_ptr()),
+                                C.c_void_p(counts_dev.data_ptr()), int(n), float(value)),
+             "e2_fill_multi")
+
+    def set_skip_zero_fill(self, on):
+        _chk(_lib.e2_set_skip_zero_fill(self.h, 1 if on else 0), "e2_set_skip_zero_fill")
+
+    def conv_last_zero_fill(self):
+        """(pointer, count) of the flat region the last conv launch zero-filled, or (0, 0)"""
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(_lib.e2_conv_last_zero_fill(self.h, C.byref(p), C.byref(n)), "e2_conv_last_zero_fill")
+        return (p.value or 0), int(n.value)
 
     def set_mfma_dtype(self, dtype):
         """'f32' (default) or 'bf16': operand rounding of the conv GEMMs (f32 sums)"""

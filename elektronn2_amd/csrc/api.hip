@@ -47,6 +47,9 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->zeros = nullptr;
   c->fork_next = 0;
   c->mfma_bf16 = 0;
+  c->skip_zero_fill = 0;
+  c->last_fill_ptr = nullptr;
+  c->last_fill_n = 0;
   for (int i = 0; i < 32; ++i) c->fork_ev[i] = nullptr;
   if (hipMalloc(&c->zeros, 1024) != hipSuccess || hipMemset(c->zeros, 0, 1024) != hipSuccess) {
     delete c;

@@ -15,6 +15,9 @@ struct e2_ctx {
   hipEvent_t fork_ev[32];   // dependency events of e2_stream_fork / e2_stream_join
   int fork_next;
   int mfma_bf16;       // e2_set_mfma_dtype: 1 = conv GEMMs round their operands to bf16
+  int skip_zero_fill;  // e2_set_skip_zero_fill: split-K outputs were zeroed by the caller
+  float* last_fill_ptr;     // flat region the last conv launch zero-filled (n = 0: none)
+  size_t last_fill_n;
 };
 
 void e2_set_error(const char* fmt, ...);

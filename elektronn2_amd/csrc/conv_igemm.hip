@@ -300,6 +300,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
              "specialised kernel width and %zu B of LDS", tile_lds);
   const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
   E2_REQUIRE(grid < (1L << 31), "igemm: grid too large");
+  ctx->last_fill_ptr = nullptr; ctx->last_fill_n = 0;
   if (p.atomic) {
     // split-K accumulates with atomics: start from zero
     const int R = a.upz * a.upy * a.upx;
@@ -307,7 +308,11 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
     const int od = a.Do * a.upz, oh = a.Ho * a.upy, ow = a.Wo * a.upx;
     if (a.osY == ow && a.osZ == (long)oh * ow && a.osC == (long)od * oh * ow &&
         (a.N == 1 || a.osN == (long)oc * od * oh * ow)) {
-      if (int rc = e2i_fill_flat(ctx, a.out, (size_t)a.N * oc * od * oh * ow, 0.f)) return rc;
+      // (a caller that batches the zero-fills of a whole step asks which region this was,
+      // e2_conv_last_zero_fill, and announces pre-zeroed outputs, e2_set_skip_zero_fill)
+      ctx->last_fill_ptr = a.out; ctx->last_fill_n = (size_t)a.N * oc * od * oh * ow;
+      if (!ctx->skip_zero_fill)
+        if (int rc = e2i_fill_flat(ctx, a.out, ctx->last_fill_n, 0.f)) return rc;
     } else {
       e2_tensor5 v{a.out, a.N, oc, od, oh, ow, a.osN, a.osC, a.osZ, a.osY};
       int rc = e2i_fill_view(ctx, &v, 0.f);

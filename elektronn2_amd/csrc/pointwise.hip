@@ -668,6 +668,39 @@ int e2i_fill_flat(e2_ctx* ctx, float* ptr, size_t n, float value) {
   return 0;
 }
 
+// many flat fills in one launch (blockIdx.y = region)
+__global__ void fill_multi_kernel(float* const* __restrict__ ptrs,
+                                  const unsigned long long* __restrict__ counts, float v) {
+  float* p = ptrs[blockIdx.y];
+  const size_t n = (size_t)counts[blockIdx.y];
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+extern "C" int e2_fill_multi(e2_ctx* ctx, const void* ptrs_dev, const void* counts_dev,
+                             int nregions, float value) {
+  E2_REQUIRE(ctx && ptrs_dev && counts_dev && nregions > 0 && nregions < 65536,
+             "e2_fill_multi: bad argument");
+  hipLaunchKernelGGL(fill_multi_kernel, dim3(512, nregions), dim3(256), 0, ctx->stream,
+                     (float* const*)ptrs_dev, (const unsigned long long*)counts_dev, value);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int e2_set_skip_zero_fill(e2_ctx* ctx, int on) {
+  E2_REQUIRE(ctx, "e2_set_skip_zero_fill: null context");
+  ctx->skip_zero_fill = on ? 1 : 0;
+  return 0;
+}
+
+extern "C" int e2_conv_last_zero_fill(const e2_ctx* ctx, void** ptr, size_t* n) {
+  E2_REQUIRE(ctx && ptr && n, "e2_conv_last_zero_fill: null argument");
+  *ptr = ctx->last_fill_ptr;
+  *n = ctx->last_fill_n;
+  return 0;
+}
+
 extern "C" int e2_fill(e2_ctx* ctx, float* ptr, size_t n, float value) {
   E2_REQUIRE(ctx && ptr, "e2_fill: null argument");
   return e2i_fill_flat(ctx, ptr, n, value);

@@ -376,7 +376,7 @@ class Conv(NeuralLayer):
             (x.stride(3),)
         plan.tuned('igemm', sig,
                    autotune.igemm_candidates(self.n_f, cin, self.filter_shape, y.shape[2:]),
-                   lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y))
+                   lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y), out=y)
         if self._mfp_pool():
             # fragment i = max-pool of the conv output shifted by the i-th offset inside the
             # pooling window (border ignored), stacked fragment-major on the batch axis
@@ -430,7 +430,8 @@ class Conv(NeuralLayer):
             plan.tuned('igemm', sig,
                        autotune.igemm_candidates(cin, self.n_f, self.filter_shape,
                                                  out.shape[2:]),
-                       lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self.filter_shape, out))
+                       lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self.filter_shape, out),
+                       out=out)
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
 

@@ -133,12 +133,49 @@ class Plan(object):
     def pgrad(self, p):
         return self.model.device_grad(p)
 
-    def tuned(self, kind, sig, cands, fn, fn_tune=None):
+    def tuned(self, kind, sig, cands, fn, fn_tune=None, out=None):
         """launch a conv kernel with its autotuned tiling (tunes on first sight,
-        never while a hipGraph capture is in progress)."""
+        never while a hipGraph capture is in progress).
+
+        ``out``: the launch's output tensor.  A split-K launch zero-fills it first (a ~5 us
+        kernel each); the eager run notes which outputs those are, the captured step
+        zeroes them all with ONE launch at the start of their segment and tells the
+        library to skip its own fill (``_zero_jobs``)."""
         from .. import autotune
-        autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing,
-                            fn_tune=fn_tune)
+        skip = (self._capturing and out is not None
+                and out.data_ptr() in self._zero_batched.get(self._seg_idx, ()))
+        if skip:
+            self.ctx.set_skip_zero_fill(True)
+        try:
+            autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing,
+                                fn_tune=fn_tune)
+        finally:
+            if skip:
+                self.ctx.set_skip_zero_fill(False)
+        if out is not None and not self._capturing:
+            ptr, n = self.ctx.conv_last_zero_fill()
+            if n and ptr == out.data_ptr():
+                self._zero_seen.append((self._seg_idx, ptr, n))
+
+    def _zero_jobs(self):
+        """per segment: (device pointers, device counts, number) of the split-K outputs the
+        last eager run zero-filled -- each exactly once in its segment (a scratch buffer
+        that two launches share keeps its in-line fills)"""
+        jobs, self._zero_batched = {}, {}
+        by_seg = {}
+        for seg, ptr, n in self._zero_seen:
+            by_seg.setdefault(seg, []).append((ptr, n))
+        for seg, lst in by_seg.items():
+            ptrs = [p for p, _ in lst]
+            uniq = [(p, n) for p, n in lst if ptrs.count(p) == 1]
+            if len(uniq) < 2:
+                continue
+            dev = self.ctx.device
+            jobs[seg] = (torch.tensor([p for p, _ in uniq], dtype=torch.int64, device=dev),
+                         torch.tensor([n for _, n in uniq], dtype=torch.int64, device=dev),
+                         len(uniq))
+            self._zero_batched[seg] = set(p for p, _ in uniq)
+        return jobs
 
     # ---- second stream ----------------------------------------------------------------
     def on_side(self, fn):
@@ -210,6 +247,8 @@ class Plan(object):
         self._graphs = None
         self._segs = None
         self._segs_world = None
+        self._seg_idx = 0
+        self._zero_seen, self._zero_batched, self._zero_keep = [], {}, None
         self._capturing = False
         self._calls = 0
         self._grad_written = set()
@@ -340,6 +379,8 @@ class Plan(object):
             self._segs, self._segs_world = self._segments(), world
             for g in (self._graphs or []):
                 ctx.graph_destroy(g)
+            if self._graphs is not None:
+                self._calls = 0          # one eager run of the new segmentation first
             self._graphs = None
             self._dp_cut_cache = False
         capture = self.use_graph and self._calls >= 1
@@ -347,10 +388,15 @@ class Plan(object):
             # the first captured call runs segment by segment: a host step between two
             # segments needs the results of the one before it
             graphs = []
+            zero_jobs = self._zero_jobs()
+            self._zero_keep = zero_jobs                  # the graphs read these tensors
             ctx.record(self._ev0)
-            for emit, after in self._segs:
+            for i, (emit, after) in enumerate(self._segs):
+                self._seg_idx = i
                 self._capturing = True
                 ctx.graph_begin()
+                if i in zero_jobs:
+                    ctx.fill_multi(*zero_jobs[i])
                 emit()
                 g = ctx.graph_end()
                 self._capturing = False
@@ -365,7 +411,10 @@ class Plan(object):
             self._calls += 1
             return
         ctx.record(self._ev0)
+        if not capture:
+            self._zero_seen = []
         for i, (emit, after) in enumerate(self._segs):
+            self._seg_idx = i
             if capture:
                 ctx.graph_launch(self._graphs[i])
             else:

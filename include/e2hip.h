@@ -204,6 +204,19 @@ int e2_copy5(e2_ctx*, const e2_tensor5* src, const e2_tensor5* dst,
              int accumulate);
 int e2_fill(e2_ctx*, float* ptr, size_t n, float value);
 
+/* Batching the zero-fills of a captured step (no reference counterpart).  A split-K conv
+ * launch (forward / data gradient with a small output) zero-fills its output and then
+ * accumulates with atomics; each such fill is a ~5 us kernel.  A caller that replays the
+ * same launches every step can (1) ask after a launch which flat region it zeroed
+ * (e2_conv_last_zero_fill: *n = 0 if none), (2) zero all of them with ONE
+ * e2_fill_multi(ptrs, counts: device arrays of nregions 64-bit entries) at the start of
+ * the step, and (3) wrap the launches in e2_set_skip_zero_fill(ctx, 1) ... (ctx, 0):
+ * "the output is already zero".  Nothing else may write the region in between. */
+int e2_fill_multi(e2_ctx*, const void* ptrs_dev, const void* counts_dev, int nregions,
+                  float value);
+int e2_set_skip_zero_fill(e2_ctx*, int on);
+int e2_conv_last_zero_fill(const e2_ctx*, void** ptr, size_t* n);
+
 /* ---- loss (computations.py:175-176 softmax; loss.py:261-347
  *      MultinoulliNLL(target_is_sparse); loss.py:1357-1363 AggregateLoss) - */
 /* ---- classifier head, fused: 1x1x1 conv to ncls <= 4 'lin' features + channel softmax
