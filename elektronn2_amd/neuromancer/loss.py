@@ -130,7 +130,7 @@ class MultinoulliNLL(Node):
 
     def _plan_fwd(self, plan):
         stats = plan.scratch[self.pred, 'stats']
-        plan.ctx.fill(stats, 0.0)
+        plan.zero_early(stats)
         head = self.pred._head(plan)
         if head is not None:
             plan.ctx.head_fwd(plan.out[head.parent], plan.param(head.w), plan.param(head.b),

@@ -157,6 +157,16 @@ class Plan(object):
             if n and ptr == out.data_ptr():
                 self._zero_seen.append((self._seg_idx, ptr, n))
 
+    def zero_early(self, t):
+        """zero a flat tensor that nothing touches between the start of the current
+        segment and this point (gradient arena, loss statistics): in the captured step it
+        joins the segment's one multi-fill instead of costing a launch of its own"""
+        if self._capturing and t.data_ptr() in self._zero_batched.get(self._seg_idx, ()):
+            return
+        self.ctx.fill(t, 0.0)
+        if not self._capturing:
+            self._zero_seen.append((self._seg_idx, t.data_ptr(), t.numel()))
+
     def _zero_jobs(self):
         """per segment: (device pointers, device counts, number) of the split-K outputs the
         last eager run zero-filled -- each exactly once in its segment (a scratch buffer
@@ -275,7 +285,7 @@ class Plan(object):
             k = self._dp_cut()[0]
             nodes = nodes[:k] if part == 0 else nodes[k:]
         if part in (None, 0):
-            self.ctx.fill(self.model.G, 0.0)
+            self.zero_early(self.model.G)
             self._grad_written = set()
         for n in nodes:
             n._plan_bwd(self)
