@@ -338,33 +338,40 @@ __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out,
 // ---------------------------------------------------------------------------
 __global__ void upconv_dpre_s2d_kernel(View5 dout, View5 yout, int pz, int py, int px,
                                        int act, float* __restrict__ s2d,
-                                       float* __restrict__ dbias) {
+                                       float* __restrict__ dbias, FastDiv dw, FastDiv dh,
+                                       FastDiv dpz, FastDiv dpy, FastDiv dpx, unsigned chunk) {
+  // 32-bit index math with magic-number division (the 64-bit % and / of the first
+  // version made this kernel ALU-bound at ~0.7 TB/s), a chunk of positions per work-group
   __shared__ float red[4];
-  const long S = (long)dout.d * dout.h * dout.w;
-  const long s = blockIdx.x * 256L + threadIdx.x;
+  const unsigned S = (unsigned)dout.d * dout.h * dout.w;
+  const unsigned s0 = blockIdx.x * chunk;
+  const unsigned s1 = min(s0 + chunk, S);
   const int c = blockIdx.y, n = blockIdx.z;
-  float g = 0.f;
-  if (s < S) {
-    const int x = (int)(s % dout.w);
-    const long t = s / dout.w;
-    const int y = (int)(t % dout.h), z = (int)(t / dout.h);
-    g = dout.p[vidx(dout, n, c, z, y, x)];
+  const unsigned R = pz * py * px;
+  const unsigned di = dout.d / pz, hi = dout.h / py, wi = dout.w / px;
+  const float* gb = dout.p + (long)n * dout.sn + (long)c * dout.sc;
+  const float* ob = yout.p + (long)n * yout.sn + (long)c * yout.sc;
+  float* sb = s2d + ((long)n * dout.c + c) * (long)R * di * hi * wi;
+  float gsum = 0.f;
+  for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
+    const unsigned t = fdiv(s, dw);
+    const unsigned x = s - t * dout.w;
+    const unsigned z = fdiv(t, dh);
+    const unsigned y = t - z * dout.h;
+    float g = gb[(long)z * dout.sd + (long)y * dout.sh + x];
     if (act == E2_ACT_RELU) {
-      const float o = yout.p[vidx(yout, n, c, z, y, x)];
+      const float o = ob[(long)z * yout.sd + (long)y * yout.sh + x];
       g = (o > 0.f) ? g : 0.f;
     }
-    const int zi = z / pz, rz = z - zi * pz;
-    const int yi = y / py, ry = y - yi * py;
-    const int xi = x / px, rx = x - xi * px;
-    const int R = pz * py * px;
-    const int r = (rz * py + ry) * px + rx;
-    const int di = dout.d / pz, hi = dout.h / py, wi = dout.w / px;
-    const long o = ((((long)n * dout.c + c) * R + r) * di + zi) * (long)hi * wi +
-                   (long)yi * wi + xi;
-    s2d[o] = g;
+    const unsigned zi = fdiv(z, dpz), rz = z - zi * pz;
+    const unsigned yi = fdiv(y, dpy), ry = y - yi * py;
+    const unsigned xi = fdiv(x, dpx), rx = x - xi * px;
+    const unsigned r = (rz * py + ry) * px + rx;
+    sb[((long)r * di + zi) * (hi * wi) + yi * wi + xi] = g;
+    gsum += g;
   }
   if (dbias != nullptr) {
-    const float tot = block_sum256(g, red);
+    const float tot = block_sum256(gsum, red);
     if (threadIdx.x == 0 && tot != 0.f) unsafeAtomicAdd(dbias + c, tot);
   }
 }
@@ -837,8 +844,11 @@ extern "C" int e2_maxpool3d_bwd(e2_ctx* ctx, const e2_tensor5* dout, const e2_te
 int e2i_upconv_dpre_s2d(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* yout, int pz,
                         int py, int px, int act, float* s2d, float* dbias) {
   View5 vd = mk(dout), vy = mk(yout);
-  hipLaunchKernelGGL(upconv_dpre_s2d_kernel, grid_for(vd), dim3(256), 0, ctx->stream, vd,
-                     vy, pz, py, px, act, s2d, dbias);
+  E2_REQUIRE((long)vd.d * vd.h * vd.w < (1L << 31), "upconv_dpre_s2d: channel too large");
+  const unsigned chunk = pw_chunk(vd);
+  hipLaunchKernelGGL(upconv_dpre_s2d_kernel, grid_chunked(vd, chunk), dim3(256), 0,
+                     ctx->stream, vd, vy, pz, py, px, act, s2d, dbias, mk_div(vd.w),
+                     mk_div(vd.h), mk_div(pz), mk_div(py), mk_div(px), chunk);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

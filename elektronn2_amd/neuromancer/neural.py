@@ -531,10 +531,27 @@ class UpConv(Conv):
         nb = plan.ctx.upconv_ws_bytes(self.n_f, self.parent.shape['f'], self.pool_shape, xs)
         plan.scratch[self, 'ws'] = plan.empty_flat(nb // 4 + 64)
 
+    def _tune_sigs(self, plan):
+        """the GEMMs inside e2_upconv3d_fwd / _bwd: forward M = Cout*R, K = Cin over the INPUT
+        positions; data gradient the transpose; weight gradient from unpadded rows (the
+        LDS-staged kernel: WK 0 / 4 candidates only)"""
+        x = plan.out[self.parent]
+        cin, R = self.parent.shape['f'], int(np.prod(self.pool_shape))
+        sp = tuple(x.shape[2:])
+        key = (self.n_f, cin) + tuple(self.pool_shape) + sp + (x.stride(3),)
+        cw = [c for c in autotune.wgrad_candidates(self.n_f * R, cin, (1, 1, 1), sp)
+              if c.split(',')[2] in ('0', '4')]
+        return dict(fwd=((3,) + key, autotune.igemm_candidates(self.n_f * R, cin, (1, 1, 1), sp)),
+                    dgrad=((4,) + key, autotune.igemm_candidates(cin, self.n_f * R, (1, 1, 1), sp)),
+                    wgrad=((5,) + key, cw))
+
     def _plan_fwd(self, plan):
-        plan.ctx.upconv3d_fwd(plan.out[self.parent], plan.param(self.w), plan.param(self.b),
-                              self.pool_shape, self.activation_func, plan.out[self],
-                              plan.scratch[self, 'ws'])
+        sig, cands = self._tune_sigs(plan)['fwd']
+        plan.tuned('igemm', sig, cands,
+                   lambda: plan.ctx.upconv3d_fwd(plan.out[self.parent], plan.param(self.w),
+                                                 plan.param(self.b), self.pool_shape,
+                                                 self.activation_func, plan.out[self],
+                                                 plan.scratch[self, 'ws']))
 
     def _plan_bwd(self, plan):
         ctx = plan.ctx
@@ -543,9 +560,17 @@ class UpConv(Conv):
         if plan.needs_grad(self.parent):
             dst, first = plan.grad_slot(self.parent)
             dx = dst if first else plan.tmp_like(dst)
-        ctx.upconv3d_bwd(plan.out[self.parent], plan.param(self.w), plan.out[self],
-                         plan.grad[self], self.pool_shape, self.activation_func, dx,
-                         plan.pgrad(self.w), plan.pgrad(self.b), plan.scratch[self, 'ws'])
+        # one call = space-to-depth + data-gradient GEMM + weight-gradient GEMM, all of them
+        # overwriting their outputs (idempotent): each GEMM's tiling is tuned with the
+        # other at its best known one
+        sigs = self._tune_sigs(plan)
+
+        def run():
+            ctx.upconv3d_bwd(plan.out[self.parent], plan.param(self.w), plan.out[self],
+                             plan.grad[self], self.pool_shape, self.activation_func, dx,
+                             plan.pgrad(self.w), plan.pgrad(self.b), plan.scratch[self, 'ws'])
+        plan.tuned('igemm', sigs['dgrad'][0], sigs['dgrad'][1] if dx is not None else [],
+                   lambda: plan.tuned('wgrad', sigs['wgrad'][0], sigs['wgrad'][1], run))
         if dx is not None and not first:
             ctx.copy5(dx, dst, accumulate=True)
 
