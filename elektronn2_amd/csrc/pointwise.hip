@@ -69,26 +69,29 @@ __global__ void fill_flat_kernel(float* p, size_t n, float v) {
     p[i] = v;
 }
 
-__global__ void fill_view_kernel(View5 v, float val) {
+// (32-bit index math with magic-number division: 64-bit % and / made these ALU-bound)
+__global__ void fill_view_kernel(View5 v, float val, FastDiv dw, FastDiv dh) {
   // grid: (ceil(d*h*w/256), c, n)
-  const long S = (long)v.d * v.h * v.w;
-  const long s = blockIdx.x * 256L + threadIdx.x;
+  const unsigned S = (unsigned)v.d * v.h * v.w;
+  const unsigned s = blockIdx.x * 256u + threadIdx.x;
   if (s >= S) return;
-  const int x = (int)(s % v.w);
-  const long t = s / v.w;
-  const int y = (int)(t % v.h), z = (int)(t / v.h);
-  v.p[vidx(v, blockIdx.z, blockIdx.y, z, y, x)] = val;
+  const unsigned t = fdiv(s, dw);
+  const unsigned x = s - t * v.w;
+  const unsigned z = fdiv(t, dh);
+  const unsigned y = t - z * v.h;
+  v.p[vidx(v, blockIdx.z, blockIdx.y, (int)z, (int)y, (int)x)] = val;
 }
 
-__global__ void copy_view_kernel(View5 src, View5 dst, int accumulate) {
-  const long S = (long)src.d * src.h * src.w;
-  const long s = blockIdx.x * 256L + threadIdx.x;
+__global__ void copy_view_kernel(View5 src, View5 dst, int accumulate, FastDiv dw, FastDiv dh) {
+  const unsigned S = (unsigned)src.d * src.h * src.w;
+  const unsigned s = blockIdx.x * 256u + threadIdx.x;
   if (s >= S) return;
-  const int x = (int)(s % src.w);
-  const long t = s / src.w;
-  const int y = (int)(t % src.h), z = (int)(t / src.h);
-  const float v = src.p[vidx(src, blockIdx.z, blockIdx.y, z, y, x)];
-  float* d = dst.p + vidx(dst, blockIdx.z, blockIdx.y, z, y, x);
+  const unsigned t = fdiv(s, dw);
+  const unsigned x = s - t * src.w;
+  const unsigned z = fdiv(t, dh);
+  const unsigned y = t - z * src.h;
+  const float v = src.p[vidx(src, blockIdx.z, blockIdx.y, (int)z, (int)y, (int)x)];
+  float* d = dst.p + vidx(dst, blockIdx.z, blockIdx.y, (int)z, (int)y, (int)x);
   *d = accumulate ? (*d + v) : v;
 }
 
@@ -658,7 +661,9 @@ static void launch_pool_bwd_fixed(e2_ctx* ctx, const View5& vd, const View5& vy,
 int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
   if (int rc = check_view(t, "fill_view")) return rc;
   View5 v = mk(t);
-  hipLaunchKernelGGL(fill_view_kernel, grid_for(v), dim3(256), 0, ctx->stream, v, value);
+  E2_REQUIRE((long)v.d * v.h * v.w < (1L << 31), "fill_view: channel too large");
+  hipLaunchKernelGGL(fill_view_kernel, grid_for(v), dim3(256), 0, ctx->stream, v, value,
+                     mk_div(v.w), mk_div(v.h));
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -722,8 +727,9 @@ extern "C" int e2_copy5(e2_ctx* ctx, const e2_tensor5* src, const e2_tensor5* ds
                  src->h == dst->h && src->w == dst->w,
              "e2_copy5: size mismatch");
   View5 s = mk(src), d = mk(dst);
+  E2_REQUIRE((long)s.d * s.h * s.w < (1L << 31), "e2_copy5: channel too large");
   hipLaunchKernelGGL(copy_view_kernel, grid_for(s), dim3(256), 0, ctx->stream, s, d,
-                     accumulate);
+                     accumulate, mk_div(s.w), mk_div(s.h));
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
