@@ -476,3 +476,43 @@ def test_pack_multi_equals_single_pack(ctx):
             ref.fill_(float("nan"))
         for w in ws:
             w.mul_(-0.5)
+
+
+def test_fill_multi_and_skip_zero_fill(ctx):
+    """e2_fill_multi zeroes many regions in one launch; a split-K conv reports the region it
+    zero-filled (e2_conv_last_zero_fill) and, told that the output is already zero
+    (e2_set_skip_zero_fill), accumulates onto it without its own fill"""
+    a = torch.full((1000,), 3.0, device="cuda"); b = torch.full((77,), 4.0, device="cuda")
+    c = torch.full((5,), 5.0, device="cuda")
+    ptrs = torch.tensor([a.data_ptr(), b[7:].data_ptr()], dtype=torch.int64, device="cuda")
+    cnts = torch.tensor([1000, 60], dtype=torch.int64, device="cuda")
+    ctx.fill_multi(ptrs, cnts, 2, 0.0)
+    assert float(a.abs().sum()) == 0 and float(b[7:67].abs().sum()) == 0
+    assert float(b[:7].sum()) == 28 and float(b[67:].sum()) == 40 and float(c.sum()) == 25
+
+    rng = np.random.RandomState(9)
+    x = rng.rand(1, 24, 4, 9, 11).astype(np.float32)
+    w = (rng.randn(20, 24, 2, 3, 3) / 10).astype(np.float32)
+    ref = O.conv3d_fwd(x, w)
+    ws = torch.empty(ctx.conv_ws_bytes(20, 24, (2, 3, 3)) // 4 + 64, device="cuda")
+    ctx.conv3d_pack(dev(w), 0, ws)
+    os.environ["E2_IGEMM_FORCE"] = "2,1,8,4"          # split-K 4: atomics onto a zeroed output
+    try:
+        y = torch.full(ref.shape, float("nan"), device="cuda")
+        ctx.conv3d_fwd_packed(dev(x), ws, 20, (2, 3, 3), y)
+        ptr, n = ctx.conv_last_zero_fill()
+        assert ptr == y.data_ptr() and n == y.numel()
+        assert relerr(y, ref) < TOL
+        ctx.set_skip_zero_fill(True)
+        try:
+            y.fill_(1.0)                               # "already zero" is the caller's promise:
+            ctx.conv3d_fwd_packed(dev(x), ws, 20, (2, 3, 3), y)   # ... the launch only adds
+        finally:
+            ctx.set_skip_zero_fill(False)
+        assert relerr(y - 1.0, ref) < 1e-4
+        os.environ["E2_IGEMM_FORCE"] = "2,1,8,1"      # no split-K: nothing to zero
+        ctx.conv3d_fwd_packed(dev(x), ws, 20, (2, 3, 3), y)
+        assert ctx.conv_last_zero_fill()[1] == 0
+        assert relerr(y, ref) < TOL
+    finally:
+        del os.environ["E2_IGEMM_FORCE"]
