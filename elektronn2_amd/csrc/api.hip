@@ -311,8 +311,10 @@ extern "C" size_t e2_upconv3d_workspace_bytes(int cout, int cin, int pz, int py,
                                               int n, int d, int h, int w) {
   const int R = pz * py * px;
   // packed weights + the space-to-depth image of dpre used by the backward
+  // (+ alignment of the image and the 128 readable bytes the direct weight-gradient
+  // kernel wants behind its last element)
   return sizeof(float) * (up_pack_floats(cout, cin, R) +
-                          (size_t)n * cout * R * d * h * w) + 256;
+                          (size_t)n * cout * R * d * h * w) + 512;
 }
 
 extern "C" int e2_upconv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
@@ -391,7 +393,9 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
     g.x = x->ptr; g.dy = s2d; g.dw = dw;
     g.N = x->n; g.Cin = cin; g.Cout = cout * R;
     g.kd = g.kh = g.kw = 1;
-    g.dy_padded = 0;
+    // 1x1x1 taps: the dense space-to-depth image IS its own zero-padded form (no border,
+    // no gap columns), and the workspace leaves 128 B behind it: the direct kernel applies
+    g.dy_padded = 1;
     g.Do = x->d; g.Ho = x->h; g.Wo = x->w;
     g.xsN = x->sn; g.xsC = x->sc; g.xsZ = x->sd; g.xsY = x->sh;
     g.dsN = (long)cout * R * S; g.dsC = S; g.dsZ = (long)x->h * x->w; g.dsY = x->w;

@@ -533,14 +533,13 @@ class UpConv(Conv):
 
     def _tune_sigs(self, plan):
         """the GEMMs inside e2_upconv3d_fwd / _bwd: forward M = Cout*R, K = Cin over the INPUT
-        positions; data gradient the transpose; weight gradient from unpadded rows (the
-        LDS-staged kernel: WK 0 / 4 candidates only)"""
+        positions; data gradient the transpose; weight gradient over the dense space-to-depth
+        image (1x1x1 taps: it is its own padded form, so the direct kernel applies)"""
         x = plan.out[self.parent]
         cin, R = self.parent.shape['f'], int(np.prod(self.pool_shape))
         sp = tuple(x.shape[2:])
         key = (self.n_f, cin) + tuple(self.pool_shape) + sp + (x.stride(3),)
-        cw = [c for c in autotune.wgrad_candidates(self.n_f * R, cin, (1, 1, 1), sp)
-              if c.split(',')[2] in ('0', '4')]
+        cw = autotune.wgrad_candidates(self.n_f * R, cin, (1, 1, 1), sp)
         return dict(fwd=((3,) + key, autotune.igemm_candidates(self.n_f * R, cin, (1, 1, 1), sp)),
                     dgrad=((4,) + key, autotune.igemm_candidates(cin, self.n_f * R, (1, 1, 1), sp)),
                     wgrad=((5,) + key, cw))

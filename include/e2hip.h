@@ -58,7 +58,7 @@ int  e2_version(void);
  * gradient kernels (tap rows of 1, 3, 4 or 5) and of e2_conv3d_wgrad_pad are rounded
  * to bf16 (nearest even) on their way into the matrix core; products and sums stay f32;
  * tensors in memory stay f32.  The first-layer, head, generic-width kernels and the plain
- * e2_conv3d_wgrad / UpConv weight-gradient entry points always compute in f32.  Not to be changed while a graph is being captured. */
+ * e2_conv3d_wgrad entry point always compute in f32 (UpConv follows the setting).  Not to be changed while a graph is being captured. */
 int  e2_set_mfma_dtype(e2_ctx* ctx, int dtype);
 int  e2_get_mfma_dtype(const e2_ctx* ctx);
 
