@@ -1,0 +1,36 @@
+"""soak: N training steps of neuro3d_lite@183 on random patches of a synthetic volume
+(device-resident sampler, warp + grey augmentation), checking that the loss stays finite
+and falls and that the captured graphs keep replaying.  usage: soak.py [steps] [--mfma bf16]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scipy.ndimage as ndi
+import elektronn2_amd
+from elektronn2_amd import nets
+from elektronn2_amd.data import PatchSampler
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else 2000
+if '--mfma' in sys.argv:
+    elektronn2_amd.set_mfma_dtype(sys.argv[sys.argv.index('--mfma') + 1])
+np.random.seed(0)
+model = nets.neuro3d_lite((None, 1, 23, 183, 183))
+model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+rng = np.random.RandomState(0)
+vol = ndi.gaussian_filter(rng.rand(60, 400, 400).astype(np.float32), 3.0)
+vol = ((vol - vol.min()) / (vol.max() - vol.min()))[None]
+lab = (vol > np.median(vol)).astype(np.float32)
+tn = model.target_node
+smp = PatchSampler([vol], [lab], model.input_node.shape.spatial_shape, tn.shape.strides,
+                   tn.shape.offsets, seed=1)
+t0 = time.time()
+losses = []
+for i in range(steps):
+    d, t = smp.getbatch(1, 'train', grey_augment_channels=[0], warp=0.5)
+    losses.append(float(model.trainingstep(d, t, optimiser='Adam')[0]))
+    if (i + 1) % 500 == 0:
+        print("step %d  loss (mean of last 100) %.4f  %.2f ms/step wall" % (
+            i + 1, np.mean(losses[-100:]), (time.time() - t0) / (i + 1) * 1e3), flush=True)
+P = model.P.cpu().numpy()
+assert np.isfinite(losses).all() and np.isfinite(P).all()
+assert np.mean(losses[-100:]) < 0.7 * np.mean(losses[:20]), (np.mean(losses[:20]), np.mean(losses[-100:]))
+print("soak ok: %d steps, loss %.4f -> %.4f" % (steps, np.mean(losses[:20]), np.mean(losses[-100:])))
