@@ -1,5 +1,5 @@
-// conv_first.hip -- the FIRST layer of the neuro3d nets: Cin = 1, kd = 1,
-// (kh,kw) taps, pooling (1,py,px), bias, activation -- fused.
+// conv_first.hip -- the FIRST layer of the neuro3d nets / the U-Net stem: Cin = 1, kd = 1,
+// (kh,kw) taps, pooling (1,py,px) (or none), bias, activation -- fused.
 //
 // Reference ops: Conv._make_output conv -> pool -> +b -> act (neural.py:662-712)
 // on the raw input, and T.grad of it wrt w and b (model.py:182).  With one
@@ -125,7 +125,7 @@ __device__ __forceinline__ void ff_butterfly16(float (&v)[16], int lane) {
 template <int KH, int KW, int PY, int PX>
 __global__ __launch_bounds__(256) void first_bwd_kernel(First p, float* __restrict__ part) {
   constexpr int T = KH * KW;
-  static_assert(T == 16 || T == 36, "tap count");
+  static_assert(T == 9 || T == 16 || T == 36, "tap count");
   __shared__ float red[2][16][T + 1];
   const int lane_x = threadIdx.x & 31, row = threadIdx.x >> 5;
   const int lane = threadIdx.x & 63;
@@ -215,6 +215,7 @@ static int first_supported(int kd, int kh, int kw, int pz, int py, int px) {
   if (kd != 1 || pz != 1) return 0;
   if (kh == 4 && kw == 4 && py == 2 && px == 2) return 1;
   if (kh == 6 && kw == 6 && py == 2 && px == 2) return 2;
+  if (kh == 3 && kw == 3 && py == 1 && px == 1) return 3;     // U-Net stem: no pooling
   return 0;
 }
 
@@ -253,8 +254,10 @@ extern "C" int e2_conv1_pool_act_fwd(e2_ctx* ctx, const e2_tensor5* x, const flo
   const int grid = (int)std::min<long>(nTiles, ctx->num_cu * 8);
   if (v == 1)
     hipLaunchKernelGGL((first_fwd_kernel<4, 4, 2, 2>), dim3(grid), dim3(256), 0, ctx->stream, p, (int)nTiles);
-  else
+  else if (v == 2)
     hipLaunchKernelGGL((first_fwd_kernel<6, 6, 2, 2>), dim3(grid), dim3(256), 0, ctx->stream, p, (int)nTiles);
+  else
+    hipLaunchKernelGGL((first_fwd_kernel<3, 3, 1, 1>), dim3(grid), dim3(256), 0, ctx->stream, p, (int)nTiles);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -285,8 +288,10 @@ extern "C" int e2_conv1_pool_act_bwd(e2_ctx* ctx, const e2_tensor5* x, const flo
   float* part = (float*)ws;
   if (v == 1)
     hipLaunchKernelGGL((first_bwd_kernel<4, 4, 2, 2>), dim3((int)nTiles), dim3(256), 0, ctx->stream, p, part);
-  else
+  else if (v == 2)
     hipLaunchKernelGGL((first_bwd_kernel<6, 6, 2, 2>), dim3((int)nTiles), dim3(256), 0, ctx->stream, p, part);
+  else
+    hipLaunchKernelGGL((first_bwd_kernel<3, 3, 1, 1>), dim3((int)nTiles), dim3(256), 0, ctx->stream, p, part);
   E2_CHECK_HIP(hipGetLastError());
   const int T = kh * kw, total = p.Cout * (T + 1);
   const int slices = (int)std::min<long>(nTiles, 64);

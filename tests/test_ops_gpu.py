@@ -387,14 +387,17 @@ def test_graph_capture_replay(ctx):
         ctx.set_stream(old)
 
 
-@pytest.mark.parametrize("k,sp", [((1, 4, 4), (3, 23, 71)), ((1, 6, 6), (2, 25, 77)), ((1, 4, 4), (1, 19, 11))])
-def test_fused_first_layer(ctx, k, sp):
-    """csrc/conv_first.hip: conv(1 ch) -> pool(1,2,2) -> +b -> relu, fwd and bwd (recompute)."""
+@pytest.mark.parametrize("k,sp,pool", [((1, 4, 4), (3, 23, 71), (1, 2, 2)),
+                                       ((1, 6, 6), (2, 25, 77), (1, 2, 2)),
+                                       ((1, 4, 4), (1, 19, 11), (1, 2, 2)),
+                                       ((1, 3, 3), (3, 21, 70), (1, 1, 1))])
+def test_fused_first_layer(ctx, k, sp, pool):
+    """csrc/conv_first.hip: conv(1 ch) -> pool(1,2,2) or none -> +b -> relu, fwd and bwd
+    (recompute)."""
     rng = np.random.RandomState(21)
     x = rng.rand(2, 1, *sp).astype(np.float32)
     w = (rng.randn(20, 1, *k) / 3).astype(np.float32)
     b = (rng.randn(20) / 4).astype(np.float32)
-    pool = (1, 2, 2)
     assert ctx.conv1_supported(1, k, pool) and not ctx.conv1_supported(2, k, pool)
     out_ref, cache = O.conv_node_fwd(x, w, b, pool, 'relu')
     out = torch.full(out_ref.shape, float("nan"), device="cuda")
