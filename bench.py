@@ -42,7 +42,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak 
 # --pmc WRITE_SIZE runs of this script, profiles/r01_e_pmc_traffic.csv):
 # 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
 # It cannot be measured inside the timed run; null for workloads not profiled.
-PMC_TRAFFIC_BYTES = {"lite183": (2 * 826.2 + 414.4) * 1024 * 1024}
+PMC_TRAFFIC_BYTES = {"lite183": (2 * 817.6 + 414.3) * 1024 * 1024}
 
 
 def algorithmic_gflop(model):
