@@ -9,9 +9,10 @@ the process and in ``$E2HIP_TUNE_CACHE`` (default: ``.tune_cache.json`` next to 
 file, git-ignored);
 ``elektronn2_amd/tuned.json`` ships the choices for the BASELINE workloads.
 
-Tilings are passed to the library through the E2_IGEMM_FORCE / E2_WGRAD_FORCE
-environment overrides, which the library reads at every launch; a launch
-captured into a hipGraph keeps whatever tiling was active at capture time.
+Tilings reach the library through the C ABI (``e2_set_tiling`` /
+``Context.set_tiling``), per context, around each launch; a launch captured into a
+hipGraph keeps whatever tiling was active at capture time.  ``force(kind, cfg)`` pins a
+tiling for every problem of a kind (tests, experiments); it outranks the cache.
 """
 from __future__ import annotations
 
@@ -136,6 +137,17 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
     return sorted(set(cands))
 
 
+_forced = {}
+
+
+def force(kind, cfg):
+    """pin ('igemm' | 'wgrad') launches to one tiling string; None lifts the pin"""
+    if cfg:
+        _forced[kind] = cfg
+    else:
+        _forced.pop(kind, None)
+
+
 def _time(ctx, fn, iters=4):
     fn()
     e0, e1 = ctx.event(), ctx.event()
@@ -153,46 +165,48 @@ def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None):
     accumulating); when tuning ran, the result is produced by one final
     ``fn_tune`` call instead of ``fn``.  Returns the tiling string used."""
     global _dirty
-    env = "E2_IGEMM_FORCE" if kind == "igemm" else "E2_WGRAD_FORCE"
+    ft = fn_tune if fn_tune is not None else fn
+    if kind in _forced:
+        ctx.set_tiling(kind, _forced[kind])
+        try:
+            fn()
+        finally:
+            ctx.set_tiling(kind, None)
+        return _forced[kind]
     # the bf16 operand form of a kernel has its own best tiling
     suffix = "_bf16" if getattr(ctx, "mfma_dtype", "f32") == "bf16" else ""
     key = "%s%s|%s" % (kind, suffix, ",".join(str(int(v)) for v in sig))
     cache = _load()
     best = cache.get(key)
     tuned_now = False
-    ft = fn_tune if fn_tune is not None else fn
     if best is None and enabled() and allow_tune:
-        old = os.environ.pop(env, None)
         tuned_now = True
+        results = []
         try:
-            results = []
             try:
-                t = _time(ctx, ft)
-                results.append((t, ""))
+                results.append((_time(ctx, ft), ""))
             except E2Error:
                 pass
             for c in cands:
-                os.environ[env] = c
+                ctx.set_tiling(kind, c)
                 try:
                     results.append((_time(ctx, ft), c))
                 except E2Error:
                     continue
-            os.environ.pop(env, None)
-            if results:
-                results.sort()
-                best = results[0][1]
-                cache[key] = best
-                _dirty = True
         finally:
-            if old is not None:
-                os.environ[env] = old
+            ctx.set_tiling(kind, None)
+        if results:
+            results.sort()
+            best = results[0][1]
+            cache[key] = best
+            _dirty = True
     final = ft if tuned_now else fn
     if best:
-        os.environ[env] = best
+        ctx.set_tiling(kind, best)
         try:
             final()
         finally:
-            os.environ.pop(env, None)
+            ctx.set_tiling(kind, None)
     else:
         final()
     return best

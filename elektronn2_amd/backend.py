@@ -101,6 +101,7 @@ def _load():
         "e2_set_skip_zero_fill": (C.c_int, [vp, C.c_int]),
         "e2_conv_last_zero_fill": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
+        "e2_set_tiling": (C.c_int, [vp, C.c_int, C.c_char_p]),
         "e2_get_mfma_dtype": (C.c_int, [vp]),
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
@@ -429,6 +430,13 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(_lib.e2_conv_last_zero_fill(self.h, C.byref(p), C.byref(n)), "e2_conv_last_zero_fill")
         return (p.value or 0), int(n.value)
+
+    def set_tiling(self, kind, cfg):
+        """force the tiling of the following 'igemm' ("MT,NT,CC,SK": conv fwd / dgrad /
+        UpConv) or 'wgrad' ("MT,NT,WK,BP,PS") launches of this context; None / '' returns
+        the choice to the library's cost model (e2_set_tiling)"""
+        code = {'igemm': 0, 'wgrad': 1}[kind]
+        _chk(_lib.e2_set_tiling(self.h, code, (cfg or "").encode()), "e2_set_tiling")
 
     def set_mfma_dtype(self, dtype):
         """'f32' (default) or 'bf16': operand rounding of the conv GEMMs (f32 sums)"""

@@ -50,6 +50,7 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->skip_zero_fill = 0;
   c->last_fill_ptr = nullptr;
   c->last_fill_n = 0;
+  c->tiling[0][0] = c->tiling[1][0] = 0;
   for (int i = 0; i < 32; ++i) c->fork_ev[i] = nullptr;
   if (hipMalloc(&c->zeros, 1024) != hipSuccess || hipMemset(c->zeros, 0, 1024) != hipSuccess) {
     delete c;
@@ -57,6 +58,20 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
     return 1;
   }
   *out = c;
+  return 0;
+}
+
+extern "C" int e2_set_tiling(e2_ctx* ctx, int kind, const char* cfg) {
+  E2_REQUIRE(ctx, "e2_set_tiling: null context");
+  E2_REQUIRE(kind == E2_TILING_IGEMM || kind == E2_TILING_WGRAD, "e2_set_tiling: unknown kind %d", kind);
+  if (!cfg) cfg = "";
+  E2_REQUIRE(strlen(cfg) < sizeof(ctx->tiling[0]), "e2_set_tiling: configuration string too long");
+  if (cfg[0]) {
+    int v[5], n = sscanf(cfg, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+    E2_REQUIRE(n == (kind == E2_TILING_IGEMM ? 4 : 5), "e2_set_tiling: '%s' is not %s", cfg,
+               kind == E2_TILING_IGEMM ? "\"MT,NT,CC,SK\"" : "\"MT,NT,WK,BP,PS\"");
+  }
+  strcpy(ctx->tiling[kind], cfg);
   return 0;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include "../../include/e2hip.h"
 
@@ -18,7 +19,22 @@ struct e2_ctx {
   int skip_zero_fill;  // e2_set_skip_zero_fill: split-K outputs were zeroed by the caller
   float* last_fill_ptr;     // flat region the last conv launch zero-filled (n = 0: none)
   size_t last_fill_n;
+  char tiling[2][64];       // e2_set_tiling: forced tiling of the igemm / wgrad launches ("" = cost model)
 };
+
+// Debug switches (timing ablations, in-kernel stamps, verbose launch log) are compiled in
+// only with -DE2_DEBUG_ENV (make DEBUG_ENV=1): the release library never reads the process
+// environment -- tilings arrive through e2_set_tiling().
+#ifdef E2_DEBUG_ENV
+#include <stdlib.h>
+static inline const char* e2_dbg_env(const char* name) { return getenv(name); }
+#else
+static inline const char* e2_dbg_env(const char*) { return nullptr; }
+#endif
+static inline int e2_dbg_env_int(const char* name) {
+  const char* v = e2_dbg_env(name);
+  return v ? atoi(v) : 0;
+}
 
 void e2_set_error(const char* fmt, ...);
 

@@ -204,7 +204,7 @@ extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs
   E2_REQUIRE(ctx && jobs_dev && njobs > 0 && njobs < 65536, "pack_multi: bad argument");
   // (tap volumes whose tile would not fit the static LDS buffer -- beyond 5x5x5 -- are not
   // used by any net here; such a job list takes the plain gather kernel)
-  if (getenv("E2_PACK_GATHER"))
+  if (e2_dbg_env("E2_PACK_GATHER"))
     hipLaunchKernelGGL(pack_multi_gather_kernel, dim3(256, njobs), dim3(256), 0, ctx->stream,
                        (const PackJobDev*)jobs_dev);
   else
@@ -264,8 +264,8 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   const bool fast = has_fast_kw(a.kw);
   IgemmCfg best{0, 0, 0, 0};
   double bestCost = 1e300;
-  const char* force = getenv("E2_IGEMM_FORCE");
-  if (force) {
+  const char* force = ctx->tiling[E2_TILING_IGEMM];
+  if (force[0]) {
     IgemmCfg f{0, 0, 0, 0};
     if (sscanf(force, "%d,%d,%d,%d", &f.MT, &f.NT, &f.CC, &f.SK) == 4) { *ok = 1; return f; }
   }
@@ -351,7 +351,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   p.Lpad = span_lpad(a, BN);
   p.CC = c.CC;
   p.Din = a.Do + a.kd - 1;
-  p.dbg = getenv("E2_IGEMM_DBG") ? atoi(getenv("E2_IGEMM_DBG")) : 0;
+  p.dbg = e2_dbg_env_int("E2_IGEMM_DBG");
   p.N = a.N;
   p.nPT = e2_cdiv(p.Q, BN);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), c.MT);
@@ -368,7 +368,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   // wide epilogue (fast path): dense output rows, plain stores
   const size_t tile_lds = (size_t)4 * 16 * c.MT * (16 * c.NT + 4) * 4;
   p.wide = (fast && p.splitK == 1 && a.upz * a.upy * a.upx == 1 && a.osY == a.Wo &&
-            std::max(lds, tile_lds) <= 160 * 1024 && !getenv("E2_IGEMM_NARROW")) ? 1 : 0;
+            std::max(lds, tile_lds) <= 160 * 1024 && !e2_dbg_env("E2_IGEMM_NARROW")) ? 1 : 0;
   if (p.wide) lds = std::max(lds, tile_lds);
   p.bias = a.bias; p.act = a.act;
   E2_REQUIRE(!a.bias || p.wide, "igemm: the fused bias/act epilogue needs dense output rows, a "
@@ -397,7 +397,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   // debug: per-work-group timeline stamps (fast path only), printed after a sync
   p.stamps = nullptr;
   static unsigned long long* stamp_buf = nullptr;
-  const bool want_stamps = getenv("E2_IGEMM_STAMPS") != nullptr && fast && !ctx->capturing;
+  const bool want_stamps = e2_dbg_env("E2_IGEMM_STAMPS") != nullptr && fast && !ctx->capturing;
   if (want_stamps) {
     if (!stamp_buf) E2_CHECK_HIP(hipMalloc(&stamp_buf, 8 * sizeof(unsigned long long) * 65536));
     E2_REQUIRE(grid <= 65536, "igemm stamps: grid too large");
@@ -406,7 +406,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   }
   // 1x1 taps: four channel groups per pipeline step when the chunk allows it
   const int GU = (fast && p.THW == 1 && c.CC % 16 == 0) ? 4 : 1;
-  if (getenv("E2_VERBOSE"))
+  if (e2_dbg_env("E2_VERBOSE"))
     fprintf(stderr, "[e2] igemm%s Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d CC=%d SK=%d GU=%d grid=%ld lds=%zu\n",
             (ctx->mfma_bf16 && fast) ? "(bf16)" : "", a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, GU, grid, lds);
   int rc;

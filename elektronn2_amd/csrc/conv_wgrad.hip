@@ -452,8 +452,8 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
   WCfg best{0, 0, 0, 0, 0};
   double bestCost = 1e300;
   const double dw_bytes = 4.0 * a.Cout * (double)NTOT;
-  const char* force = getenv("E2_WGRAD_FORCE");
-  if (force) {
+  const char* force = ctx->tiling[E2_TILING_WGRAD];
+  if (force[0]) {
     WCfg f{0, 0, 0, 0, 0};
     if (sscanf(force, "%d,%d,%d,%d,%d", &f.MT, &f.NT, &f.WK, &f.BP, &f.PS) == 5) { *ok = 1; return f; }
   }
@@ -580,16 +580,16 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   p.Din = a.Do + a.kd - 1;
   p.N = a.N;
   p.divWo = mk_divw((unsigned)a.Wo);
-  p.dbg = getenv("E2_WGRAD_DBG") ? atoi(getenv("E2_WGRAD_DBG")) : 0;
+  p.dbg = e2_dbg_env_int("E2_WGRAD_DBG");
   p.bf16 = (ctx->mfma_bf16 && a.dy_padded) ? 1 : 0;
   size_t lds = 2 * (size_t)p.bufFloats * 4;
-  if (getenv("E2_WGRAD_LDSPAD")) lds += (size_t)atoi(getenv("E2_WGRAD_LDSPAD"));
+  lds += (size_t)e2_dbg_env_int("E2_WGRAD_LDSPAD");
   E2_REQUIRE(lds <= 160 * 1024, "wgrad: tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
   if (!a.accumulate)
     if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.NTOT, 0.f)) return rc;
-  if (getenv("E2_VERBOSE"))
+  if (e2_dbg_env("E2_VERBOSE"))
     fprintf(stderr, "[e2] wgrad%s Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d WK=%d BP=%d PS=%d grid=%ld lds=%zu\n",
             p.bf16 ? "(bf16)" : "", a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.WK, c.BP, p.nPS, grid, lds);
   return dispatch_w(ctx, p, c.MT, c.NT, c.BP, c.WK, (int)grid, lds);

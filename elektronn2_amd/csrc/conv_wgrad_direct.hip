@@ -647,13 +647,13 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   p.Din = a.Do + a.kd - 1;
   p.N = a.N;
   p.divDsY = mk_divd((unsigned)a.dsY);
-  p.dbg = getenv("E2_WGRAD_DBG") ? atoi(getenv("E2_WGRAD_DBG")) : 0;
+  p.dbg = e2_dbg_env_int("E2_WGRAD_DBG");
   const size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "wgrad(direct): tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
   p.stamps = nullptr;
   static unsigned long long* stamp_buf = nullptr;
-  const bool want_stamps = getenv("E2_WGRAD_STAMPS") != nullptr && !ctx->capturing && grid <= 65536;
+  const bool want_stamps = e2_dbg_env("E2_WGRAD_STAMPS") != nullptr && !ctx->capturing && grid <= 65536;
   if (want_stamps) {
     if (!stamp_buf) E2_CHECK_HIP(hipMalloc(&stamp_buf, 8 * sizeof(unsigned long long) * 65536));
     E2_CHECK_HIP(hipMemsetAsync(stamp_buf, 0, 8 * sizeof(unsigned long long) * grid, ctx->stream));
@@ -662,7 +662,7 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   E2_REQUIRE(grid < (1L << 31), "wgrad: grid too large");
   if (!a.accumulate)
     if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.NTOT, 0.f)) return rc;
-  if (getenv("E2_VERBOSE"))
+  if (e2_dbg_env("E2_VERBOSE"))
     fprintf(stderr, "[e2] wgrad(direct%s) Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MT=%d NT=%d BP=%d WK=%d PS=%d grid=%ld lds=%zu\n",
             ctx->mfma_bf16 ? ", bf16" : "", a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, MT, NT, BP, WK, p.nPS, grid, lds);
   int rc = 2;

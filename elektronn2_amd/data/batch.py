@@ -39,8 +39,39 @@ class PatchSampler(object):
     centred in their images.  ``patch_size`` = the input node's spatial shape,
     ``strides`` / ``offsets`` = the target node's (cnndata.py:134-140)."""
 
+    @classmethod
+    def from_nodes(cls, input_node, target_node=None, data=None, targets=None,
+                   cube_prios=None, valid_cubes=None, aniso_factor=2, target_vec_ix=None,
+                   target_discrete_ix=None, seed=None, border_mode='crop', d_path=None,
+                   l_path=None, d_files=None, l_files=None, h5stream=False, zxy=True):
+        """The reference constructor protocol (``BatchCreatorImage(input_node,
+        target_node, **data_init_kwargs)``, cnndata.py:110-176): the geometry is read from
+        the nodes -- ``patch_size = input_node.shape.spatial_shape``, ``strides`` /
+        ``offsets`` of ``target_node.shape`` (cnndata.py:134-140) -- so a reference
+        config's ``data_init_kwargs`` dict drives it unchanged.  The cubes are given as
+        in-memory arrays (``data`` / ``targets``: lists of (f, z, x, y)); the file keys of
+        the dict (``d_path``, ``l_path``, ``d_files``, ``l_files``, ``h5stream``, ``zxy``,
+        ``border_mode``) belong to the HDF5 loader, which is outside the hot path, and are
+        accepted and ignored."""
+        if target_node is None:
+            raise ValueError("from_nodes: a target node is required (img-img mode)")
+        if data is None or targets is None:
+            raise ValueError("from_nodes: pass the cubes as data=[...], targets=[...] "
+                             "(HDF5 loading is not part of this build)")
+        if len(data) != len(targets):
+            raise ValueError("d_files and l_files must be lists of same length!")
+        if input_node.shape.ndim != target_node.shape.ndim:
+            raise ValueError("img-scalar mode is outside the hot path")
+        if target_vec_ix is not None:
+            raise NotImplementedError("vector targets (target_vec_ix) are outside the hot path")
+        return cls(data, targets, input_node.shape.spatial_shape, target_node.shape.strides,
+                   target_node.shape.offsets, aniso_factor=aniso_factor,
+                   target_discrete_ix=target_discrete_ix, seed=seed,
+                   valid=valid_cubes if valid_cubes is not None else (),
+                   cube_prios=cube_prios)
+
     def __init__(self, data, targets, patch_size, strides, offsets, aniso_factor=2,
-                 target_discrete_ix=None, seed=None, valid=()):
+                 target_discrete_ix=None, seed=None, valid=(), cube_prios=None):
         from ..neuromancer.plan import get_ctx
         self.ctx = get_ctx()
         dev = self.ctx.device
@@ -55,7 +86,10 @@ class PatchSampler(object):
         self.aniso_factor = aniso_factor
         self.target_discrete_ix = target_discrete_ix
         self.rng = np.random.RandomState(seed)
-        w = np.array([self.t[i][0].numel() for i in self.train], np.float64)
+        if cube_prios is None:               # proportional to the cube sizes, cnndata.py:535-541
+            w = np.array([self.t[i][0].numel() for i in self.train], np.float64)
+        else:
+            w = np.array([cube_prios[i] for i in self.train], np.float64)
         self._sampling_weight = np.hstack((0, np.cumsum(w / w.sum())))   # cnndata.py:576-583
         self.n_failed_warp = 0
         self.n_successful_warp = 0

@@ -81,6 +81,46 @@ def unet3d_lite(in_sh=(None, 1, 22, 140, 140), name=None):
     return model
 
 
+def unet3d(in_sh=(None, 1, 116, 132, 132), name=None):
+    """examples/unet3d.py:61-100 (BASELINE configs[4]): three (2,2,2) poolings, two
+    (3,3,3) convs per level, three UpConvMerge stages with UpConv p=(2,2,2), 2-class head;
+    (1,1,116,132,132) -> (1,2,28,44,44)."""
+    from . import neuromancer as nm
+    if name is not None:
+        nm.model_manager.newmodel(name)
+    inp = nm.Input(in_sh, 'b,f,z,x,y', name='raw')
+    conv0 = nm.Conv(inp, 32, (3, 3, 3))
+    conv1 = nm.Conv(conv0, 64, (3, 3, 3))
+    down0 = nm.Pool(conv1, (2, 2, 2), mode='max')
+    conv2 = nm.Conv(down0, 64, (3, 3, 3))
+    conv3 = nm.Conv(conv2, 128, (3, 3, 3))
+    down1 = nm.Pool(conv3, (2, 2, 2), mode='max')
+    conv4 = nm.Conv(down1, 128, (3, 3, 3))
+    conv5 = nm.Conv(conv4, 256, (3, 3, 3))
+    down2 = nm.Pool(conv5, (2, 2, 2), mode='max')
+    conv6 = nm.Conv(down2, 256, (3, 3, 3))
+    conv7 = nm.Conv(conv6, 512, (3, 3, 3))
+    mrg0 = nm.UpConvMerge(conv5, conv7, 512)
+    mconv0 = nm.Conv(mrg0, 256, (3, 3, 3))
+    mconv1 = nm.Conv(mconv0, 256, (3, 3, 3))
+    mrg1 = nm.UpConvMerge(conv3, mconv1, 256)
+    mconv2 = nm.Conv(mrg1, 128, (3, 3, 3))
+    mconv3 = nm.Conv(mconv2, 128, (3, 3, 3))
+    mrg2 = nm.UpConvMerge(conv1, mconv3, 128)
+    mconv4 = nm.Conv(mrg2, 64, (3, 3, 3))
+    mconv5 = nm.Conv(mconv4, 64, (3, 3, 3))
+    barr = nm.Conv(mconv5, 2, (1, 1, 1), activation_func='lin', name='barr')
+    probs = nm.Softmax(barr)
+    target = nm.Input_like(mconv5, override_f=1, name='target')
+    loss_pix = nm.MultinoulliNLL(probs, target, target_is_sparse=True, name='nll_barr')
+    loss = nm.AggregateLoss(loss_pix, name='loss')
+    errors = nm.Errors(probs, target, target_is_sparse=True)
+    model = nm.model_manager.current if name is not None else nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, target_node=target, loss_node=loss,
+                          prediction_node=probs, prediction_ext=[loss, errors, probs])
+    return model
+
+
 def _pget(params):
     def P(i):
         if params is None:

@@ -16,6 +16,7 @@ reference pickles class references and drops the Adam state).
 """
 from __future__ import annotations
 
+import json
 import logging
 from collections import OrderedDict
 
@@ -26,7 +27,8 @@ from .. import config
 
 logger = logging.getLogger('elektronn2log')
 
-__all__ = ['Model', 'modelload', 'params_from_model_file']
+__all__ = ['Model', 'modelload', 'params_from_model_file', 'closest_valid_patch_size',
+           'kernel_lists_from_node_descr']
 
 
 class _CircularBuffer(object):
@@ -238,6 +240,11 @@ class Model(GraphManager):
             from .plan import get_ctx
             self.ensure_arena(get_ctx())
         dist.broadcast(self.P, src=0, group=self._dp_group)
+        # the broadcast is ordered on the current stream only; plans run on streams of
+        # their own -- a one-time host sync keeps the first step from reading P early
+        if self.P.is_cuda:
+            import torch
+            torch.cuda.current_stream(self.P.device).synchronize()
 
     def allreduce_grads(self):
         from ..parallel import allreduce_mean_
@@ -250,7 +257,15 @@ class Model(GraphManager):
 
     # ------------------------------------------------------------------ functions
     def save(self, file_name):
-        """Parameter values + optimiser state as .npz."""
+        """Save the model INCLUDING its training state to ``file_name`` (model.py:229-235).
+
+        The reference pickles ``(node descriptors, designations)`` -- class references,
+        ctor args and parameter values -- and drops the optimiser state.  Here one ``.npz``
+        written under exactly the given name holds: every parameter value (``p/<node>/
+        <param>``), the optimiser state (Adam m, s, t; SGD last_dir: ``o/<opt>/...``), the
+        iteration count, and a JSON graph description (class NAME, args, kwargs per node +
+        the designations) from which ``modelload`` re-executes the constructors, as
+        graphmanager.py:120-189 does, without unpickling code."""
         d = OrderedDict()
         for name, node in self.nodes.items():
             for k, v in node.get_param_values().items():
@@ -259,13 +274,60 @@ class Model(GraphManager):
             for k, v in opt.state_dict().items():
                 d["o/%s/%s" % (oname, k)] = v
         d["meta/iterations"] = np.array(self.iterations)
-        np.savez(file_name, **d)
+        d["meta/graph"] = np.array(json.dumps(self.serialise()))
+        with open(file_name, 'wb') as f:          # (np.savez(name) would append '.npz')
+            np.savez(f, **d)
+
+    def serialise(self):
+        """JSON-able graph description: [[name, class, args, kwargs], ...] in creation
+        order, parents as ``{"__node__": name}``, shared parameters as ``{"__param__":
+        [node, key]}``; initial-value arrays are dropped (the values are saved per node)."""
+        owner = {}
+        for name, node in self.nodes.items():
+            for k, p in node.params.items():
+                owner.setdefault(id(p), (name, k))
+
+        def enc(v, key=None):
+            if hasattr(v, '_finalize_init'):               # a Node
+                return {"__node__": v.name}
+            if id(v) in owner and hasattr(v, 'get_value'):
+                return {"__param__": list(owner[id(v)])}
+            if isinstance(v, tuple):
+                return {"__tuple__": [enc(x) for x in v]}
+            if isinstance(v, list):
+                return [enc(x) for x in v]
+            if isinstance(v, dict):
+                return {"__dict__": {str(k): enc(x) for k, x in v.items()}}
+            if isinstance(v, np.ndarray):
+                if key in ('w', 'b', 'gamma', 'mean', 'std'):
+                    return None
+                return {"__nd__": v.tolist(), "dtype": str(v.dtype)}
+            if isinstance(v, (np.integer,)):
+                return int(v)
+            if isinstance(v, (np.floating,)):
+                return float(v)
+            if isinstance(v, (np.bool_,)):
+                return bool(v)
+            if v is None or isinstance(v, (bool, int, float, str)):
+                return v
+            if hasattr(v, 'shape') and hasattr(v, 'tags') and hasattr(v, 'strides'):
+                return {"__tagged__": [list(v.shape), ",".join(v.tags)]}
+            raise TypeError("Model.save: cannot describe ctor argument %r" % (v,))
+
+        nodes = []
+        for name, (cls, args, kwargs) in self.node_descriptors.items():
+            nodes.append([name, cls, [enc(a) for a in args],
+                          {k: enc(v, k) for k, v in kwargs.items()}])
+        return {"nodes": nodes, "desig": self._desig_descr, "name": self.name}
 
     def load(self, file_name):
-        z = np.load(file_name)
+        """parameter values + optimiser state + iteration count into THIS graph"""
+        z = np.load(file_name, allow_pickle=False)
         for key in z.files:
             parts = key.split('/')
             if parts[0] == 'p':
+                if parts[1] not in self.nodes or parts[2] not in self.nodes[parts[1]].params:
+                    raise KeyError("model file has parameter %s which this graph lacks" % key)
                 self.nodes[parts[1]].params[parts[2]].set_value(z[key])
         st = {}
         for key in z.files:
@@ -391,9 +453,217 @@ def params_from_model_file(file_name):
     return out
 
 
-def modelload(file_name, model):
-    """Load parameter values (and optimiser state) saved by ``Model.save`` into
-    an already constructed ``model`` (the reference re-executes pickled ctors,
-    model.py:623-729; here the config's ``create_model()`` rebuilds the graph)."""
-    model.load(file_name)
-    return model
+def kernel_lists_from_node_descr(nodes):
+    """(filter_shapes, pool_shapes, mfp) of the Conv nodes of a serialised graph
+    (model.py:870-895; UpConv excluded, as there)."""
+    filters, pools, mfps = [], [], []
+    for name, cls, args, kwargs in nodes:
+        if cls != 'Conv':
+            continue
+        f = _dec_plain(args[2]) if len(args) > 2 else _dec_plain(kwargs['filter_shape'])
+        if len(args) > 3:
+            p = _dec_plain(args[3])
+        else:
+            p = _dec_plain(kwargs.get('pool_shape'))
+        filters.append(tuple(f))
+        pools.append(tuple(p) if p is not None else tuple(1 for _ in f))
+        mfps.append(bool(kwargs.get('mfp', False)))
+    return filters, pools, mfps
+
+
+def closest_valid_patch_size(filters, pools, desired, mfp=None):
+    """Per spatial axis the largest valid input extent <= ``desired`` (the smallest valid
+    one if ``desired`` is below it): utils/cnncalculator.py:57-103,309-313.  Valid means
+    every layer has output and ``(s - k + 1) % p == 0`` (``== 1`` with max-fragment
+    pooling), neural.py:746-750."""
+    nd = len(filters[0])
+    mfp = mfp or [False] * len(filters)
+    out = []
+    for ax in range(nd):
+        def ok(s):
+            for f, p, m in zip(filters, pools, mfp):
+                s = s - f[ax] + 1
+                if s <= 0:
+                    return False
+                if p[ax] > 1:
+                    if (s % p[ax]) != (1 if m else 0):
+                        return False
+                    s //= p[ax]
+            return True
+        valid = [s for s in range(2, 5000) if ok(s)]
+        if not valid:
+            raise ValueError("no valid patch size on axis %i" % ax)
+        smaller = [s for s in valid if s <= int(desired[ax])]
+        out.append(smaller[-1] if smaller else valid[0])
+    return tuple(out)
+
+
+def _dec_plain(v):
+    if isinstance(v, dict):
+        if "__tuple__" in v:
+            return tuple(_dec_plain(x) for x in v["__tuple__"])
+        if "__nd__" in v:
+            return np.asarray(v["__nd__"], dtype=v.get("dtype", "float32"))
+        if "__dict__" in v:
+            return {k: _dec_plain(x) for k, x in v["__dict__"].items()}
+    if isinstance(v, list):
+        return [_dec_plain(x) for x in v]
+    return v
+
+
+def modelload(file_name, model=None, override_mfp_to_active=False, imposed_patch_size=None,
+              imposed_batch_size=None, name=None, **model_load_kwargs):
+    """Load a Model saved by ``Model.save`` (model.py:623-729).
+
+    ``model`` given: parameter values, optimiser state and iteration count go into that
+    already constructed graph (``create_model(); modelload(f, model)`` -- training resumes
+    where it stopped, Adam moments and step counter included).
+
+    ``model`` None: the graph is rebuilt by re-executing the saved constructor calls
+    (graphmanager.py:120-189) in a new model ``name``.  ``imposed_batch_size`` /
+    ``imposed_patch_size`` change the input node's shape first; the patch size is moved to
+    the closest valid one unless the net contains UpConvs (then it is taken as given and
+    the constructors raise if it does not fit, model.py:691-713).
+    ``override_mfp_to_active`` switches every Conv to max-fragment pooling and inserts
+    ``FragmentsToDense`` in front of the prediction node (model.py:658-689); only the
+    prediction path is rebuilt in that case (targets and losses have no dense shape).
+    ``make_weights_constant=True`` freezes all parameters."""
+    if model is not None:
+        model.load(file_name)
+        return model
+    from . import node_basic, neural, loss as loss_mod
+    z = np.load(file_name, allow_pickle=False)
+    if "meta/graph" not in z.files:
+        raise ValueError("%s holds parameters only (no graph description): pass the "
+                         "constructed model, modelload(file, model)" % (file_name,))
+    descr = json.loads(str(z["meta/graph"]))
+    nodes, desig = descr["nodes"], dict(descr["desig"])
+    logger.info("Loading model from %s" % file_name)
+    changed_input = imposed_patch_size is not None or imposed_batch_size is not None \
+        or override_mfp_to_active
+    if changed_input and not desig.get('input_node'):
+        raise ValueError("To use 'override_mfp_to_active' or 'imposed_patch_size', the "
+                         "saved model must have a designated 'input_node'")
+    by_name = {n[0]: n for n in nodes}
+    if changed_input:
+        inp = by_name[desig['input_node']]
+        shape = list(_dec_plain(inp[2][0]) if inp[2] else _dec_plain(inp[3]['shape']))
+        tags = (inp[2][1] if len(inp[2]) > 1 else inp[3]['tags'])
+        tags = tags.split(',') if isinstance(tags, str) else list(tags)
+        spatial = [i for i, t in enumerate(tags) if t.strip() in ('z', 'y', 'x')]
+        if imposed_batch_size is not None:
+            shape[[t.strip() for t in tags].index('b')] = imposed_batch_size
+        filters, pools, mfps = kernel_lists_from_node_descr(nodes)
+        if override_mfp_to_active:
+            mfps = [True] * len(mfps)
+            if imposed_patch_size is None:
+                imposed_patch_size = [shape[i] for i in spatial]
+        if imposed_patch_size is not None:
+            if len(imposed_patch_size) != len(spatial):
+                raise ValueError("The dimensionality of the model and the imposed "
+                                 "patchsize do not match.")
+            if any(n[1] == 'UpConv' for n in nodes):
+                valid = tuple(int(v) for v in imposed_patch_size)
+                logger.warning("Imposed patch size is not failsafe for UpConvs")
+            else:
+                valid = closest_valid_patch_size(filters, pools, imposed_patch_size, mfps)
+            for i, v in zip(spatial, valid):
+                shape[i] = int(v)
+        if inp[2]:
+            inp[2][0] = {"__tuple__": shape}
+        else:
+            inp[3]['shape'] = {"__tuple__": shape}
+    keep = None
+    if override_mfp_to_active:
+        pred = by_name[desig['prediction_node']]
+        # ancestors of the prediction node only
+        keep, todo = set(), [pred[0]]
+        def parents_of(v, acc):
+            if isinstance(v, dict):
+                if "__node__" in v:
+                    acc.append(v["__node__"])
+                for x in v.values():
+                    parents_of(x, acc)
+            elif isinstance(v, list):
+                for x in v:
+                    parents_of(x, acc)
+        while todo:
+            nm_ = todo.pop()
+            if nm_ in keep:
+                continue
+            keep.add(nm_)
+            acc = []
+            parents_of(by_name[nm_][2], acc)
+            parents_of(by_name[nm_][3], acc)
+            todo.extend(acc)
+        for n in nodes:
+            if n[1] == 'Conv' and n[0] in keep:
+                n[3]['mfp'] = True
+        dense_name = 'to_dense_' + pred[0]
+        dense = [dense_name, 'FragmentsToDense', [pred[2][0]], {}]
+        pred[2][0] = {"__node__": dense_name}
+        nodes.insert(nodes.index(pred), dense)
+        keep.add(dense_name)
+        desig = dict(input_node=desig['input_node'], prediction_node=desig['prediction_node'])
+
+    new = node_basic.model_manager.newmodel(name)
+    classes = {}
+    for mod in (node_basic, neural, loss_mod):
+        for k in dir(mod):
+            v = getattr(mod, k, None)
+            if isinstance(v, type) and issubclass(v, node_basic.Node):
+                classes[k] = v
+    classes['Input_like'] = node_basic.Input_like
+    built = {}
+
+    def dec(v):
+        if isinstance(v, dict):
+            if "__node__" in v:
+                return built[v["__node__"]]
+            if "__param__" in v:
+                return built[v["__param__"][0]].params[v["__param__"][1]]
+            if "__tuple__" in v:
+                return tuple(dec(x) for x in v["__tuple__"])
+            if "__nd__" in v:
+                return np.asarray(v["__nd__"], dtype=v.get("dtype", "float32"))
+            if "__dict__" in v:
+                return {k: dec(x) for k, x in v["__dict__"].items()}
+            if "__tagged__" in v:
+                from .graphutils import TaggedShape
+                return TaggedShape(v["__tagged__"][0], v["__tagged__"][1])
+        if isinstance(v, list):
+            return [dec(x) for x in v]
+        return v
+
+    for nname, cls, args, kwargs in nodes:
+        if keep is not None and nname not in keep:
+            continue
+        if cls not in classes:
+            raise ValueError("model file names node class %r, which this build does not "
+                             "provide" % (cls,))
+        kw = {k: dec(v) for k, v in kwargs.items()}
+        kw['name'] = nname
+        built[nname] = classes[cls](*[dec(a) for a in args], **kw)
+    if desig:
+        new.designate_nodes(**{k: v for k, v in desig.items() if v})
+    # values: every saved parameter whose node was rebuilt
+    for key in z.files:
+        parts = key.split('/')
+        if parts[0] == 'p' and parts[1] in new.nodes:
+            new.nodes[parts[1]].params[parts[2]].set_value(z[key])
+    if keep is None:
+        st = {}
+        for key in z.files:
+            parts = key.split('/')
+            if parts[0] == 'o':
+                st.setdefault(parts[1], {})[parts[2]] = z[key]
+        for oname, sd in st.items():
+            if oname in new.optimisers:
+                new.optimisers[oname].load_state_dict(sd)
+        if "meta/iterations" in z.files:
+            new.iterations = int(z["meta/iterations"])
+    if model_load_kwargs.get('make_weights_constant'):
+        for node in new.nodes.values():
+            for p_ in node.params.values():
+                p_.apply_train = False
+    return new

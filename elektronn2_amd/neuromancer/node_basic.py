@@ -425,7 +425,11 @@ class Node(object, metaclass=MetaNode):
         vol[:, :raw_sh[0], :raw_sh[1], :raw_sh[2]] = torch.from_numpy(raw).to(dev)
         dense = torch.zeros((n_lab,) + tuple(int(n_t[i] * prob_sh[i]) for i in range(3)),
                             dtype=torch.float32, device=dev)
-        x_buf = plan.input_buffer(inp)
+        x_buf = plan.input_buffer(inp, None)
+        # vol / dense were filled on the current stream; the blocks run on the plan's
+        plan.stream.wait_stream(torch.cuda.current_stream(dev))
+        vol.record_stream(plan.stream)
+        dense.record_stream(plan.stream)
         sz, sx, sy = (int(v) for v in strides)
         for zt in range(n_t[0]):
             for xt in range(n_t[1]):
@@ -517,8 +521,16 @@ def Input_like(ref, dtype=None, name='input', print_repr=True, override_f=False,
         assert dtype is not None
     else:
         raise ValueError("ref must be Node or TaggedShape.")
-    return Input(shape, tags, strides, fov=fov, dtype=dtype, name=name,
+    node = Input(shape, tags, strides, fov=fov, dtype=dtype, name=name,
                  print_repr=print_repr, hardcoded_shape=hardcoded_shape)
+    if isinstance(ref, Node) and getattr(node, '_model', None) is not None:
+        # described by its reference, so that a graph rebuilt with another patch or batch
+        # size (modelload) gets targets of the new shape
+        node._model.node_descriptors[node.name] = (
+            'Input_like', (ref,), dict(dtype=dtype, print_repr=print_repr,
+                                       override_f=override_f,
+                                       hardcoded_shape=hardcoded_shape))
+    return node
 
 
 class Concat(Node):

@@ -71,6 +71,7 @@ class Optimiser(object):
                 float(self._beta2()), float(self.global_weight_decay.get_value()))
         if self._hyper is None:
             self._hyper = torch.zeros(8, dtype=torch.float32, device=plan.ctx.device)
+            self._apply_pending_hyper()
         if vals != self._hyper_host:
             self._hyper[:4].copy_(torch.tensor(vals, dtype=torch.float32))
             self._hyper_host = vals
@@ -105,6 +106,9 @@ class Optimiser(object):
     def load_state_dict(self, d):
         pass
 
+    def _apply_pending_hyper(self):
+        pass
+
 
 class SGD(Optimiser):
     """d' = g + mom*d ; p' = p - lr*(d' + wd*p [*apply_reg])  (optimiser.py:146-160)."""
@@ -112,11 +116,15 @@ class SGD(Optimiser):
 
     def __init__(self, *a):
         self.last_dir = None
+        self._pending = None
         super(SGD, self).__init__(*a)
 
     def _ensure_state(self, plan):
         if self.last_dir is None:
             self.last_dir = plan.zeros_flat(max(self.model.n_train, 4))
+        if self._pending is not None:
+            self._apply(self._pending)
+            self._pending = None
 
     def device_update(self, plan):
         m = self.model
@@ -132,10 +140,22 @@ class SGD(Optimiser):
             return {}
         return {'last_dir': self.last_dir.cpu().numpy()}
 
+    def _apply(self, d):
+        import torch
+        if 'last_dir' in d:
+            v = np.ascontiguousarray(d['last_dir'], dtype=np.float32)
+            if v.size != self.last_dir.numel():
+                raise ValueError("SGD state of %i elements does not fit this model (%i)"
+                                 % (v.size, self.last_dir.numel()))
+            self.last_dir.copy_(torch.from_numpy(v))
+
     def load_state_dict(self, d):
-        if 'last_dir' in d and self.last_dir is not None:
-            import torch
-            self.last_dir.copy_(torch.from_numpy(d['last_dir']))
+        """the buffers are created lazily by the first step: a state loaded into a fresh
+        model is kept and applied when they exist (``create_model(); modelload(f, model)``)"""
+        if self.last_dir is None:
+            self._pending = dict(d)
+        else:
+            self._apply(d)
 
 
 class Adam(Optimiser):
@@ -147,6 +167,8 @@ class Adam(Optimiser):
         self.beta2 = VariableParam(value=0.999, name='beta2', dtype=graphutils.floatX)
         self.squared_accum = None
         self.momentum = None
+        self._pending = None
+        self._pending_t = None
         super(Adam, self).__init__(*a)
         self.meta_params['beta2'] = self.beta2
 
@@ -158,6 +180,9 @@ class Adam(Optimiser):
             n = max(self.model.n_train, 4)
             self.momentum = plan.zeros_flat(n)
             self.squared_accum = plan.zeros_flat(n)
+        if self._pending is not None:
+            self._apply(self._pending)
+            self._pending = None
 
     def device_update(self, plan):
         m = self.model
@@ -167,7 +192,9 @@ class Adam(Optimiser):
 
     @property
     def t(self):
-        return 0.0 if self._hyper is None else float(self._hyper[4].item())
+        if self._hyper is None:
+            return 0.0 if self._pending_t is None else float(self._pending_t)
+        return float(self._hyper[4].item())
 
     def state_dict(self):
         if self.momentum is None:
@@ -175,10 +202,32 @@ class Adam(Optimiser):
         return {'m': self.momentum.cpu().numpy(), 's': self.squared_accum.cpu().numpy(),
                 't': np.array(self.t)}
 
-    def load_state_dict(self, d):
+    def _apply(self, d):
         import torch
-        if self.momentum is not None and 'm' in d:
-            self.momentum.copy_(torch.from_numpy(d['m']))
-            self.squared_accum.copy_(torch.from_numpy(d['s']))
-        if self._hyper is not None and 't' in d:
-            self._hyper[4] = float(d['t'])
+        if 'm' in d:
+            m = np.ascontiguousarray(d['m'], dtype=np.float32)
+            s = np.ascontiguousarray(d['s'], dtype=np.float32)
+            if m.size != self.momentum.numel() or s.size != self.momentum.numel():
+                raise ValueError("Adam state of %i elements does not fit this model (%i)"
+                                 % (m.size, self.momentum.numel()))
+            self.momentum.copy_(torch.from_numpy(m))
+            self.squared_accum.copy_(torch.from_numpy(s))
+
+    def _apply_pending_hyper(self):
+        if self._pending_t is not None:
+            self._hyper[4] = float(self._pending_t)
+            self._pending_t = None
+
+    def load_state_dict(self, d):
+        """m, s and the step counter t.  The device buffers are created lazily by the
+        first step; a state loaded before that (``create_model(); modelload(f, model)``)
+        is kept and applied when they exist, so resuming continues the bias correction
+        and the moments instead of silently restarting them."""
+        if self.momentum is None:
+            self._pending = {k: d[k] for k in ('m', 's') if k in d} or None
+        else:
+            self._apply(d)
+        if 't' in d:
+            self._pending_t = float(np.asarray(d['t']))
+            if self._hyper is not None:
+                self._apply_pending_hyper()

@@ -234,6 +234,9 @@ class Plan(object):
     # ---- build ------------------------------------------------------------------------
     def build(self, batch):
         self.ctx = get_ctx()
+        for g in (getattr(self, '_graphs', None) or []):     # batch size changed: drop the
+            self.ctx.graph_destroy(g)                        # graphs captured for the old one
+        self._graphs = None
         self.batch = int(batch)
         self.stream = torch.cuda.Stream(device=self.ctx.device)
         # second stream: weight gradients (and the weight repack) run next to the
@@ -401,19 +404,34 @@ class Plan(object):
             zero_jobs = self._zero_jobs()
             self._zero_keep = zero_jobs                  # the graphs read these tensors
             ctx.record(self._ev0)
-            for i, (emit, after) in enumerate(self._segs):
-                self._seg_idx = i
-                self._capturing = True
-                ctx.graph_begin()
-                if i in zero_jobs:
-                    ctx.fill_multi(*zero_jobs[i])
-                emit()
-                g = ctx.graph_end()
-                self._capturing = False
-                graphs.append(g)
-                ctx.graph_launch(g)
-                if after is not None:
-                    after()
+            try:
+                for i, (emit, after) in enumerate(self._segs):
+                    self._seg_idx = i
+                    self._capturing = True
+                    ctx.graph_begin()
+                    try:
+                        if i in zero_jobs:
+                            ctx.fill_multi(*zero_jobs[i])
+                        emit()
+                    except BaseException:
+                        # leave capture mode (a stream stuck in capture poisons every later
+                        # launch of the context) and drop the partial graph
+                        self._capturing = False
+                        try:
+                            ctx.graph_destroy(ctx.graph_end())
+                        except Exception:
+                            pass
+                        raise
+                    g = ctx.graph_end()
+                    self._capturing = False
+                    graphs.append(g)
+                    ctx.graph_launch(g)
+                    if after is not None:
+                        after()
+            except BaseException:
+                for g in graphs:
+                    ctx.graph_destroy(g)
+                raise
             self._graphs = graphs
             from .. import autotune
             autotune.save()
@@ -458,10 +476,18 @@ class Plan(object):
             batch = 1
         if not self._built or batch != self.batch:
             self.build(batch)
+        # the plan's stream is non-blocking: device inputs were produced on the caller's
+        # current stream (PatchSampler's warp kernels, a broadcast, a fill) -- order the
+        # copies behind it, and keep the source alive until they have run
+        self.stream.wait_stream(torch.cuda.current_stream(self.ctx.device))
         with torch.cuda.stream(self.stream):
             for node, a in zip(self.inputs, args):
                 dst = self.out[node]
                 if isinstance(a, torch.Tensor):
+                    if a.data_ptr() == dst.data_ptr():
+                        continue          # written in place (input_buffer): nothing to copy
+                    if a.is_cuda:
+                        a.record_stream(self.stream)
                     dst.copy_(a.to(torch.float32), non_blocking=True)
                 else:
                     h = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
@@ -504,7 +530,12 @@ class Plan(object):
         return self.fetch()
 
     # Input nodes own the static input buffers
-    def input_buffer(self, node):
+    def input_buffer(self, node, batch=1):
+        """the plan's static device buffer of an Input node.  A producer (PatchSampler,
+        bench.py) may write it in place on the current stream and pass it to the call: the
+        copy is then skipped (set_inputs orders the plan's stream behind the producer)."""
+        if not self._built or (batch is not None and int(batch) != self.batch):
+            self.build(batch)
         return self.out[node]
 
 

@@ -10,9 +10,13 @@
  * Conventions
  *   - every function returns 0 on success, non-zero on error; the message is
  *     available from e2_last_error() (thread-local).
- *   - all data pointers are DEVICE pointers owned by the caller; the library
- *     never allocates device memory behind the caller's back (workspace sizes
- *     come from e2_*_workspace_bytes()).
+ *   - all data pointers are DEVICE pointers owned by the caller; workspace sizes
+ *     come from e2_*_workspace_bytes().  The library's only device allocation is
+ *     one 1 KiB page of zeros per context, made in e2_ctx_create and released in
+ *     e2_ctx_destroy (source of masked DMA lanes); a -DE2_DEBUG_ENV build may also
+ *     allocate in-kernel timeline buffers when asked to through the environment.
+ *   - the release library never reads the process environment: tilings arrive
+ *     through e2_set_tiling().
  *   - layouts: activations (b,f,z,x,y) = NCDHW, fp32; weights
  *     (n_f, n_in, kz, kx, ky) = KCDHW, fp32  (neural.py:615-623 'dnn' order).
  *     Tensors are described by e2_tensor5: sizes + element strides, so crops,
@@ -44,6 +48,7 @@ typedef struct e2_tensor5 {
 
 enum { E2_ACT_LIN = 0, E2_ACT_RELU = 1 };
 enum { E2_MFMA_F32 = 0, E2_MFMA_BF16 = 1 };
+enum { E2_TILING_IGEMM = 0, E2_TILING_WGRAD = 1 };
 
 /* ---- context / stream / errors --------------------------------------- */
 int  e2_ctx_create(int device, e2_ctx** out);
@@ -61,6 +66,18 @@ int  e2_version(void);
  * e2_conv3d_wgrad entry point always compute in f32 (UpConv follows the setting).  Not to be changed while a graph is being captured. */
 int  e2_set_mfma_dtype(e2_ctx* ctx, int dtype);
 int  e2_get_mfma_dtype(const e2_ctx* ctx);
+/* Tiling of the conv GEMM launches (no reference counterpart; stands where Theano's
+ * per-op algorithm choice `dnn_conv3d(..., algo=...)` stood, computations.py:30,391).
+ * kind E2_TILING_IGEMM: cfg = "MT,NT,CC,SK" for the packed forward / dgrad / UpConv
+ * launches (16*MT output channels x 64*NT positions per work-group, CC input channels
+ * per LDS chunk, SK-way split of K); kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
+ * e2_conv3d_wgrad / e2_conv3d_wgrad_pad (WK 1 / 14 direct kernel, 0 / 4 LDS-staged;
+ * BP positions per tile, PS position splits).  The setting holds for every following
+ * launch of that kind on this context until changed; cfg NULL or "" returns the choice
+ * to the library's cost model.  A tiling the problem cannot use (LDS, instance list)
+ * makes the launch fail with an error, never silently fall back.  A launch captured
+ * into a graph keeps the tiling that was set at capture time. */
+int  e2_set_tiling(e2_ctx* ctx, int kind, const char* cfg);
 
 /* ---- conv  (computations.py:364-428 conv(), 3-D branch; F1: true
  *      convolution, kernel flipped in every spatial dim, 'valid') --------- */

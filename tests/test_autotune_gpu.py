@@ -51,7 +51,7 @@ def test_every_candidate_tiling_is_correct(ctx, prob):
     bad, ran = [], 0
     try:
         for c in autotune.wgrad_candidates(cout, cin, k, osp):
-            os.environ["E2_WGRAD_FORCE"] = c
+            ctx.set_tiling("wgrad", c)
             dw = torch.full(w.shape, float("nan"), device="cuda")
             try:
                 ctx.conv3d_wgrad_pad(xd, dyp, dw)
@@ -60,9 +60,9 @@ def test_every_candidate_tiling_is_correct(ctx, prob):
             ran += 1
             if not rel(dw, dw_ref) < 2e-5:
                 bad.append(("wgrad", c))
-        os.environ.pop("E2_WGRAD_FORCE", None)
+        ctx.set_tiling("wgrad", None)
         for c in autotune.igemm_candidates(cout, cin, k, osp):
-            os.environ["E2_IGEMM_FORCE"] = c
+            ctx.set_tiling("igemm", c)
             y = torch.full(y_ref.shape, float("nan"), device="cuda")
             try:
                 ctx.conv3d_fwd(xd, wd, y)
@@ -72,7 +72,7 @@ def test_every_candidate_tiling_is_correct(ctx, prob):
             if not rel(y, y_ref) < 2e-5:
                 bad.append(("fwd", c))
         for c in autotune.igemm_candidates(cin, cout, k, sp):
-            os.environ["E2_IGEMM_FORCE"] = c
+            ctx.set_tiling("igemm", c)
             dx = torch.full(x.shape, float("nan"), device="cuda")
             try:
                 ctx.conv3d_dgrad(dyp, wd, dx)
@@ -82,7 +82,7 @@ def test_every_candidate_tiling_is_correct(ctx, prob):
             if not rel(dx, dx_ref) < 2e-5:
                 bad.append(("dgrad", c))
     finally:
-        os.environ.pop("E2_WGRAD_FORCE", None)
-        os.environ.pop("E2_IGEMM_FORCE", None)
+        ctx.set_tiling("wgrad", None)
+        ctx.set_tiling("igemm", None)
     assert ran > 20
     assert not bad, bad

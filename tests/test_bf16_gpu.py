@@ -69,10 +69,7 @@ def test_fwd_dgrad_wgrad_bf16(bctx, case):
     y_ref, y_f32 = O.conv3d_fwd(xb, wb), O.conv3d_fwd(x, w)
     xd, wd = dev(x), dev(w)
     ws = torch.empty(bctx.conv_ws_bytes(Co, Ci, k) // 4 + 64, device="cuda")
-    env = {}
-    if fi:
-        env["E2_IGEMM_FORCE"] = fi
-    os.environ.update(env)
+    bctx.set_tiling("igemm", fi or None)
     try:
         bctx.conv3d_pack(wd, 0, ws)
         y = torch.full(y_ref.shape, float("nan"), device="cuda")
@@ -96,15 +93,13 @@ def test_fwd_dgrad_wgrad_bf16(bctx, case):
         assert relerr(dx, O.conv3d_dgrad(dyb, wb, x.shape)) < TOL
         assert 1e-4 < relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < 2e-2
     finally:
-        for key in env:
-            del os.environ[key]
-    if fw:
-        os.environ["E2_WGRAD_FORCE"] = fw
+        bctx.set_tiling("igemm", None)
+    bctx.set_tiling("wgrad", fw or None)
     try:
         dw = torch.full(w.shape, float("nan"), device="cuda")
         bctx.conv3d_wgrad_pad(xd, dyp, dw)
     finally:
-        os.environ.pop("E2_WGRAD_FORCE", None)
+        bctx.set_tiling("wgrad", None)
     assert relerr(dw, O.conv3d_wgrad(dyb, xb, w.shape)) < TOL
     assert 1e-4 < relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < 2e-2
 

@@ -242,79 +242,6 @@ def test_predict_dense_baseline_net_spot_check():
         assert np.abs(dense[(slice(None),) + pos] - ref).max() < 1e-5, pos
 
 
-def torch_mirror(model, x, t, dtype):
-    """evaluate the model's node graph with torch-CPU closed forms (oracle/torch_step.py)
-    and return (loss, {param name: gradient}) from autograd"""
-    from elektronn2_amd import neuromancer as nm
-    from oracle import torch_step as TS
-    P = {}
-    for name, p in model.loss_node.all_trainable_params.items():
-        P[name] = torch.tensor(p.get_value(), dtype=dtype, requires_grad=True)
-    val = {}
-    logits = None
-    for node in model.loss_node.all_parents.values():
-        cls = type(node).__name__
-        if node is model.input_node:
-            val[node] = torch.tensor(x, dtype=dtype)
-        elif cls == 'UpConv':
-            val[node] = TS.upconv_node(val[node.parent], P[node.name + '_w'], P[node.name + '_b'],
-                                       node.pool_shape, node.activation_func)
-        elif cls == 'Conv':
-            val[node] = TS.conv_node(val[node.parent], P[node.name + '_w'], P[node.name + '_b'],
-                                     node.pool_shape, node.activation_func)
-        elif cls == 'Pool':
-            val[node] = torch.nn.functional.max_pool3d(val[node.parent], node.pool_shape)
-        elif cls == 'Crop':
-            v, c = val[node.parent], node.crop
-            val[node] = v[:, :, c[0]:v.shape[2] - c[0], c[1]:v.shape[3] - c[1],
-                          c[2]:v.shape[4] - c[2]]
-        elif cls == 'Concat':
-            val[node] = torch.cat([val[q] for q in node.parent], dim=1)
-        elif cls == 'Softmax':
-            logits = val[node.parent]
-    L, _ = TS.nll_loss(logits, torch.tensor(t, dtype=dtype))
-    L.backward()
-    return float(L), {k: v.grad.numpy() for k, v in P.items()}
-
-
-def test_unet3d_lite_native_size_parity():
-    """BASELINE configs[2]: examples/unet3d_lite.py at its own input (1,1,22,140,140)
-    -> (1,2,10,52,52), 398 GF per step: loss and every parameter gradient against the
-    torch-CPU float64 evaluation of the same graph.  Output (loss) tolerance 1e-4
-    (north_star).  Gradient tolerance 1e-3 of each tensor's max magnitude: 20 fp32
-    layers deep, a pre-activation within fp32 rounding of zero lands on the other side
-    of the relu than in float64 and moves single gradient elements by O(1e-4..1e-3)
-    of the tensor's maximum (typical worst tensor 1.5e-4, seen up to 3.5e-4; torch-CPU
-    fp32 sits at 1.3e-3, tools/unet_diag.py).
-    Then the captured hipGraphs are replayed: loss and gradients must stay put (a
-    hipMemsetAsync node re-ordered against the split-K kernel behind it once broke
-    exactly this, see csrc/pointwise.hip e2i_fill_flat)."""
-    from elektronn2_amd import neuromancer as nm, nets
-    nm.model_manager.reset()
-    np.random.seed(5)
-    model = nets.unet3d_lite()
-    assert model.prediction_node.shape.spatial_shape == [10, 52, 52]
-    rng = np.random.RandomState(6)
-    x = rng.rand(1, 1, 22, 140, 140).astype(np.float32)
-    t = rng.randint(0, 2, (1, 1, 10, 52, 52)).astype(np.float32)
-    torch.set_num_threads(16)
-    L, G = torch_mirror(model, x, t, torch.float64)
-    assert abs(float(model.loss(x, t)) - L) / L < TOL
-    g = model.gradients(x, t)
-    names = list(model.loss_node.all_trainable_params.keys())
-    worst = 0.0
-    for i, nme in enumerate(names):
-        ref = G[nme]
-        worst = max(worst, float(np.abs(g[i] - ref).max() / (np.abs(ref).max() + 1e-30)))
-    assert worst < 10 * TOL, worst
-    L0 = float(model.loss(x, t))
-    for _ in range(6):                       # call 2 captures, calls 3.. replay
-        g2 = model.gradients(x, t)
-        assert abs(float(model.loss(x, t)) - L0) / L0 < 1e-5
-        for a, b in zip(g, g2):
-            assert float(np.abs(a - b).max() / (np.abs(a).max() + 1e-30)) < 2e-3
-
-
 @pytest.mark.parametrize("batch", [2, 3])
 def test_batch_larger_than_one(batch):
     """the BASELINE configs train with one sample per step, but the node API takes any
@@ -337,4 +264,4 @@ def test_batch_larger_than_one(batch):
     ref_losses, _ = O.net_train_steps(spec, params, x, t, 3)
     for i in range(3):
         loss = float(m.trainingstep(x, t, optimiser='Adam')[0])
-        assert abs(loss - ref_losses[i]) < 5e-4 * abs(ref_losses[i])
+        assert abs(loss - ref_losses[i]) < 2 * TOL * abs(ref_losses[i])

@@ -86,11 +86,11 @@ def test_conv3d_fwd_forced_tilings(ctx, force):
     w = (rng.randn(200, 24, 3, 2, 3) / 12).astype(np.float32)
     y_ref = O.conv3d_fwd(x, w)
     y = torch.full(y_ref.shape, float("nan"), device="cuda")
-    os.environ["E2_IGEMM_FORCE"] = force
+    ctx.set_tiling("igemm", force)
     try:
         ctx.conv3d_fwd(dev(x), dev(w), y)
     finally:
-        del os.environ["E2_IGEMM_FORCE"]
+        ctx.set_tiling("igemm", None)
     assert relerr(y, y_ref) < TOL
 
 
@@ -134,11 +134,11 @@ def test_conv3d_1x1_forced_tilings(ctx, force):
     w = (rng.randn(100, 70, 1, 1, 1) / 8).astype(np.float32)
     y_ref = O.conv3d_fwd(x, w)
     y = torch.full(y_ref.shape, float("nan"), device="cuda")
-    os.environ["E2_IGEMM_FORCE"] = force
+    ctx.set_tiling("igemm", force)
     try:
         ctx.conv3d_fwd(dev(x), dev(w), y)
     finally:
-        del os.environ["E2_IGEMM_FORCE"]
+        ctx.set_tiling("igemm", None)
     assert relerr(y, y_ref) < TOL
 
 
@@ -164,14 +164,14 @@ def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
     dyp = flat[:int(np.prod(pshape))].view(pshape)
     dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
     dw = torch.full(w.shape, float("nan"), device="cuda")
-    os.environ["E2_WGRAD_FORCE"] = force
+    ctx.set_tiling("wgrad", force)
     try:
         ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
         assert relerr(dw, dw_ref) < TOL
         ctx.conv3d_wgrad_pad(dev(x), dyp, dw, accumulate=True)
         assert relerr(dw, 2 * dw_ref) < TOL
     finally:
-        del os.environ["E2_WGRAD_FORCE"]
+        ctx.set_tiling("wgrad", None)
 
 
 @pytest.mark.parametrize("force", ["1,1,1,64,3", "2,2,1,128,5", "3,4,1,64,2", "4,1,4,128,7",
@@ -182,11 +182,11 @@ def test_conv3d_wgrad_forced_tilings(ctx, force):
     dy = rng.randn(2, 100, 3, 11, 19).astype(np.float32)
     ref = O.conv3d_wgrad(dy, x, (100, 9, 2, 2, 3))
     dw = torch.full(ref.shape, float("nan"), device="cuda")
-    os.environ["E2_WGRAD_FORCE"] = force
+    ctx.set_tiling("wgrad", force)
     try:
         ctx.conv3d_wgrad(dev(x), dev(dy), dw)
     finally:
-        del os.environ["E2_WGRAD_FORCE"]
+        ctx.set_tiling("wgrad", None)
     assert relerr(dw, ref) < TOL
 
 
@@ -499,7 +499,7 @@ def test_fill_multi_and_skip_zero_fill(ctx):
     ref = O.conv3d_fwd(x, w)
     ws = torch.empty(ctx.conv_ws_bytes(20, 24, (2, 3, 3)) // 4 + 64, device="cuda")
     ctx.conv3d_pack(dev(w), 0, ws)
-    os.environ["E2_IGEMM_FORCE"] = "2,1,8,4"          # split-K 4: atomics onto a zeroed output
+    ctx.set_tiling("igemm", "2,1,8,4")                 # split-K 4: atomics onto a zeroed output
     try:
         y = torch.full(ref.shape, float("nan"), device="cuda")
         ctx.conv3d_fwd_packed(dev(x), ws, 20, (2, 3, 3), y)
@@ -513,9 +513,9 @@ def test_fill_multi_and_skip_zero_fill(ctx):
         finally:
             ctx.set_skip_zero_fill(False)
         assert relerr(y - 1.0, ref) < 1e-4
-        os.environ["E2_IGEMM_FORCE"] = "2,1,8,1"      # no split-K: nothing to zero
+        ctx.set_tiling("igemm", "2,1,8,1")             # no split-K: nothing to zero
         ctx.conv3d_fwd_packed(dev(x), ws, 20, (2, 3, 3), y)
         assert ctx.conv_last_zero_fill()[1] == 0
         assert relerr(y, ref) < TOL
     finally:
-        del os.environ["E2_IGEMM_FORCE"]
+        ctx.set_tiling("igemm", None)

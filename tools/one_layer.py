@@ -11,6 +11,11 @@ iters = int(sys.argv[10]) if len(sys.argv) > 10 else 10
 ctx = backend.Context(0)
 if os.environ.get('E2_MFMA_DTYPE'):
     ctx.set_mfma_dtype(os.environ['E2_MFMA_DTYPE'])
+# tiling overrides of this tool (the library itself never reads the environment)
+if os.environ.get("E2_IGEMM_FORCE"):
+    ctx.set_tiling("igemm", os.environ["E2_IGEMM_FORCE"])
+if os.environ.get("E2_WGRAD_FORCE"):
+    ctx.set_tiling("wgrad", os.environ["E2_WGRAD_FORCE"])
 k = (kd, kh, kw)
 osp = (D - kd + 1, H - kh + 1, W - kw + 1)
 x = torch.rand(1, cin, D, H, W, device="cuda")
