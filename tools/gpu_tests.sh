@@ -1,0 +1,11 @@
+#!/bin/bash
+# GPU test suite (run on the GPU box via gpurun): tools/gpu_tests.sh <tag> [pytest args]
+set -o pipefail
+T=${1:-tests}; shift
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out/$T
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=15 "$@" > gpurun_out/$T/pytest_gpu.log 2>&1
+rc=$?
+tail -40 gpurun_out/$T/pytest_gpu.log
+exit $rc
