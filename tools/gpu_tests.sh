@@ -5,7 +5,8 @@ T=${1:-tests}; shift
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$T
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q --durations=15 "$@" > gpurun_out/$T/pytest_gpu.log 2>&1
+if [ $# -eq 0 ]; then set -- tests -x; fi
+timeout -k 10 1100 python -m pytest -m gpu -q --durations=15 "$@" > gpurun_out/$T/pytest_gpu.log 2>&1
 rc=$?
-tail -40 gpurun_out/$T/pytest_gpu.log
+tail -60 gpurun_out/$T/pytest_gpu.log
 exit $rc
