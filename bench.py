@@ -35,6 +35,8 @@ WORKLOADS = {
     "full185": ("neuro3d", (23, 185, 185), 119.02),
     # BASELINE configs[2]; algorithmic GF with UpConv counted at its closed form
     "unet_lite140": ("unet3d_lite", (22, 140, 140), 397.8),
+    # BASELINE configs[4]: examples/unet3d.py at its own input, UpConv p=(2,2,2)
+    "unet132": ("unet3d", (116, 132, 132), 1576.9),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (--mfma bf16 only)
@@ -43,6 +45,12 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak 
 # 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
 # It cannot be measured inside the timed run; null for workloads not profiled.
 PMC_TRAFFIC_BYTES = {"lite183": (2 * 817.6 + 414.3) * 1024 * 1024}
+PMC_TRAFFIC_SOURCE = "profiles/r01_e_pmc_traffic.csv"
+# Matrix-pipe utilisation of the whole step from the rocprofv3 PMC pass of this script
+# (tools/gpu_round.sh -> tools/pmc_mfma.py): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel
+# cycles at the clock the chip held), summed over the kernels of a step; None = not profiled.
+PMC_MFMA_UTIL = {}
+PMC_MFMA_SOURCE = None
 
 
 def algorithmic_gflop(model):
@@ -59,6 +67,17 @@ def conv_params(model):
     """[(w, b)] of the Conv nodes in graph order (the initial weights, for the CPU leg)"""
     return [(n.w.get_value().copy(), n.b.get_value().copy()) for n in model.nodes.values()
             if type(n).__name__ == 'Conv']
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 def host_cores():
@@ -228,7 +247,7 @@ def main():
     np.random.seed(1)                         # identical initial weights on every rank
     model = getattr(nets, builder)((None, 1) + sp)
     osp = tuple(model.prediction_node.shape.spatial_shape)
-    if builder == "unet3d_lite":
+    if builder in ("unet3d_lite", "unet3d"):
         gflop = gf_table                      # UpConv / merge net: SURVEY.md §8d's figure
         args.no_cpu_baseline = True           # the CPU leg is the sequential-net port
     else:
@@ -285,10 +304,21 @@ def main():
     loss = float(plan.scratch[model.loss_node.parent[0], 'loss'].item())
     assert np.isfinite(loss), "non-finite loss"
 
+    ranks = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+        # who took part: one line per rank (device, PCI bus id, backend) gathered on rank 0,
+        # so that a scaling run shows N distinct GPUs behind the N ranks
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+              "device": dev.index, "name": props.name,
+              "pci": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+              "backend": torch.distributed.get_backend(), "ms_per_step": dev_ms}
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, me)
+        ranks = gathered
 
     if rank != 0:
         return
@@ -313,14 +343,16 @@ def main():
                                % ((builder,) + tuple(sp) + tuple(osp) +
                                   ((", conv GEMM operands rounded to bf16, f32 sums, f32 tensors",)
                                    if bf16 else ("",))),
-                   "parallelism": "dp%d" % world,
+                   "parallelism": "dp%d" % world, "ranks": ranks,
                    "output_voxels_per_sec": float(np.prod(osp)) * world * args.steps / dt,
                    "hipgraph": bool(plan.use_graph), "final_loss": loss},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None if bf16 else PMC_TRAFFIC_BYTES.get(args.workload),
-                     "traffic_unit": "B/step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, "
-                                     "profiles/r01_e_pmc_traffic.csv)",
+                     "traffic_unit": "B/step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, %s)"
+                                     % PMC_TRAFFIC_SOURCE,
+                     "mfma_util": None if bf16 else PMC_MFMA_UTIL.get(args.workload),
+                     "mfma_util_source": PMC_MFMA_SOURCE,
                      "kernel": "training step (hipGraph): conv3d igemm fwd/dgrad/wgrad on "
                                + ("v_mfma_f32_16x16x16_bf16 / 16x16x32_bf16" if bf16 else
                                   "v_mfma_f32_16x16x4_f32") + " + pointwise + Adam",
@@ -335,14 +367,19 @@ def main():
         cores = host_cores()
         x = xs[0].cpu().numpy()
         t = ts[0].cpu().numpy()
-        med, all_t = TS.time_cpu_step(spec, params0, x, t, cores, warmup=1, steps=3)
+        # BASELINE.md §3 protocol: same tensors, batch 1, 2 warm-up steps, median of 5
+        med, all_t = TS.time_cpu_step(spec, params0, x, t, cores, warmup=2, steps=5)
         out["cpu_baseline"] = {
             "value": float(np.prod((1, 1) + sp)) / med, "unit": "voxels/s", "cores": cores,
             "kind": "port",
-            "sample": "3 full training steps (median) of the same workload, torch-CPU fp32 "
-                      "(oneDNN) port of the reference step; Theano itself is not "
-                      "installable offline (BASELINE.md §3)",
+            "sample": "5 full training steps (median, after 2 warm-up steps) of the same "
+                      "workload, torch-CPU fp32 (oneDNN) port of the reference step; Theano "
+                      "itself is not installable offline (BASELINE.md §3), oneDNN direct "
+                      "convolution is expected to be faster than Theano's conv3d2d",
             "s_per_step": med,
+            "gflops": gflop / med,
+            "cpu_model": cpu_model(),
+            "torch": torch.__version__,
         }
     print(json.dumps(out))
 

@@ -220,11 +220,16 @@ class Model(GraphManager):
         return [self.device_grad(p) for p in self.trainable_params]
 
     # ------------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, group=None):
+    def enable_data_parallel(self, group=None, weight_by_labelled=True):
+        """replicas + gradient exchange.  ``weight_by_labelled``: combine the
+        ranks' gradients as the reference's whole-batch normalisation does when the ranks
+        see different numbers of labelled voxels (parallel.BucketedMean); one extra
+        one-element all-reduce per step, the plain mean when the counts are equal."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self._dp_group = group if group is not None else dist.group.WORLD
+        self._dp_weighted = bool(weight_by_labelled)
         self.broadcast_params()
 
     def dp_world(self):
@@ -246,14 +251,17 @@ class Model(GraphManager):
             import torch
             torch.cuda.current_stream(self.P.device).synchronize()
 
-    def allreduce_grads(self):
-        from ..parallel import allreduce_mean_
-        allreduce_mean_(self.G, self._dp_group)
+    def allreduce_grads(self, count=None):
+        ex = self.grad_exchange(count)
+        ex.start(0, self.G.numel())
+        ex.finish()
 
-    def grad_exchange(self):
-        """sliced exchange of the gradient arena (parallel.BucketedMean)"""
+    def grad_exchange(self, count=None):
+        """sliced exchange of the gradient arena (parallel.BucketedMean); ``count``: this
+        rank's labelled-voxel count on the device (weighted mean, see enable_data_parallel)"""
         from ..parallel import BucketedMean
-        return BucketedMean(self.G, self._dp_group)
+        return BucketedMean(self.G, self._dp_group,
+                            count=count if getattr(self, '_dp_weighted', False) else None)
 
     # ------------------------------------------------------------------ functions
     def save(self, file_name):

@@ -323,6 +323,17 @@ class Plan(object):
                 break
         return self._dp_cut_cache
 
+    def _labelled_count(self):
+        """one-element device view: the number of labelled target voxels of this rank's
+        batch (written by the forward pass of the single MultinoulliNLL under the loss), or
+        None when the loss has another structure"""
+        ln = self.loss_node
+        kids = ln.parent if isinstance(ln.parent, (list, tuple)) else [ln.parent]
+        if len(kids) != 1 or type(kids[0]).__name__ != 'MultinoulliNLL':
+            return None
+        st = self.scratch.get((kids[0].pred, 'stats'))
+        return None if st is None else st[1:2]
+
     def _emit_update(self):
         if self.step in ('Adam', 'SGD'):
             self.model.optimisers[self.step].device_update(self)
@@ -349,7 +360,8 @@ class Plan(object):
                     if upd and not dp:
                         self._emit_update()
             segs.append((self._emit_forward, host_steps))
-            segs.append((rest, self.model.allreduce_grads if dp else None))
+            segs.append((rest, (lambda: self.model.allreduce_grads(self._labelled_count()))
+                         if dp else None))
             if dp:
                 segs.append((self._emit_update, None))
             return segs
@@ -363,7 +375,7 @@ class Plan(object):
                 self._emit_backward(0)
 
             def start_tail():
-                self._ex = self.model.grad_exchange()
+                self._ex = self.model.grad_exchange(self._labelled_count())
                 self._ex.start(cut[1], n_train)
 
             def finish():
@@ -378,7 +390,8 @@ class Plan(object):
                 self._emit_backward()
                 if upd and not dp:
                     self._emit_update()
-        segs.append((whole, self.model.allreduce_grads if dp else None))
+        segs.append((whole, (lambda: self.model.allreduce_grads(self._labelled_count()))
+                     if dp else None))
         if dp:
             segs.append((self._emit_update, None))
         return segs

@@ -54,14 +54,32 @@ class BucketedMean:
     current stream (RCCL runs it on its own stream); finish() makes the current stream
     wait for every slice."""
 
-    def __init__(self, flat, group=None):
+    def __init__(self, flat, group=None, count=None):
+        """``count``: one-element tensor with this rank's number of LABELLED target voxels.
+        The reference normalises the NLL by the labelled count of the WHOLE batch
+        (loss.py:342-344); a rank's gradient is normalised by its own count, so with
+        ragged counts the whole-batch gradient is the count-weighted mean
+        sum_r n_r g_r / sum_r n_r, not the plain mean.  With ``count`` given, every slice
+        is scaled by n_r * world / sum_r n_r before it is summed (one extra one-element
+        all-reduce per step); equal counts reduce to the plain mean."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._work, self._covered = [], 0
+        self._count, self._weight = count, None
+
+    def _scale_slice(self, lo, hi):
+        if self._count is None:
+            return
+        if self._weight is None:
+            tot = self._count.detach().clone()
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+            self._weight = self._count.detach() * float(self.world) / torch.clamp(tot, min=1e-30)
+        self.flat[lo:hi].mul_(self._weight)
 
     def start(self, lo, hi):
         if self.world == 1 or hi <= lo:
             return
+        self._scale_slice(lo, hi)
         self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM,
                                           group=self.group, async_op=True))
         self._covered += hi - lo
@@ -74,7 +92,7 @@ class BucketedMean:
         if self._covered != self.flat.numel():
             raise RuntimeError("BucketedMean: slices cover %d of %d elements"
                                % (self._covered, self.flat.numel()))
-        self._work, self._covered = [], 0
+        self._work, self._covered, self._weight = [], 0, None
         self.flat.mul_(1.0 / self.world)
         return self.flat
 

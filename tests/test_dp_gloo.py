@@ -97,6 +97,77 @@ def test_two_rank_allreduce_mean_keeps_replicas_identical():
     assert np.abs(res[0] - ref).max() < 1e-6
 
 
+def _ragged_data(rank):
+    """rank r leaves a different share of its target unlabelled (-1)"""
+    x, t = _data(rank)
+    t = t.clone()
+    t.view(-1)[::(2 + rank)] = -1
+    return x, t
+
+
+def _worker4(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from elektronn2_amd import parallel
+    assert parallel.init_from_env("gloo") == world
+    net = TS.TorchNet(SPEC, O.init_net(SPEC, 1, seed=1))
+    x, t = _ragged_data(rank)
+    net.loss_and_grads(x, t)
+    flat = _flat_grads(net)
+    count = (t >= 0).sum().to(torch.float32).view(1)
+    # the launch plan's segment order (plan.py _segments, overlapped form): [forward +
+    # backward of the late layers] -> exchange of the arena's tail starts -> [backward of
+    # the early layers] -> exchange of the head -> wait, scale -> [optimiser]
+    lo = flat.numel() // 4 // 4 * 4
+    weighted = flat.clone()
+    ex = parallel.BucketedMean(weighted, count=count)
+    ex.start(lo, weighted.numel())
+    ex.start(0, lo)
+    ex.finish()
+    plain = flat.clone()
+    parallel.allreduce_mean_(plain)
+    # the single-exchange form gives the same weighted result
+    one = flat.clone()
+    ex1 = parallel.BucketedMean(one, count=count)
+    ex1.start(0, one.numel())
+    ex1.finish()
+    # (same numbers up to the summation order of gloo's ring over different slice sizes)
+    assert (one - weighted).abs().max() <= 1e-6 * weighted.abs().max()
+    q.put((rank, weighted.numpy(), plain.numpy(), float(count)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_four_ranks_ragged_labels_give_the_whole_batch_gradient():
+    """world 4, every rank with a different number of labelled voxels: the reference
+    normalises the NLL by the labelled count of the WHOLE batch (loss.py:342-344), so the
+    data-parallel gradient must be the count-weighted mean of the per-rank gradients --
+    checked against ONE process evaluating the batch of four; the plain mean (what equal
+    counts reduce to) is measurably different here."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=240) for _ in range(4)]
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    res.sort(key=lambda r: r[0])
+    assert len({r[3] for r in res}) == 4, "the counts must be ragged for this test"
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]), "ranks disagree on the exchanged gradient"
+        assert np.array_equal(r[2], res[0][2])
+    torch.set_num_threads(1)
+    net = TS.TorchNet(SPEC, O.init_net(SPEC, 1, seed=1))
+    xs, ts = zip(*[_ragged_data(r) for r in range(4)])
+    net.loss_and_grads(torch.cat(xs), torch.cat(ts))        # whole-batch normalisation
+    ref = _flat_grads(net).numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(res[0][1] - ref).max() < 2e-6 * scale
+    assert np.abs(res[0][2] - ref).max() > 1e-3 * scale      # the plain mean is NOT it
+
+
 def test_rank_seeds_are_distinct_and_single_process_is_identity():
     from elektronn2_amd import parallel
     assert len({parallel.rank_seed(0, r) for r in range(8)}) == 8

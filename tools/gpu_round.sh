@@ -1,17 +1,21 @@
 #!/bin/bash
-# full GPU verification + profile collection (run on the GPU box via gpurun)
+# Profile collection of one workload for the record (run on the GPU box via gpurun):
+#   tools/gpu_round.sh <workload> <tag>  ->  gpurun_out/<tag>/  bench.json, kernel_stats.csv,
+#   pmc_mfma.csv, pmc_fetch.csv, pmc_write.csv   (copy the ones to keep into profiles/)
 set -o pipefail
-mkdir -p gpurun_out/r
+W=${1:-lite183}; T=${2:-round}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/r/pytest_gpu.log 2>&1 || { tail -20 gpurun_out/r/pytest_gpu.log; exit 1; }
-tail -2 gpurun_out/r/pytest_gpu.log
-timeout -k 10 120 python __graft_entry__.py smoke > gpurun_out/r/smoke.log 2>&1 || { tail -20 gpurun_out/r/smoke.log; exit 1; }
-tail -2 gpurun_out/r/smoke.log
-timeout -k 10 200 python bench.py > gpurun_out/r/bench.json 2> gpurun_out/r/bench.err || { tail -20 gpurun_out/r/bench.err; exit 1; }
-cat gpurun_out/r/bench.json
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r/prof -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r/bench_prof.json 2> gpurun_out/r/prof.err || { tail -20 gpurun_out/r/prof.err; exit 1; }
-cat gpurun_out/r/bench_prof.json
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > gpurun_out/r/pmc_fetch.json 2> gpurun_out/r/pmc_fetch.err || { tail -20 gpurun_out/r/pmc_fetch.err; exit 1; }
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r/pmc_write -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-graph > gpurun_out/r/pmc_write.json 2> gpurun_out/r/pmc_write.err || { tail -20 gpurun_out/r/pmc_write.err; exit 1; }
-find gpurun_out/r -name '*.csv' | xargs ls -la
+O=gpurun_out/$T
+mkdir -p $O
+timeout -k 10 400 python bench.py --workload $W > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+cat $O/bench.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err || { tail -20 $O/prof.err; exit 1; }
+cp $(find $O/prof -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv && rm -rf $O/prof
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_mfma -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/pmc_mfma.json 2> $O/pmc_mfma.err || { tail -20 $O/pmc_mfma.err; exit 1; }
+python tools/pmc_mfma.py $O/pmc_mfma 7 > $O/pmc_mfma.csv && rm -rf $O/pmc_mfma
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/pmc_fetch.json 2> $O/pmc_fetch.err || { tail -20 $O/pmc_fetch.err; exit 1; }
+python tools/pmc_sum.py $O/pmc_fetch FETCH_SIZE 7 > $O/pmc_fetch.csv && rm -rf $O/pmc_fetch
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-graph > $O/pmc_write.json 2> $O/pmc_write.err || { tail -20 $O/pmc_write.err; exit 1; }
+python tools/pmc_sum.py $O/pmc_write WRITE_SIZE 7 > $O/pmc_write.csv && rm -rf $O/pmc_write
+tail -3 $O/pmc_mfma.csv; tail -1 $O/pmc_fetch.csv; tail -1 $O/pmc_write.csv
