@@ -104,6 +104,58 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
             for cc in ccs:
                 for sk in sks:
                     cands.append("%d,%d,%d,%d" % (mt, nt, cc, sk))
+    return cands + igemm4_candidates(cout, cin, k, out_sp, split_k)
+
+
+IGEMM4_INSTANCES = [(5, 2), (5, 4), (8, 2), (8, 4), (10, 2), (10, 4), (13, 1), (13, 2), (16, 1),
+                    (16, 2), (19, 1), (19, 2), (20, 1), (20, 2), (25, 1), (25, 2)]
+
+
+def g4_pairs(mg, nt, kw):
+    """input channels per pipeline step of an igemm4 instance (csrc/igemm4_core.hpp g4_pairs)"""
+    na = (4 * mg + 63) // 64
+    u = 1
+    while u < 8 and u * kw * mg * nt < 96 and 2 * (2 * u) * kw * (na + nt) + 4 * mg * nt <= 200:
+        u *= 2
+    return u
+
+
+def igemm4_candidates(cout, cin, k, out_sp, split_k=True, n_cu=256):
+    """"4,MG,NT,CC,SK,WM": the 4x4x1-MFMA kernel (channels padded to 4, not 16).  Tile
+    heights (4*MG*WM) with the least channel padding, a few position-tile widths, channel
+    chunks that are multiples of the instance's step, split-K only when the grid is small."""
+    if k[2] not in (1, 3, 4, 5):
+        return []
+    q = out_sp[1] * out_sp[2]
+    cinp = -(-cin // 4) * 4
+    shapes = []
+    for mg, nt in IGEMM4_INSTANCES:
+        for wm in (1, 2, 4):
+            bm = 4 * mg * wm
+            nmt = -(-cout // bm)
+            pad = nmt * bm - cout
+            if pad >= 4 * mg and wm > 1:          # a whole wave of the tile would idle
+                continue
+            if nmt > 1 and bm < 40:
+                continue
+            shapes.append((pad / float(cout), -bm, mg, nt, wm, nmt))
+    shapes.sort()
+    best_pad = shapes[0][0] if shapes else 0
+    cands = []
+    for padf, _, mg, nt, wm, nmt in shapes:
+        if padf > best_pad + 0.08:
+            break
+        u = g4_pairs(mg, nt, k[2])
+        step = u * 4 // __import__('math').gcd(u, 4)
+        bn = 64 * nt * (4 // wm)
+        base = out_sp[0] * (-(-q // bn)) * nmt
+        sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 6)
+        ccs = sorted(set(-(-c // step) * step for c in (8, 16, 32, 64, cinp, -(-cin // 2), -(-cin // 3))
+                         if c >= 4))
+        ccs = [c for c in ccs if c <= 128 and -(-cin // c) * c <= cinp + 32]
+        for cc in ccs:
+            for sk in sks:
+                cands.append("4,%d,%d,%d,%d,%d" % (mg, nt, cc, sk, wm))
     return cands
 
 

@@ -33,7 +33,7 @@
 //   per-lane part of every operand address is loop invariant.
 // LDS rows are padded so that rows qd and qd+1 sit 16 banks apart
 // (stride == 16 mod 32): ds_read_b32 of a 32-lane half is conflict free.
-#include "igemm_core.hpp"
+#include "igemm4_core.hpp"
 #include <stdlib.h>
 #include <algorithm>
 #include <vector>
@@ -215,7 +215,10 @@ extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs
 }
 
 // ---- host side ----------------------------------------------------------------
-struct IgemmCfg { int MT, NT, CC, SK; };
+// kind 0: 16x16x4 kernel, tile 16*MT channels x 64*NT positions ("MT,NT,CC,SK");
+// kind 4: 4x4x1 kernel (igemm4_core.hpp), MT = channel groups of 4 per wave, WM = compute
+// waves along the channels ("4,MG,NT,CC,SK,WM")
+struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1; };
 
 static const int kMTs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13};
 
@@ -267,7 +270,12 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   const char* force = ctx->tiling[E2_TILING_IGEMM];
   if (force[0]) {
     IgemmCfg f{0, 0, 0, 0};
-    if (sscanf(force, "%d,%d,%d,%d", &f.MT, &f.NT, &f.CC, &f.SK) == 4) { *ok = 1; return f; }
+    int v[6];
+    const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
+    if (nf == 4) { f.MT = v[0]; f.NT = v[1]; f.CC = v[2]; f.SK = v[3]; *ok = 1; return f; }
+    if (nf == 6 && v[0] == 4) {
+      f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5]; *ok = 1; return f;
+    }
   }
   const double out_bytes = 4.0 * a.N * a.Cout * a.Do * (double)Q;
   const int cinP = ((a.Cin + 3) / 4) * 4;
@@ -326,6 +334,87 @@ int e2i_pack_weights(e2_ctx* ctx, const float* w, float* wp, int Cout, int Cin,
   return 0;
 }
 
+int e2i_igemm4_pairs(int kw, int MG, int NT) {
+  switch (kw) {
+    case 1: return e2i_igemm4_pairs_k1(MG, NT);
+    case 3: return e2i_igemm4_pairs_k3(MG, NT);
+    case 4: return e2i_igemm4_pairs_k4(MG, NT);
+    case 5: return e2i_igemm4_pairs_k5(MG, NT);
+  }
+  return 0;
+}
+
+// zero-fill of a split-K output (atomics accumulate onto it); notes the region for callers
+// that batch the fills of a whole step (e2_conv_last_zero_fill / e2_set_skip_zero_fill)
+static int igemm_zero_output(e2_ctx* ctx, const IgemmArgs& a) {
+  const int R = a.upz * a.upy * a.upx;
+  const int oc = a.Cout / (R > 1 ? R : 1);
+  const int od = a.Do * a.upz, oh = a.Ho * a.upy, ow = a.Wo * a.upx;
+  if (a.osY == ow && a.osZ == (long)oh * ow && a.osC == (long)od * oh * ow &&
+      (a.N == 1 || a.osN == (long)oc * od * oh * ow)) {
+    ctx->last_fill_ptr = a.out; ctx->last_fill_n = (size_t)a.N * oc * od * oh * ow;
+    if (!ctx->skip_zero_fill)
+      if (int rc = e2i_fill_flat(ctx, a.out, ctx->last_fill_n, 0.f)) return rc;
+    return 0;
+  }
+  e2_tensor5 v{a.out, a.N, oc, od, oh, ow, a.osN, a.osC, a.osZ, a.osY};
+  return e2i_fill_view(ctx, &v, 0.f);
+}
+
+// the 4x4x1-MFMA kernel (igemm4_core.hpp)
+static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
+  E2_REQUIRE(has_fast_kw(a.kw), "igemm4: tap rows of %d have no instance", a.kw);
+  const int U = e2i_igemm4_pairs(a.kw, c.MT, c.NT);
+  E2_REQUIRE(U > 0, "igemm4: no instance MG=%d NT=%d", c.MT, c.NT);
+  E2_REQUIRE(c.WM == 1 || c.WM == 2 || c.WM == 4, "igemm4: WM must be 1, 2 or 4");
+  E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC % U == 0, "igemm4: CC must be a multiple of 4 and of %d", U);
+  E2_REQUIRE(c.SK >= 1, "igemm4: SK must be >= 1");
+  IgemmP p;
+  p.in = a.in; p.wp = a.wp; p.out = a.out;
+  p.Cin = a.Cin; p.Cout = a.Cout; p.kd = a.kd; p.kh = a.kh; p.kw = a.kw;
+  p.THW = a.kh * a.kw;
+  p.Do = a.Do; p.Ho = a.Ho; p.Wo = a.Wo; p.Q = a.Ho * a.Wo;
+  p.isN = a.isN; p.isC = a.isC; p.isZ = a.isZ; p.isY = a.isY;
+  p.osN = a.osN; p.osC = a.osC; p.osZ = a.osZ; p.osY = a.osY;
+  p.ciP = a.ciP; p.coP = a.coP;
+  const int BN = 64 * c.NT * (4 / c.WM), BM = 4 * c.MT * c.WM;
+  p.Lpad = pad16mod32(span_lmax(a, BN) + 3);
+  p.CC = c.CC;
+  p.Din = a.Do + a.kd - 1;
+  p.dbg = 0;
+  p.N = a.N;
+  p.nPT = e2_cdiv(p.Q, BN);
+  p.nMT = e2_cdiv(a.Cout, BM);
+  p.nChunkC = e2_cdiv(a.Cin, c.CC);
+  p.splitK = a.bias ? 1 : std::min(c.SK, a.kd * p.nChunkC);
+  p.atomic = (p.splitK > 1) ? 1 : 0;
+  p.upz = a.upz; p.upy = a.upy; p.upx = a.upx;
+  p.bufFloats = c.CC * p.Lpad + 64;
+  p.stamps = nullptr; p.bias = a.bias; p.act = a.act; p.bf16 = 0; p.wide = 0;
+  // channels past Cin are staged as copies of the last one: their weight rows must exist and be zero
+  E2_REQUIRE(p.nChunkC * c.CC <= a.ciP, "igemm4: CC=%d pads Cin=%d beyond the packed image", c.CC, a.Cin);
+  // a wave reads 64-channel rows starting at its first channel
+  const int NA = (4 * c.MT + 63) / 64;
+  E2_REQUIRE((p.nMT - 1) * BM + (c.WM - 1) * 4 * c.MT + 64 * NA <= a.coP, "igemm4: tile exceeds the packed coP");
+  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  E2_REQUIRE(lds <= 160 * 1024, "igemm4: tiling needs %zu B of LDS", lds);
+  const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
+  E2_REQUIRE(grid < (1L << 31), "igemm4: grid too large");
+  ctx->last_fill_ptr = nullptr; ctx->last_fill_n = 0;
+  if (p.atomic)
+    if (int rc = igemm_zero_output(ctx, a)) return rc;
+  if (e2_dbg_env("E2_VERBOSE"))
+    fprintf(stderr, "[e2] igemm4 Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MG=%d NT=%d CC=%d SK=%d WM=%d U=%d grid=%ld lds=%zu\n",
+            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, c.WM, U, grid, lds);
+  Igemm4Extra x{c.WM};
+  switch (a.kw) {
+    case 1: return e2i_igemm4_launch_k1(ctx, p, x, c.MT, c.NT, (int)grid, lds);
+    case 3: return e2i_igemm4_launch_k3(ctx, p, x, c.MT, c.NT, (int)grid, lds);
+    case 4: return e2i_igemm4_launch_k4(ctx, p, x, c.MT, c.NT, (int)grid, lds);
+    default: return e2i_igemm4_launch_k5(ctx, p, x, c.MT, c.NT, (int)grid, lds);
+  }
+}
+
 int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   E2_REQUIRE(a.Do > 0 && a.Ho > 0 && a.Wo > 0 && a.Cin > 0 && a.Cout > 0,
              "igemm: empty problem");
@@ -334,6 +423,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   IgemmCfg c = choose_cfg(ctx, a, &ok);
   E2_REQUIRE(ok, "igemm: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d W=%d)", a.Cin,
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
+  if (c.kind == 4) return igemm4_conv(ctx, a, c);
   const bool fast = has_fast_kw(a.kw);
   E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC <= (fast ? 64 : 32),
              "igemm: CC must be a multiple of 4, at most %d", fast ? 64 : 32);
@@ -376,24 +466,8 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
   E2_REQUIRE(grid < (1L << 31), "igemm: grid too large");
   ctx->last_fill_ptr = nullptr; ctx->last_fill_n = 0;
-  if (p.atomic) {
-    // split-K accumulates with atomics: start from zero
-    const int R = a.upz * a.upy * a.upx;
-    const int oc = a.Cout / (R > 1 ? R : 1);
-    const int od = a.Do * a.upz, oh = a.Ho * a.upy, ow = a.Wo * a.upx;
-    if (a.osY == ow && a.osZ == (long)oh * ow && a.osC == (long)od * oh * ow &&
-        (a.N == 1 || a.osN == (long)oc * od * oh * ow)) {
-      // (a caller that batches the zero-fills of a whole step asks which region this was,
-      // e2_conv_last_zero_fill, and announces pre-zeroed outputs, e2_set_skip_zero_fill)
-      ctx->last_fill_ptr = a.out; ctx->last_fill_n = (size_t)a.N * oc * od * oh * ow;
-      if (!ctx->skip_zero_fill)
-        if (int rc = e2i_fill_flat(ctx, a.out, ctx->last_fill_n, 0.f)) return rc;
-    } else {
-      e2_tensor5 v{a.out, a.N, oc, od, oh, ow, a.osN, a.osC, a.osZ, a.osY};
-      int rc = e2i_fill_view(ctx, &v, 0.f);
-      if (rc) return rc;
-    }
-  }
+  if (p.atomic)
+    if (int rc = igemm_zero_output(ctx, a)) return rc;
   // debug: per-work-group timeline stamps (fast path only), printed after a sync
   p.stamps = nullptr;
   static unsigned long long* stamp_buf = nullptr;

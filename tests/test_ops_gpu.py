@@ -125,6 +125,71 @@ def test_conv3d_fused_bias_act(ctx, act, k):
         assert np.array_equal(g[:, 0], 0.5 * dout[:, 0]) and not g[:, 1].any()
 
 
+@pytest.mark.parametrize("force", ["4,5,2,8,1,1", "4,5,4,16,1,2", "4,8,2,24,1,4", "4,8,4,8,2,1",
+                                   "4,10,2,12,1,2", "4,10,4,8,3,1", "4,13,1,8,1,4", "4,13,2,24,1,2",
+                                   "4,16,1,16,1,1", "4,16,2,8,2,4", "4,19,1,24,1,2", "4,19,2,12,1,1",
+                                   "4,20,1,8,1,2", "4,20,2,24,1,1", "4,25,1,12,1,2", "4,25,2,24,2,2"])
+def test_conv3d_fwd_4x4_mfma_tilings(ctx, force):
+    """the 4x4x1-MFMA kernel (igemm4_core.hpp): every (MG, NT) instance, waves along the
+    channels (WM 1/2/4), channel chunks with a ragged last chunk (Cin = 22), split-K, an
+    odd Cout (50: not a multiple of 4), position tiles that straddle rows and planes' ends"""
+    rng = np.random.RandomState(27)
+    x = rng.rand(2, 22, 5, 13, 37).astype(np.float32)
+    w = (rng.randn(50, 22, 3, 2, 3) / 12).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    y = torch.full(y_ref.shape, float("nan"), device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        ctx.conv3d_fwd(dev(x), dev(w), y)
+    finally:
+        ctx.set_tiling("igemm", None)
+    assert relerr(y, y_ref) < TOL
+
+
+@pytest.mark.parametrize("kw,force", [(1, "4,13,1,16,1,4"), (1, "4,25,2,32,1,1"), (1, "4,5,4,8,2,2"),
+                                      (4, "4,10,2,8,1,2"), (4, "4,16,1,12,2,1"),
+                                      (5, "4,8,4,8,1,1"), (5, "4,20,1,4,1,2")])
+def test_conv3d_4x4_mfma_tap_widths_dgrad_and_fused_act(ctx, kw, force):
+    """tap rows of 1, 4 and 5 (3 is covered above): forward, data gradient on the padded
+    gradient buffer (strided rows) and the fused bias + relu epilogue with its signed
+    zeros, all through the 4x4x1 kernel"""
+    rng = np.random.RandomState(kw)
+    k = (1, 1, 1) if kw == 1 else (2, 3, kw)
+    Ci, Co = 70, 100
+    x = rng.rand(1, Ci, 4, 12, 21).astype(np.float32)
+    w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k))).astype(np.float32)
+    b = rng.randn(Co).astype(np.float32) * 0.1
+    y_ref = O.conv3d_fwd(x, w)
+    ws = torch.empty(ctx.conv_ws_bytes(Co, Ci, k) // 4 + 64, device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        ctx.conv3d_pack(dev(w), 0, ws)
+        y = torch.full(y_ref.shape, float("nan"), device="cuda")
+        ctx.conv3d_fwd_packed(dev(x), ws, Co, k, y)
+        assert relerr(y, y_ref) < TOL
+        if "," + force.split(",")[4] + "," == ",1,":      # no split-K: fused epilogue
+            ya = torch.full(y_ref.shape, float("nan"), device="cuda")
+            ctx.conv3d_fwd_packed_act(dev(x), ws, Co, k, dev(b), 'relu', ya)
+            pre = y_ref + b.reshape(1, -1, 1, 1, 1)
+            assert relerr(ya, np.maximum(pre, 0)) < TOL
+            neg = torch.signbit(ya).cpu().numpy()           # -0.0 marks a NEGATIVE pre-activation
+            assert neg[pre < -1e-6].all() and not neg[pre > 1e-6].any()
+        dy = rng.randn(*y_ref.shape).astype(np.float32)
+        osp = y_ref.shape[2:]
+        pshape = (1, Co) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+        flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
+        dyp = flat[:int(np.prod(pshape))].view(pshape)
+        dyp[:, :, k[0] - 1:k[0] - 1 + osp[0], k[1] - 1:k[1] - 1 + osp[1],
+            k[2] - 1:k[2] - 1 + osp[2]] = dev(dy)
+        ctx.conv3d_pack(dev(w), 1, ws)
+        dx = torch.full(x.shape, float("nan"), device="cuda")
+        # the data gradient has Cin = 70 output channels: 4*MG*WM may not cover it in one tile
+        ctx.conv3d_dgrad_packed(dyp, ws, Ci, k, dx)
+        assert relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < TOL
+    finally:
+        ctx.set_tiling("igemm", None)
+
+
 @pytest.mark.parametrize("force", ["7,2,32,1", "13,1,16,2", "2,4,48,1", "5,2,64,1", "1,1,8,1"])
 def test_conv3d_1x1_forced_tilings(ctx, force):
     """1x1x1 taps (plain GEMM): GU = 4 channel groups per step when CC % 16 == 0,
@@ -263,6 +328,18 @@ def test_maxpool_standalone_and_floor(ctx):
 
 UPCONV_CASES = [(1, 8, 6, (2, 2, 2), (3, 4, 5), 'relu'), (1, 32, 16, (1, 2, 2), (2, 5, 6), 'relu'),
                 (2, 5, 7, (2, 1, 3), (2, 3, 4), 'lin'), (1, 64, 64, (2, 2, 2), (2, 9, 9), 'relu')]
+
+
+@pytest.mark.parametrize("force", ["4,16,2,16,1,1", "4,13,1,8,1,4", "4,8,4,8,2,2"])
+def test_upconv3d_4x4_mfma_scatter_epilogue(ctx, force):
+    """UpConv forward through the 4x4x1 kernel: 1x1x1 GEMM to Cout * prod(pool) rows with the
+    depth-to-space scatter in the epilogue (the backward's data gradient takes the same kernel)"""
+    for case in UPCONV_CASES:
+        ctx.set_tiling("igemm", force)
+        try:
+            test_upconv3d(ctx, case)
+        finally:
+            ctx.set_tiling("igemm", None)
 
 
 @pytest.mark.parametrize("case", UPCONV_CASES)
