@@ -17,6 +17,7 @@ tiling for every problem of a kind (tests, experiments); it outranks the cache.
 from __future__ import annotations
 
 import json
+import math
 import os
 
 from .backend import E2Error
@@ -107,8 +108,8 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     return cands + igemm4_candidates(cout, cin, k, out_sp, split_k)
 
 
-IGEMM4_INSTANCES = [(5, 2), (5, 4), (8, 2), (8, 4), (10, 2), (10, 4), (13, 1), (13, 2), (16, 1),
-                    (16, 2), (19, 1), (19, 2), (20, 1), (20, 2), (25, 1), (25, 2)]
+IGEMM4_INSTANCES = [(5, 2), (5, 4), (8, 2), (8, 4), (10, 2), (10, 3), (13, 1), (13, 2), (16, 1),
+                    (16, 2), (19, 1), (20, 1), (25, 1)]
 
 
 def g4_pairs(mg, nt, kw):
@@ -146,16 +147,22 @@ def igemm4_candidates(cout, cin, k, out_sp, split_k=True, n_cu=256):
         if padf > best_pad + 0.08:
             break
         u = g4_pairs(mg, nt, k[2])
-        step = u * 4 // __import__('math').gcd(u, 4)
+        step = u * 4 // math.gcd(u, 4)
+        if ((step // u) * k[1]) % 2:               # an even number of pipeline steps per chunk
+            step *= 2
         bn = 64 * nt * (4 // wm)
         base = out_sp[0] * (-(-q // bn)) * nmt
         sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 6)
-        ccs = sorted(set(-(-c // step) * step for c in (8, 16, 32, 64, cinp, -(-cin // 2), -(-cin // 3))
-                         if c >= 4))
-        ccs = [c for c in ccs if c <= 128 and -(-cin // c) * c <= cinp + 32]
+        # the chunk size only sets the LDS footprint (three ring buffers): a few small ones
+        ccs = sorted(set(-(-c // step) * step for c in (8, 16, 32) if c >= 4))
+        ccs = [c for c in ccs if -(-cin // c) * c <= cinp + 32][:3]
         for cc in ccs:
             for sk in sks:
-                cands.append("4,%d,%d,%d,%d,%d" % (mg, nt, cc, sk, wm))
+                tiles = base * sk
+                for g in (1, 2, 3):
+                    if g > 1 and tiles <= (g - 1) * n_cu:
+                        continue
+                    cands.append("4,%d,%d,%d,%d,%d,%d" % (mg, nt, cc, sk, wm, g))
     return cands
 
 

@@ -218,7 +218,7 @@ extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs
 // kind 0: 16x16x4 kernel, tile 16*MT channels x 64*NT positions ("MT,NT,CC,SK");
 // kind 4: 4x4x1 kernel (igemm4_core.hpp), MT = channel groups of 4 per wave, WM = compute
 // waves along the channels ("4,MG,NT,CC,SK,WM")
-struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1; };
+struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1, G = 1; };
 
 static const int kMTs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13};
 
@@ -270,11 +270,12 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   const char* force = ctx->tiling[E2_TILING_IGEMM];
   if (force[0]) {
     IgemmCfg f{0, 0, 0, 0};
-    int v[6];
-    const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]);
+    int v[7];
+    const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
     if (nf == 4) { f.MT = v[0]; f.NT = v[1]; f.CC = v[2]; f.SK = v[3]; *ok = 1; return f; }
-    if (nf == 6 && v[0] == 4) {
-      f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5]; *ok = 1; return f;
+    if (nf >= 6 && v[0] == 4) {
+      f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5];
+      f.G = nf == 7 ? v[6] : 1; *ok = 1; return f;
     }
   }
   const double out_bytes = 4.0 * a.N * a.Cout * a.Do * (double)Q;
@@ -367,8 +368,9 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   const int U = e2i_igemm4_pairs(a.kw, c.MT, c.NT);
   E2_REQUIRE(U > 0, "igemm4: no instance MG=%d NT=%d", c.MT, c.NT);
   E2_REQUIRE(c.WM == 1 || c.WM == 2 || c.WM == 4, "igemm4: WM must be 1, 2 or 4");
-  E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC % U == 0, "igemm4: CC must be a multiple of 4 and of %d", U);
-  E2_REQUIRE(c.SK >= 1, "igemm4: SK must be >= 1");
+  E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC % U == 0 && ((c.CC / U) * a.kh) % 2 == 0,
+             "igemm4: CC must be a multiple of 4 and of %d with an even number of steps per chunk", U);
+  E2_REQUIRE(c.SK >= 1 && c.G >= 1 && c.G <= 8, "igemm4: SK must be >= 1, G in 1..8");
   IgemmP p;
   p.in = a.in; p.wp = a.wp; p.out = a.out;
   p.Cin = a.Cin; p.Cout = a.Cout; p.kd = a.kd; p.kh = a.kh; p.kw = a.kw;
@@ -386,7 +388,12 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   p.nPT = e2_cdiv(p.Q, BN);
   p.nMT = e2_cdiv(a.Cout, BM);
   p.nChunkC = e2_cdiv(a.Cin, c.CC);
-  p.splitK = a.bias ? 1 : std::min(c.SK, a.kd * p.nChunkC);
+  {   // K splits: every split gets at least one chunk
+    const int nChunks = a.kd * p.nChunkC;
+    int sk = a.bias ? 1 : std::min(c.SK, nChunks);
+    const int per = e2_cdiv(nChunks, sk);
+    p.splitK = e2_cdiv(nChunks, per);
+  }
   p.atomic = (p.splitK > 1) ? 1 : 0;
   p.upz = a.upz; p.upy = a.upy; p.upx = a.upx;
   p.bufFloats = c.CC * p.Lpad + 64;
@@ -396,17 +403,18 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   // a wave reads 64-channel rows starting at its first channel
   const int NA = (4 * c.MT + 63) / 64;
   E2_REQUIRE((p.nMT - 1) * BM + (c.WM - 1) * 4 * c.MT + 64 * NA <= a.coP, "igemm4: tile exceeds the packed coP");
-  const size_t lds = 2 * (size_t)p.bufFloats * 4;
+  const size_t lds = 3 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "igemm4: tiling needs %zu B of LDS", lds);
-  const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
-  E2_REQUIRE(grid < (1L << 31), "igemm4: grid too large");
+  const long tiles = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;
+  E2_REQUIRE(tiles < (1L << 31), "igemm4: too many tiles");
+  const long grid = std::min<long>(tiles, (long)c.G * ctx->num_cu);
   ctx->last_fill_ptr = nullptr; ctx->last_fill_n = 0;
   if (p.atomic)
     if (int rc = igemm_zero_output(ctx, a)) return rc;
   if (e2_dbg_env("E2_VERBOSE"))
-    fprintf(stderr, "[e2] igemm4 Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MG=%d NT=%d CC=%d SK=%d WM=%d U=%d grid=%ld lds=%zu\n",
-            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, c.WM, U, grid, lds);
-  Igemm4Extra x{c.WM};
+    fprintf(stderr, "[e2] igemm4 Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MG=%d NT=%d CC=%d SK=%d WM=%d U=%d tiles=%ld grid=%ld lds=%zu\n",
+            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, c.WM, U, tiles, grid, lds);
+  Igemm4Extra x{c.WM, (int)tiles};
   switch (a.kw) {
     case 1: return e2i_igemm4_launch_k1(ctx, p, x, c.MT, c.NT, (int)grid, lds);
     case 3: return e2i_igemm4_launch_k3(ctx, p, x, c.MT, c.NT, (int)grid, lds);

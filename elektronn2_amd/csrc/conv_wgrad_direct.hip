@@ -579,19 +579,23 @@ static int launch_d(e2_ctx* ctx, const WdP& p, int grid, size_t lds) {
 
 template <int MT>
 static int dispatch_d2(e2_ctx* ctx, const WdP& p, int NT, int BP, int WK, int grid, size_t lds) {
+  // (MT x 4 tiles of 20+ blocks do not fit 256 registers: the compiler spills operand
+  // registers of the hand-scheduled loop to scratch -- no such instance, check_scratch.py)
   if (WK == 4) {
     if (BP == 128 && NT == 2) return launch_d<MT, 2, 128, 4>(ctx, p, grid, lds);
-    if (BP == 128 && NT == 4) return launch_d<MT, 4, 128, 4>(ctx, p, grid, lds);
     if (BP == 256 && NT == 2) return launch_d<MT, 2, 256, 4>(ctx, p, grid, lds);
-    if (BP == 256 && NT == 4) return launch_d<MT, 4, 256, 4>(ctx, p, grid, lds);
+    if constexpr (MT * 4 < 20) {
+      if (BP == 128 && NT == 4) return launch_d<MT, 4, 128, 4>(ctx, p, grid, lds);
+      if (BP == 256 && NT == 4) return launch_d<MT, 4, 256, 4>(ctx, p, grid, lds);
+    }
   } else if (BP == 128) {
     if (NT == 1) return launch_d<MT, 1, 128, 1>(ctx, p, grid, lds);
     if (NT == 2) return launch_d<MT, 2, 128, 1>(ctx, p, grid, lds);
-    if (NT == 4) return launch_d<MT, 4, 128, 1>(ctx, p, grid, lds);
+    if constexpr (MT * 4 < 20) if (NT == 4) return launch_d<MT, 4, 128, 1>(ctx, p, grid, lds);
   } else if (BP == 256) {
     if (NT == 1) return launch_d<MT, 1, 256, 1>(ctx, p, grid, lds);
     if (NT == 2) return launch_d<MT, 2, 256, 1>(ctx, p, grid, lds);
-    if (NT == 4) return launch_d<MT, 4, 256, 1>(ctx, p, grid, lds);
+    if constexpr (MT * 4 < 20) if (NT == 4) return launch_d<MT, 4, 256, 1>(ctx, p, grid, lds);
   }
   e2_set_error("wgrad(direct): no instance NT=%d BP=%d WK=%d", NT, BP, WK);
   return 2;

@@ -110,12 +110,31 @@ constexpr int g4_pairs() {
 
 struct Igemm4Extra {
   int WM;                 // compute waves along the channels (1, 2 or 4)
+  int tilesTotal;         // N * splitK * nMT * Do * nPT
 };
 
+// one (n, k-split, channel tile, z-plane, position tile) unit of work
+struct G4Tile {
+  int z, mt, ks, n;
+  int q0, r0, c0, L;      // first position, its row / column, span length in floats
+  int cb, ce;             // chunk range of this tile's K split
+  long span_lo;
+};
+
+// The kernel is PERSISTENT: work-group w walks the tiles w, w + grid, w + 2*grid, ... and
+// treats the (tile, channel chunk) pairs as ONE sequence of items staged through a ring of
+// three LDS buffers.  The producer waves run two items ahead, so at the barrier that opens
+// item i the data of item i+1 has landed as well: the compute waves fetch the first
+// operands of a chunk during the last step of the chunk before it and the step pipeline
+// runs through chunk boundaries without a bubble (the two-buffer form paid ~1.5 k cycles
+// per chunk); a work-group pays the DMA latency once, not once per tile, and tile counts
+// per work-group differ by at most one (the one-tile-per-work-group grid left up to half
+// of the last round idle).
 template <int MG, int NT, int KW>
 __global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int U = g4_pairs<MG, NT, KW>();
+  constexpr int NBUF = 3;
   const int WM = x.WM, WN = 4 / WM;
   const int BM = 4 * MG * WM, BN = 64 * NT * WN;
   const int CC = p.CC;
@@ -123,202 +142,230 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x)
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = wave8 & 3;
   const bool producer = wave8 >= 4;
-
-  int bid = blockIdx.x;
-  const int pt = bid % p.nPT; bid /= p.nPT;
-  const int z = bid % p.Do;  bid /= p.Do;
-  const int mt = bid % p.nMT; bid /= p.nMT;
-  const int ks = bid % p.splitK;
-  const int n = bid / p.splitK;
-
-  const int q0 = pt * BN;
-  const int qlast = min(q0 + BN, p.Q) - 1;
-  const int r0 = q0 / p.Wo, c0 = q0 - r0 * p.Wo;
-  const int rl = qlast / p.Wo, cl = qlast - rl * p.Wo;
   const int isY = (int)p.isY;
-  const long span_lo = (long)r0 * p.isY + c0;
-  const int L = (rl - r0) * isY + (cl - c0) + (p.kh - 1) * isY + p.kw;
   const int Lpad = p.Lpad;
-
   const int nChunks = p.kd * p.nChunkC;
-  const int per = (nChunks + p.splitK - 1) / p.splitK;
-  const int cb = ks * per, ce = min(cb + per, nChunks);
+  const int per = (nChunks + p.splitK - 1) / p.splitK;    // (the host keeps every split non-empty)
+
+  auto decode = [&](int t, G4Tile& T) {
+    const int pt = t % p.nPT; t /= p.nPT;
+    T.z = t % p.Do; t /= p.Do;
+    T.mt = t % p.nMT; t /= p.nMT;
+    T.ks = t % p.splitK;
+    T.n = t / p.splitK;
+    T.q0 = pt * BN;
+    const int qlast = min(T.q0 + BN, p.Q) - 1;
+    T.r0 = T.q0 / p.Wo; T.c0 = T.q0 - T.r0 * p.Wo;
+    const int rl = qlast / p.Wo, cl = qlast - rl * p.Wo;
+    T.span_lo = (long)T.r0 * p.isY + T.c0;
+    T.L = (rl - T.r0) * isY + (cl - T.c0) + (p.kh - 1) * isY + p.kw;
+    T.cb = T.ks * per; T.ce = min(T.cb + per, nChunks);
+  };
 
   if (producer) {
-    // ---- producers: input spans of chunk ch -> LDS buffer (ch - cb) & 1.  Every chunk
-    // stages CC channels; channels past Cin repeat the last one (their weights are zero).
+    // ---- producers: input spans of item i -> LDS buffer i % 3.  Every chunk stages CC
+    // channels; channels past Cin repeat the last one (their weights are zero).
     const int pw = wave8 - 4;
-    const int nJ = (L + 63) >> 6;
-    const int nJ16 = (L + 255) >> 8;
-    const float* in_n = p.in + (long)n * p.isN + (long)z * p.isZ + span_lo;
-    auto stage = [&](int ch, int buf) {
+    auto stage = [&](const G4Tile& T, int ch, int buf) {
+      const int nJ = (T.L + 63) >> 6;
+      const int nJ16 = (T.L + 255) >> 8;
       const int dz = ch / p.nChunkC;
       const int cbase = (ch - dz * p.nChunkC) * CC;
       float* xl = smem + buf * p.bufFloats;
-      const float* xb = in_n + (long)dz * p.isZ;
+      const float* xb = p.in + (long)T.n * p.isN + (long)(T.z + dz) * p.isZ + T.span_lo;
       for (int cc = pw; cc < CC; cc += 4) {
         const int ci = min(cbase + cc, p.Cin - 1);
         const float* src = xb + (long)ci * p.isC;
         float* dst = xl + cc * Lpad;
-        const bool tail_row = (ci == p.Cin - 1) && (z + dz == p.Din - 1) && (n == p.N - 1);
+        // 16-byte pieces; the straddling lane over-reads <= 12 bytes, which stays inside
+        // the tensor except on its very last row: that row goes by dwords
+        const bool tail_row = (ci == p.Cin - 1) && (T.z + dz == p.Din - 1) && (T.n == p.N - 1);
         if (!tail_row) {
           for (int j = 0; j < nJ16; ++j) {
             const int u = 256 * j + 4 * lane;
-            if (u < L) glds16(src + u, dst + 256 * j);
+            if (u < T.L) glds16(src + u, dst + 256 * j);
           }
         } else {
           for (int j = 0; j < nJ; ++j)
-            if (64 * j + lane < L) glds4(src + 64 * j + lane, dst + 64 * j);
+            if (64 * j + lane < T.L) glds4(src + 64 * j + lane, dst + 64 * j);
         }
       }
     };
-    if (cb < ce) stage(cb, 0);
-    for (int ch = cb; ch < ce; ++ch) {
+    // item counts: barriers to take (all of this work-group's items) / items staged
+    int nItems = 0;
+    for (int t = blockIdx.x; t < x.tilesTotal; t += gridDim.x) {
+      G4Tile T; decode(t, T);
+      nItems += T.ce - T.cb;
+    }
+    G4Tile S; int st = blockIdx.x, sch = 0, staged = 0;      // the staging cursor
+    if (st < x.tilesTotal) { decode(st, S); sch = S.cb; }
+    auto stage_next = [&]() {
+      if (staged >= nItems) return;
+      stage(S, sch, staged % NBUF);
+      ++staged;
+      if (++sch == S.ce) {
+        st += gridDim.x;
+        if (st < x.tilesTotal) { decode(st, S); sch = S.cb; }
+      }
+    };
+    stage_next();
+    stage_next();
+    for (int i = 0; i < nItems; ++i) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                       // chunk ch is in LDS; buffer of ch-1 is free
-      if (ch + 1 < ce) stage(ch + 1, ((ch - cb) & 1) ^ 1);
+      __syncthreads();            // items <= i+1 are in LDS; the buffer of item i-1 is free
+      stage_next();               // item i+2 -> the buffer of item i-1
     }
     return;
   }
 
   // ---- compute waves ----------------------------------------------------------
   const int wm = wave % WM, wn = wave / WM;
-  const int m0w = mt * BM + wm * (4 * MG);            // the wave's first output channel
-  const int qw = q0 + wn * (64 * NT);                 // ... and first position
-  unsigned posoffB[NT];
-#pragma unroll
-  for (int nb = 0; nb < NT; ++nb) {
-    const int q = min(qw + nb * 64 + lane, p.Q - 1);
-    const int r = q / p.Wo, c = q - r * p.Wo;
-    posoffB[nb] = 4u * (unsigned)((r - r0) * isY + (c - c0));
-  }
-  f32x4 acc[MG][NT];
-#pragma unroll
-  for (int g = 0; g < MG; ++g)
-#pragma unroll
-    for (int nb = 0; nb < NT; ++nb) acc[g][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   G4Addr<NT, KW, U> ad;
 #pragma unroll
   for (int j = 0; j < KW; ++j) ad.voff[j] = 4u * (unsigned)(lane + 4 * j * p.coP);
   const int nCGp = p.ciP >> 2;
-  const int nCblk = CC / U;                           // channel blocks per chunk (CC % U == 0)
-  const int nSteps = nCblk * p.kh;
+  const int nCblk = CC / U;                           // channel blocks per chunk (CC % 2U == 0)
+  const int nSteps = nCblk * p.kh;                    // even
   const unsigned stepY = 4u * (unsigned)isY, stepC = 4u * (unsigned)Lpad;
   const long cgStride = (long)p.THW * 4 * p.coP;      // floats between two channel groups' rows
-
-  // operands' addresses of the step (channel block cblk, tap row ty) of chunk (dz, cbase):
-  // channels cbase + cblk*U + u; their image rows are row0 + (u >> 2) * THW*4 + (u & 3)
-  auto set_addr = [&](int cblk, int ty, int dz, int cbase, unsigned xbase) {
-    const int cc0 = cbase + cblk * U;
-    const long row0 = ((long)(dz * nCGp + (cc0 >> 2)) * p.THW + ty * p.kw) * 4 + (cc0 & 3);
-    const float* a0 = p.wp + row0 * p.coP + m0w;
-    const unsigned so0 = xbase + (unsigned)(cblk * U) * stepC + (unsigned)ty * stepY;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      ad.abase[u] = a0 + (long)(u >> 2) * cgStride + (long)(u & 3) * p.coP;
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) ad.b[u][nb] = posoffB[nb] + so0 + (unsigned)u * stepC;
-    }
-  };
+  const int R = p.upz * p.upy * p.upx;
   constexpr int NA = G4Regs<MG, NT, KW, U>::NA;
-  constexpr int RALL = U * KW * (NA + NT), RA = U * KW * NA;
+  constexpr int RALL = U * KW * (NA + NT);
   G4Regs<MG, NT, KW, U> g0, g1;
+  int item = 0;                                       // index of the tile's first item (ring position)
 #define E2_WAIT()                                                         \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
   __builtin_amdgcn_sched_barrier(0);
-  // (fc, fty): the step whose operands are fetched next; past the chunk's end the last
-  // step is fetched again (never used)
+
+  for (int t = blockIdx.x; t < x.tilesTotal; t += gridDim.x) {
+    G4Tile T; decode(t, T);
+    const int m0w = T.mt * BM + wm * (4 * MG);        // the wave's first output channel
+    const int qw = T.q0 + wn * (64 * NT);             // ... and first position
+    unsigned posoffB[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+      const int q = min(qw + nb * 64 + lane, p.Q - 1);
+      const int r = q / p.Wo, c = q - r * p.Wo;
+      posoffB[nb] = 4u * (unsigned)((r - T.r0) * isY + (c - T.c0));
+    }
+    f32x4 acc[MG][NT];
+#pragma unroll
+    for (int g = 0; g < MG; ++g)
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) acc[g][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nCh = T.ce - T.cb;
+    const int total = nCh * nSteps;
+    // fetch cursor: chunk (relative to the tile), channel block, tap row + what follows from
+    // the chunk: kernel plane dz, first channel, LDS buffer
+    int fch = 0, fc = 0, fty = 0;
+    int fdz = T.cb / p.nChunkC;
+    int fcb = (T.cb - fdz * p.nChunkC) * CC;
+    int fbuf = item % NBUF;
+    // operands' addresses of the step under the cursor: channels fcb + fc*U + u; their image
+    // rows are row0 + (u >> 2) * THW*4 + (u & 3)
+    auto set_addr = [&]() {
+      const int cc0 = fcb + fc * U;
+      const long row0 = ((long)(fdz * nCGp + (cc0 >> 2)) * p.THW + fty * p.kw) * 4 + (cc0 & 3);
+      const float* a0 = p.wp + row0 * p.coP + m0w;
+      const unsigned so0 = lds_addr(smem + fbuf * p.bufFloats) + (unsigned)(fc * U) * stepC +
+                           (unsigned)fty * stepY;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ad.abase[u] = a0 + (long)(u >> 2) * cgStride + (long)(u & 3) * p.coP;
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) ad.b[u][nb] = posoffB[nb] + so0 + (unsigned)u * stepC;
+      }
+    };
+    // advance the cursor by one step; past the tile's end it stays on the last step (that
+    // fetch is never used)
 #define E2_NEXT()                                                         \
-  {                                                                       \
-    ++fty;                                                                \
-    const bool wrap = (fty == p.kh);                                      \
-    fty = wrap ? 0 : fty;                                                 \
-    fc += wrap ? 1 : 0;                                                   \
-    const bool end = (fc == nCblk);                                       \
-    fc = end ? nCblk - 1 : fc;                                            \
-    fty = end ? p.kh - 1 : fty;                                           \
-  }
-  for (int ch = cb; ch < ce; ++ch) {
-    const int cur = (ch - cb) & 1;
-    const int dz = ch / p.nChunkC;
-    const int cbase = (ch - dz * p.nChunkC) * CC;
-    const unsigned xbase = lds_addr(smem + cur * p.bufFloats);
-    int fc = 0, fty = 0;
-    // weights of the first step: independent of the LDS contents, start them early
-    set_addr(0, 0, dz, cbase, xbase);
-    g4_reads<MG, NT, KW, U, 0, RA>(g0, ad);
-    __syncthreads();                         // the producers saw their DMA land
-    g4_reads<MG, NT, KW, U, RA, RALL>(g0, ad);
+    {                                                                     \
+      int nty = fty + 1, nfc = fc, nch = fch;                             \
+      if (nty == p.kh) { nty = 0; ++nfc; }                                \
+      if (nfc == nCblk) { nfc = 0; ++nch; }                               \
+      if (nch < nCh) {                                                    \
+        if (nch != fch) {                                                 \
+          fcb += CC;                                                      \
+          if (fcb >= p.nChunkC * CC) { fcb = 0; ++fdz; }                  \
+          fbuf = (fbuf + 1 == NBUF) ? 0 : fbuf + 1;                       \
+        }                                                                 \
+        fty = nty; fc = nfc; fch = nch;                                   \
+      }                                                                   \
+    }
+    __syncthreads();                         // the tile's first item (and the one after it) landed
+    set_addr();
+    g4_reads<MG, NT, KW, U, 0, RALL>(g0, ad);
     E2_WAIT()
     g0.touch();
-    int s = 0;
-    for (; s + 1 < nSteps; s += 2) {
+    int cs = 0;                              // steps computed in the current chunk
+    for (int s = 0; s < total; s += 2) {
       E2_NEXT()
-      set_addr(fc, fty, dz, cbase, xbase);
+      set_addr();
       __builtin_amdgcn_sched_barrier(0);
       g4_steps<MG, NT, KW, U, 0>(g0, g1, acc, ad);     // compute s, fetch s+1
       E2_WAIT()
       g1.touch();
       E2_NEXT()
-      set_addr(fc, fty, dz, cbase, xbase);
+      set_addr();
       __builtin_amdgcn_sched_barrier(0);
       g4_steps<MG, NT, KW, U, 0>(g1, g0, acc, ad);     // compute s+1, fetch s+2
       E2_WAIT()
       g0.touch();
+      cs += 2;
+      if (cs == nSteps) {                    // chunk done (its successor's first operands are in g0)
+        cs = 0;
+        if (s + 2 < total) __syncthreads();  // opens the next item of this tile
+      }
     }
-    if (s < nSteps) g4_only<MG, NT, KW, U, 0>(g0, acc);
-  }
 #undef E2_NEXT
-#undef E2_WAIT
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  g0.touch();
-  g1.touch();
+    item += nCh;
 
-  // ---- epilogue: register r of accumulator (g, nb) = channel m0w + 4g + r at the lane's
-  // position; every store instruction writes 64 consecutive positions of one channel ----
-  const int R = p.upz * p.upy * p.upx;
-  long ooff[NT];
-  bool ok[NT];
+    // ---- epilogue: register r of accumulator (g, nb) = channel m0w + 4g + r at the lane's
+    // position; every store instruction writes 64 consecutive positions of one channel ----
+    unsigned ooff[NT];          // (offset inside one output plane: fits 32 bits)
+    bool ok[NT];
 #pragma unroll
-  for (int nb = 0; nb < NT; ++nb) {
-    const int q = qw + nb * 64 + lane;
-    ok[nb] = q < p.Q;
-    const int qq = min(q, p.Q - 1);
-    const int r = qq / p.Wo, c = qq - r * p.Wo;
-    ooff[nb] = (long)(r * p.upy) * p.osY + (long)c * p.upx;
-  }
-  float* ob = p.out + (long)n * p.osN + (long)(z * p.upz) * p.osZ;
+    for (int nb = 0; nb < NT; ++nb) {
+      const int q = qw + nb * 64 + lane;
+      ok[nb] = q < p.Q;
+      const int qq = min(q, p.Q - 1);
+      const int r = qq / p.Wo, c = qq - r * p.Wo;
+      ooff[nb] = (unsigned)(r * p.upy) * (unsigned)p.osY + (unsigned)(c * p.upx);
+    }
+    float* ob = p.out + (long)T.n * p.osN + (long)(T.z * p.upz) * p.osZ;
 #pragma unroll
-  for (int g = 0; g < MG; ++g) {
+    for (int g = 0; g < MG; ++g) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int co = m0w + 4 * g + rr;                 // wave-uniform
-      if (co >= p.Cout) continue;
-      float* dst;
-      if (R == 1) {
-        dst = ob + (long)co * p.osC;
-      } else {
-        const int cr = co / R, sub = co - cr * R;
-        const int rz = sub / (p.upy * p.upx);
-        const int rem = sub - rz * (p.upy * p.upx);
-        const int ry = rem / p.upx, rx = rem - ry * p.upx;
-        dst = ob + (long)cr * p.osC + (long)rz * p.osZ + (long)ry * p.osY + rx;
-      }
-      const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) {
-        if (!ok[nb]) continue;
-        float v = acc[g][nb][rr];
-        if (p.bias) {
-          v += bv;
-          if (p.act == E2_ACT_RELU) v = (v > 0.f) ? v : ((v == 0.f) ? 0.f : -0.f);
+      for (int rr = 0; rr < 4; ++rr) {
+        const int co = m0w + 4 * g + rr;                 // wave-uniform
+        if (co >= p.Cout) continue;
+        float* dst;
+        if (R == 1) {
+          dst = ob + (long)co * p.osC;
+        } else {
+          const int cr = co / R, sub = co - cr * R;
+          const int rz = sub / (p.upy * p.upx);
+          const int rem = sub - rz * (p.upy * p.upx);
+          const int ry = rem / p.upx, rx = rem - ry * p.upx;
+          dst = ob + (long)cr * p.osC + (long)rz * p.osZ + (long)ry * p.osY + rx;
         }
-        if (p.atomic) unsafeAtomicAdd(dst + ooff[nb], v);
-        else dst[ooff[nb]] = v;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+          if (!ok[nb]) continue;
+          float v = acc[g][nb][rr];
+          if (p.bias) {
+            v += bv;
+            if (p.act == E2_ACT_RELU) v = (v > 0.f) ? v : ((v == 0.f) ? 0.f : -0.f);
+          }
+          if (p.atomic) unsafeAtomicAdd(dst + ooff[nb], v);
+          else dst[ooff[nb]] = v;
+        }
       }
     }
   }
+#undef E2_WAIT
 }
 
 // ---- launch helpers ----------------------------------------------------------
@@ -336,10 +383,13 @@ static int igemm4_launch(e2_ctx* ctx, const IgemmP& p, const Igemm4Extra& x, int
   return 0;
 }
 
-// the (MG, NT) instances: channels per wave 4*MG in {20, 32, 40, 52, 64, 76, 80, 100}
+// the (MG, NT) instances: channels per wave 4*MG in {20, 32, 40, 52, 64, 76, 80, 100}.
+// (Only tiles whose accumulators + two operand sets fit 256 registers WITHOUT scratch:
+// the build fails on a non-zero ScratchSize of these kernels, csrc/check_scratch.py -- a
+// spilled operand register is copied while the asm load that fills it is in flight.)
 #define E2_IGEMM4_INSTANCES(X) \
-  X(5, 2) X(5, 4) X(8, 2) X(8, 4) X(10, 2) X(10, 4) X(13, 1) X(13, 2) X(16, 1) X(16, 2) \
-  X(19, 1) X(19, 2) X(20, 1) X(20, 2) X(25, 1) X(25, 2)
+  X(5, 2) X(5, 4) X(8, 2) X(8, 4) X(10, 2) X(10, 3) X(13, 1) X(13, 2) X(16, 1) X(16, 2) \
+  X(19, 1) X(20, 1) X(25, 1)
 
 template <int KW>
 static int igemm4_dispatch(e2_ctx* ctx, const IgemmP& p, const Igemm4Extra& x, int MG, int NT,
