@@ -108,61 +108,66 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     return cands + igemm4_candidates(cout, cin, k, out_sp, split_k)
 
 
-IGEMM4_INSTANCES = [(5, 2), (5, 4), (8, 2), (8, 4), (10, 2), (10, 3), (13, 1), (13, 2), (16, 1),
-                    (16, 2), (19, 1), (20, 1), (25, 1)]
+IGEMM4_INSTANCES = [(4, 2), (5, 1), (5, 2), (7, 1), (7, 2), (8, 1), (10, 1), (13, 1), (16, 1)]
 
 
 def g4_pairs(mg, nt, kw):
     """input channels per pipeline step of an igemm4 instance (csrc/igemm4_core.hpp g4_pairs)"""
     na = (4 * mg + 63) // 64
     u = 1
-    while u < 8 and u * kw * mg * nt < 96 and 2 * (2 * u) * kw * (na + nt) + 4 * mg * nt <= 200:
+    while u < 8 and u * kw * mg * nt < 40 and 2 * (2 * u) * kw * (na + nt) + 4 * mg * nt <= 88:
         u *= 2
     return u
 
 
 def igemm4_candidates(cout, cin, k, out_sp, split_k=True, n_cu=256):
-    """"4,MG,NT,CC,SK,WM": the 4x4x1-MFMA kernel (channels padded to 4, not 16).  Tile
-    heights (4*MG*WM) with the least channel padding, a few position-tile widths, channel
-    chunks that are multiples of the instance's step, split-K only when the grid is small."""
+    """"4,MG,NT,CC,SK,WM,WN,G": the 4x4x1-MFMA kernel (channels padded to 4, not 16; small
+    tiles per wave, WM x WN <= 12 compute waves per work-group, persistent work-groups).
+    Channel coverage 4*MG*WM with the least padding, a few position widths 64*NT*WN, small
+    channel chunks (they only set the LDS footprint), split-K only when the grid is small."""
     if k[2] not in (1, 3, 4, 5):
         return []
     q = out_sp[1] * out_sp[2]
     cinp = -(-cin // 4) * 4
+    groups = -(-cout // 4)
     shapes = []
     for mg, nt in IGEMM4_INSTANCES:
-        for wm in (1, 2, 4):
+        for wm in range(1, 13):
             bm = 4 * mg * wm
             nmt = -(-cout // bm)
             pad = nmt * bm - cout
             if pad >= 4 * mg and wm > 1:          # a whole wave of the tile would idle
                 continue
-            if nmt > 1 and bm < 40:
+            if nmt > 1 and wm < 3 and mg * wm < groups / 4.0:
                 continue
-            shapes.append((pad / float(cout), -bm, mg, nt, wm, nmt))
+            for wn in (1, 2, 3, 4, 6, 12):
+                if wm * wn > 12 or (wm * wn < 6 and wm * wn != 4):
+                    continue
+                shapes.append((round(pad / float(cout), 3), -wm * wn, mg, nt, wm, wn, nmt))
     shapes.sort()
     best_pad = shapes[0][0] if shapes else 0
     cands = []
-    for padf, _, mg, nt, wm, nmt in shapes:
-        if padf > best_pad + 0.08:
+    for padf, _, mg, nt, wm, wn, nmt in shapes:
+        if padf > best_pad + 0.06:
             break
         u = g4_pairs(mg, nt, k[2])
         step = u * 4 // math.gcd(u, 4)
         if ((step // u) * k[1]) % 2:               # an even number of pipeline steps per chunk
             step *= 2
-        bn = 64 * nt * (4 // wm)
+        bn = 64 * nt * wn
+        if bn > 2 * q:
+            continue
         base = out_sp[0] * (-(-q // bn)) * nmt
-        sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 6)
-        # the chunk size only sets the LDS footprint (three ring buffers): a few small ones
-        ccs = sorted(set(-(-c // step) * step for c in (8, 16, 32) if c >= 4))
-        ccs = [c for c in ccs if -(-cin // c) * c <= cinp + 32][:3]
+        sks = (1,) if (base >= 160 or not split_k) else (1, 2, 4)
+        ccs = sorted(set(-(-c // step) * step for c in (8, 16) if c >= 4))
+        ccs = [c for c in ccs if -(-cin // c) * c <= cinp + 32][:2]
         for cc in ccs:
             for sk in sks:
                 tiles = base * sk
-                for g in (1, 2, 3):
-                    if g > 1 and tiles <= (g - 1) * n_cu:
+                for g in (1, 2):
+                    if g > 1 and (tiles <= n_cu or wm * wn > 6):
                         continue
-                    cands.append("4,%d,%d,%d,%d,%d,%d" % (mg, nt, cc, sk, wm, g))
+                    cands.append("4,%d,%d,%d,%d,%d,%d,%d" % (mg, nt, cc, sk, wm, wn, g))
     return cands
 
 

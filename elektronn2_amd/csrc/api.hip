@@ -68,11 +68,11 @@ extern "C" int e2_set_tiling(e2_ctx* ctx, int kind, const char* cfg) {
   E2_REQUIRE(strlen(cfg) < sizeof(ctx->tiling[0]), "e2_set_tiling: configuration string too long");
   if (cfg[0]) {
     int v[5], n = sscanf(cfg, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
-    int v5 = 0, v6 = 0;
-    if (n == 5 && kind == E2_TILING_IGEMM) n += sscanf(cfg, "%*d,%*d,%*d,%*d,%*d,%d,%d", &v5, &v6);
-    E2_REQUIRE(kind == E2_TILING_IGEMM ? (n == 4 || ((n == 6 || n == 7) && v[0] == 4)) : n == 5,
+    int v5 = 0, v6 = 0, v7 = 0;
+    if (n == 5 && kind == E2_TILING_IGEMM) n += sscanf(cfg, "%*d,%*d,%*d,%*d,%*d,%d,%d,%d", &v5, &v6, &v7);
+    E2_REQUIRE(kind == E2_TILING_IGEMM ? (n == 4 || (n == 8 && v[0] == 4)) : n == 5,
                "e2_set_tiling: '%s' is not %s", cfg,
-               kind == E2_TILING_IGEMM ? "\"MT,NT,CC,SK\" or \"4,MG,NT,CC,SK,WM[,G]\"" : "\"MT,NT,WK,BP,PS\"");
+               kind == E2_TILING_IGEMM ? "\"MT,NT,CC,SK\" or \"4,MG,NT,CC,SK,WM,WN,G\"" : "\"MT,NT,WK,BP,PS\"");
   }
   strcpy(ctx->tiling[kind], cfg);
   return 0;

@@ -216,9 +216,9 @@ extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs
 
 // ---- host side ----------------------------------------------------------------
 // kind 0: 16x16x4 kernel, tile 16*MT channels x 64*NT positions ("MT,NT,CC,SK");
-// kind 4: 4x4x1 kernel (igemm4_core.hpp), MT = channel groups of 4 per wave, WM = compute
-// waves along the channels ("4,MG,NT,CC,SK,WM")
-struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1, G = 1; };
+// kind 4: 4x4x1 kernel (igemm4_core.hpp), MT = channel groups of 4 per wave, WM x WN compute
+// waves along the channels / positions, G work-groups per CU ("4,MG,NT,CC,SK,WM,WN,G")
+struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1, WN = 4, G = 1; };
 
 static const int kMTs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13};
 
@@ -270,12 +270,12 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   const char* force = ctx->tiling[E2_TILING_IGEMM];
   if (force[0]) {
     IgemmCfg f{0, 0, 0, 0};
-    int v[7];
-    const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+    int v[8];
+    const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
     if (nf == 4) { f.MT = v[0]; f.NT = v[1]; f.CC = v[2]; f.SK = v[3]; *ok = 1; return f; }
-    if (nf >= 6 && v[0] == 4) {
-      f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5];
-      f.G = nf == 7 ? v[6] : 1; *ok = 1; return f;
+    if (nf == 8 && v[0] == 4) {
+      f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5]; f.WN = v[6];
+      f.G = v[7]; *ok = 1; return f;
     }
   }
   const double out_bytes = 4.0 * a.N * a.Cout * a.Do * (double)Q;
@@ -367,7 +367,7 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   E2_REQUIRE(has_fast_kw(a.kw), "igemm4: tap rows of %d have no instance", a.kw);
   const int U = e2i_igemm4_pairs(a.kw, c.MT, c.NT);
   E2_REQUIRE(U > 0, "igemm4: no instance MG=%d NT=%d", c.MT, c.NT);
-  E2_REQUIRE(c.WM == 1 || c.WM == 2 || c.WM == 4, "igemm4: WM must be 1, 2 or 4");
+  E2_REQUIRE(c.WM >= 1 && c.WN >= 1 && c.WM * c.WN <= 12, "igemm4: WM x WN compute waves, at most 12");
   E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC % U == 0 && ((c.CC / U) * a.kh) % 2 == 0,
              "igemm4: CC must be a multiple of 4 and of %d with an even number of steps per chunk", U);
   E2_REQUIRE(c.SK >= 1 && c.G >= 1 && c.G <= 8, "igemm4: SK must be >= 1, G in 1..8");
@@ -379,7 +379,7 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   p.isN = a.isN; p.isC = a.isC; p.isZ = a.isZ; p.isY = a.isY;
   p.osN = a.osN; p.osC = a.osC; p.osZ = a.osZ; p.osY = a.osY;
   p.ciP = a.ciP; p.coP = a.coP;
-  const int BN = 64 * c.NT * (4 / c.WM), BM = 4 * c.MT * c.WM;
+  const int BN = 64 * c.NT * c.WN, BM = 4 * c.MT * c.WM;
   p.Lpad = pad16mod32(span_lmax(a, BN) + 3);
   p.CC = c.CC;
   p.Din = a.Do + a.kd - 1;
@@ -412,9 +412,9 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   if (p.atomic)
     if (int rc = igemm_zero_output(ctx, a)) return rc;
   if (e2_dbg_env("E2_VERBOSE"))
-    fprintf(stderr, "[e2] igemm4 Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MG=%d NT=%d CC=%d SK=%d WM=%d U=%d tiles=%ld grid=%ld lds=%zu\n",
-            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, c.WM, U, tiles, grid, lds);
-  Igemm4Extra x{c.WM, (int)tiles};
+    fprintf(stderr, "[e2] igemm4 Cin=%d Cout=%d k=%d,%d,%d out=%d,%d,%d MG=%d NT=%d CC=%d SK=%d WM=%d WN=%d U=%d tiles=%ld grid=%ld lds=%zu\n",
+            a.Cin, a.Cout, a.kd, a.kh, a.kw, a.Do, a.Ho, a.Wo, c.MT, c.NT, c.CC, p.splitK, c.WM, c.WN, U, tiles, grid, lds);
+  Igemm4Extra x{c.WM, c.WN, (int)tiles};
   switch (a.kw) {
     case 1: return e2i_igemm4_launch_k1(ctx, p, x, c.MT, c.NT, (int)grid, lds);
     case 3: return e2i_igemm4_launch_k3(ctx, p, x, c.MT, c.NT, (int)grid, lds);

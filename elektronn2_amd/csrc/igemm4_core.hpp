@@ -20,9 +20,13 @@
 //   accumulator g,nb: 4 registers = channels 4g..4g+3 at the lane's position.
 // A step = U consecutive input channels x the KW taps of one tap row; the operands of step
 // s+1 are fetched while step s computes (two register sets), retired by one s_waitcnt.
-// Work-group: 4 compute waves (WM along the channels x 4/WM along the positions) + 4
-// producer waves that stage the input spans of the next channel chunk by LDS-DMA, exactly
-// as in igemm_core.hpp.
+// Work-group: WM x WN <= 12 compute waves (WM along the channels, WN along the positions)
+// + 4 producer waves that stage the input spans of the coming channel chunks by LDS-DMA.
+// Unlike the 32-cycle 16x16x4 MFMA, an 8-cycle 4x4x1 MFMA leaves no room to issue anything
+// else from the SAME wave for free (measured: one compute wave per SIMD reaches 40-60 % of
+// the pipe, profiles/r02_b_igemm4_sweeps.txt), so the tiles per wave are small (<= 64
+// accumulator registers, <= 128 VGPRs) and up to three compute waves share a SIMD: while
+// one issues its loads or address arithmetic the others keep the matrix pipe busy.
 #pragma once
 #include "igemm_core.hpp"
 
@@ -52,17 +56,22 @@ struct G4Addr {
 };
 
 // read R of a step: all weight (global) loads first -- the longer latency -- then the LDS reads
+// E2_G4_ABLATE (timing experiments only, never in a release build): 1 = no weight loads
+// inside the step loop, 2 = no LDS reads, 4 = no MFMAs
+#ifndef E2_G4_ABLATE
+#define E2_G4_ABLATE 0
+#endif
 template <int MG, int NT, int KW, int U, int R>
 __device__ __forceinline__ void g4_read(G4Regs<MG, NT, KW, U>& g, const G4Addr<NT, KW, U>& ad) {
   constexpr int NA = G4Regs<MG, NT, KW, U>::NA;
   constexpr int RA = U * KW * NA;
   if constexpr (R < RA) {
     constexpr int u = R / (KW * NA), j = (R / NA) % KW, i = R % NA;
-    g.a[u][j][i] = gl_ld<i * 256>(ad.abase[u], ad.voff[j]);
+    if constexpr (!(E2_G4_ABLATE & 1)) g.a[u][j][i] = gl_ld<i * 256>(ad.abase[u], ad.voff[j]);
   } else {
     constexpr int rb = R - RA;
     constexpr int u = rb / (KW * NT), j = (rb / NT) % KW, nb = rb % NT;
-    g.b[u][j][nb] = lds_ld<j * 4>(ad.b[u][nb]);
+    if constexpr (!(E2_G4_ABLATE & 2)) g.b[u][j][nb] = lds_ld<j * 4>(ad.b[u][nb]);
   }
 }
 template <int MG, int NT, int KW, int U, int R0, int R1>
@@ -75,6 +84,7 @@ __device__ __forceinline__ void g4_reads(G4Regs<MG, NT, KW, U>& g, const G4Addr<
 template <int MG, int NT, int KW, int U, int I>
 __device__ __forceinline__ void g4_mfma(const G4Regs<MG, NT, KW, U>& cur, f32x4 (&acc)[MG][NT]) {
   constexpr int u = I / (KW * NT * MG), j = (I / (NT * MG)) % KW, nb = (I / MG) % NT, g = I % MG;
+  if constexpr (!(E2_G4_ABLATE & 4))
   acc[g][nb] = __builtin_amdgcn_mfma_f32_4x4x1f32(cur.a[u][j][g / 16], cur.b[u][j][nb], acc[g][nb],
                                                   4, g % 16, 0);
 }
@@ -98,20 +108,21 @@ __device__ __forceinline__ void g4_only(const G4Regs<MG, NT, KW, U>& cur, f32x4 
   if constexpr (I + 1 < U * KW * MG * NT) g4_only<MG, NT, KW, U, I + 1>(cur, acc);
 }
 
-// input channels per step: enough MFMAs (>= ~96, i.e. ~800 cycles) to cover an L2 round
-// trip of the weight loads, as far as two operand sets fit the register budget
+// input channels per step: >= ~40 MFMAs per step (the other compute waves of the SIMD cover
+// the rest of a weight load's round trip), as far as two operand sets fit 128 registers
 template <int MG, int NT, int KW>
 constexpr int g4_pairs() {
   constexpr int NA = (4 * MG + 63) / 64;
   int u = 1;
-  while (u < 8 && u * KW * MG * NT < 96 && 2 * (2 * u) * KW * (NA + NT) + 4 * MG * NT <= 200) u *= 2;
+  while (u < 8 && u * KW * MG * NT < 40 && 2 * (2 * u) * KW * (NA + NT) + 4 * MG * NT <= 88) u *= 2;
   return u;
 }
 
 struct Igemm4Extra {
-  int WM;                 // compute waves along the channels (1, 2 or 4)
+  int WM, WN;             // compute waves along the channels / the positions (WM * WN <= 12)
   int tilesTotal;         // N * splitK * nMT * Do * nPT
 };
+constexpr int kG4Producers = 4;
 
 // one (n, k-split, channel tile, z-plane, position tile) unit of work
 struct G4Tile {
@@ -131,17 +142,17 @@ struct G4Tile {
 // per work-group differ by at most one (the one-tile-per-work-group grid left up to half
 // of the last round idle).
 template <int MG, int NT, int KW>
-__global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x) {
+__global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int U = g4_pairs<MG, NT, KW>();
   constexpr int NBUF = 3;
-  const int WM = x.WM, WN = 4 / WM;
+  const int WM = x.WM, WN = x.WN;
   const int BM = 4 * MG * WM, BN = 64 * NT * WN;
   const int CC = p.CC;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = wave8 & 3;
-  const bool producer = wave8 >= 4;
+  const int wave = wave8;
+  const bool producer = wave8 >= WM * WN;
   const int isY = (int)p.isY;
   const int Lpad = p.Lpad;
   const int nChunks = p.kd * p.nChunkC;
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x)
   if (producer) {
     // ---- producers: input spans of item i -> LDS buffer i % 3.  Every chunk stages CC
     // channels; channels past Cin repeat the last one (their weights are zero).
-    const int pw = wave8 - 4;
+    const int pw = wave8 - WM * WN;
     auto stage = [&](const G4Tile& T, int ch, int buf) {
       const int nJ = (T.L + 63) >> 6;
       const int nJ16 = (T.L + 255) >> 8;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x)
       const int cbase = (ch - dz * p.nChunkC) * CC;
       float* xl = smem + buf * p.bufFloats;
       const float* xb = p.in + (long)T.n * p.isN + (long)(T.z + dz) * p.isZ + T.span_lo;
-      for (int cc = pw; cc < CC; cc += 4) {
+      for (int cc = pw; cc < ((E2_G4_ABLATE & 32) ? 0 : CC); cc += kG4Producers) {
         const int ci = min(cbase + cc, p.Cin - 1);
         const float* src = xb + (long)ci * p.isC;
         float* dst = xl + cc * Lpad;
@@ -233,9 +244,13 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x)
   constexpr int RALL = U * KW * (NA + NT);
   G4Regs<MG, NT, KW, U> g0, g1;
   int item = 0;                                       // index of the tile's first item (ring position)
+#if (E2_G4_ABLATE & 8)       // (timing experiment: results are garbage)
+#define E2_WAIT() __builtin_amdgcn_sched_barrier(0);
+#else
 #define E2_WAIT()                                                         \
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             \
   __builtin_amdgcn_sched_barrier(0);
+#endif
 
   for (int t = blockIdx.x; t < x.tilesTotal; t += gridDim.x) {
     G4Tile T; decode(t, T);
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x)
         const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
-          if (!ok[nb]) continue;
+          if (!ok[nb] || ((E2_G4_ABLATE & 64) && co > 0)) continue;
           float v = acc[g][nb][rr];
           if (p.bias) {
             v += bv;
@@ -378,18 +393,18 @@ static int igemm4_launch(e2_ctx* ctx, const IgemmP& p, const Igemm4Extra& x, int
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((igemm4_kernel<MG, NT, KW>), dim3(grid), dim3(512), lds, ctx->stream, p, x);
+  hipLaunchKernelGGL((igemm4_kernel<MG, NT, KW>), dim3(grid), dim3(64 * (x.WM * x.WN + kG4Producers)),
+                     lds, ctx->stream, p, x);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-// the (MG, NT) instances: channels per wave 4*MG in {20, 32, 40, 52, 64, 76, 80, 100}.
-// (Only tiles whose accumulators + two operand sets fit 256 registers WITHOUT scratch:
+// the (MG, NT) instances: channels per wave 4*MG in {16, 20, 28, 32, 40, 52, 64}.
+// (Only tiles whose accumulators + two operand sets fit 128 registers WITHOUT scratch:
 // the build fails on a non-zero ScratchSize of these kernels, csrc/check_scratch.py -- a
 // spilled operand register is copied while the asm load that fills it is in flight.)
 #define E2_IGEMM4_INSTANCES(X) \
-  X(5, 2) X(5, 4) X(8, 2) X(8, 4) X(10, 2) X(10, 3) X(13, 1) X(13, 2) X(16, 1) X(16, 2) \
-  X(19, 1) X(20, 1) X(25, 1)
+  X(4, 2) X(5, 1) X(5, 2) X(7, 1) X(7, 2) X(8, 1) X(10, 1) X(13, 1) X(16, 1)
 
 template <int KW>
 static int igemm4_dispatch(e2_ctx* ctx, const IgemmP& p, const Igemm4Extra& x, int MG, int NT,

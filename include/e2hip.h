@@ -70,10 +70,10 @@ int  e2_get_mfma_dtype(const e2_ctx* ctx);
  * per-op algorithm choice `dnn_conv3d(..., algo=...)` stood, computations.py:30,391).
  * kind E2_TILING_IGEMM: cfg = "MT,NT,CC,SK" for the packed forward / dgrad / UpConv
  * launches (16x16x4 MFMA kernel: 16*MT output channels x 64*NT positions per work-group,
- * CC input channels per LDS chunk, SK-way split of K), or cfg = "4,MG,NT,CC,SK,WM[,G]"
- * (4x4x1 MFMA kernel, persistent: 4*MG channels x 64*NT positions per WAVE, WM of the four
- * compute waves side by side along the channels and 4/WM along the positions, G work-groups
- * per CU walking the tiles); kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
+ * CC input channels per LDS chunk, SK-way split of K), or cfg = "4,MG,NT,CC,SK,WM,WN,G"
+ * (4x4x1 MFMA kernel, persistent: 4*MG channels x 64*NT positions per WAVE, WM x WN <= 12
+ * compute waves per work-group along the channels / positions, G work-groups per CU
+ * walking the tiles); kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
  * e2_conv3d_wgrad / e2_conv3d_wgrad_pad (WK 1 / 14 direct kernel, 0 / 4 LDS-staged;
  * BP positions per tile, PS position splits).  The setting holds for every following
  * launch of that kind on this context until changed; cfg NULL or "" returns the choice

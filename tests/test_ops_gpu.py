@@ -125,14 +125,15 @@ def test_conv3d_fused_bias_act(ctx, act, k):
         assert np.array_equal(g[:, 0], 0.5 * dout[:, 0]) and not g[:, 1].any()
 
 
-@pytest.mark.parametrize("force", ["4,5,2,8,1,1", "4,5,4,16,1,2,2", "4,8,2,24,1,4", "4,8,4,8,2,1",
-                                   "4,10,2,16,1,2,3", "4,10,3,8,3,1", "4,13,1,8,1,4", "4,13,2,24,1,2",
-                                   "4,16,1,16,1,1,2", "4,16,2,8,2,4", "4,19,1,24,1,2", "4,20,1,8,1,2",
-                                   "4,25,1,16,1,2", "4,25,1,8,2,2,2"])
+@pytest.mark.parametrize("force", ["4,4,2,8,1,4,3,1", "4,5,1,8,1,3,4,1", "4,5,2,16,1,1,4,2",
+                                   "4,5,2,8,2,3,2,1", "4,7,1,8,1,2,6,1", "4,7,2,24,1,2,2,1",
+                                   "4,8,1,16,1,2,4,1", "4,10,1,8,3,1,12,1", "4,13,1,8,1,1,4,2",
+                                   "4,16,1,16,1,1,6,1", "4,5,1,8,1,6,2,1", "4,13,1,24,1,4,1,1"])
 def test_conv3d_fwd_4x4_mfma_tilings(ctx, force):
-    """the 4x4x1-MFMA kernel (igemm4_core.hpp): every (MG, NT) instance, waves along the
-    channels (WM 1/2/4), channel chunks with a ragged last chunk (Cin = 22), split-K, an
-    odd Cout (50: not a multiple of 4), position tiles that straddle rows and planes' ends"""
+    """the 4x4x1-MFMA kernel (igemm4_core.hpp): every (MG, NT) instance, WM x WN compute
+    waves (4 .. 12 per work-group), one and two work-groups per CU walking the tiles,
+    channel chunks with a ragged last chunk (Cin = 22), split-K, an odd Cout (50: not a
+    multiple of 4), position tiles that straddle rows and planes' ends"""
     rng = np.random.RandomState(27)
     x = rng.rand(2, 22, 5, 13, 37).astype(np.float32)
     w = (rng.randn(50, 22, 3, 2, 3) / 12).astype(np.float32)
@@ -146,9 +147,10 @@ def test_conv3d_fwd_4x4_mfma_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
-@pytest.mark.parametrize("kw,force", [(1, "4,13,1,16,1,4"), (1, "4,25,1,32,1,2"), (1, "4,5,4,16,2,2"),
-                                      (4, "4,10,2,8,1,2"), (4, "4,16,1,12,2,1"),
-                                      (5, "4,8,4,8,1,1"), (5, "4,20,1,4,1,2")])
+@pytest.mark.parametrize("kw,force", [(1, "4,13,1,16,1,2,4,1"), (1, "4,5,2,32,1,5,2,1"),
+                                      (1, "4,7,2,16,2,4,1,1"), (4, "4,10,1,8,1,3,4,1"),
+                                      (4, "4,16,1,12,2,2,2,2"), (5, "4,8,1,8,1,4,3,1"),
+                                      (5, "4,5,1,4,1,5,2,1")])
 def test_conv3d_4x4_mfma_tap_widths_dgrad_and_fused_act(ctx, kw, force):
     """tap rows of 1, 4 and 5 (3 is covered above): forward, data gradient on the padded
     gradient buffer (strided rows) and the fused bias + relu epilogue with its signed
@@ -167,7 +169,7 @@ def test_conv3d_4x4_mfma_tap_widths_dgrad_and_fused_act(ctx, kw, force):
         y = torch.full(y_ref.shape, float("nan"), device="cuda")
         ctx.conv3d_fwd_packed(dev(x), ws, Co, k, y)
         assert relerr(y, y_ref) < TOL
-        if "," + force.split(",")[4] + "," == ",1,":      # no split-K: fused epilogue
+        if force.split(",")[4] == "1":                     # no split-K: fused epilogue
             ya = torch.full(y_ref.shape, float("nan"), device="cuda")
             ctx.conv3d_fwd_packed_act(dev(x), ws, Co, k, dev(b), 'relu', ya)
             pre = y_ref + b.reshape(1, -1, 1, 1, 1)
@@ -208,7 +210,7 @@ def test_conv3d_1x1_forced_tilings(ctx, force):
 
 
 @pytest.mark.parametrize("force", ["1,1,1,128,3", "2,2,1,256,5", "3,4,1,128,2", "4,1,1,256,7",
-                                   "5,2,1,128,1", "7,4,1,128,3", "7,2,1,256,2", "7,1,1,128,40",
+                                   "5,2,1,128,1", "7,2,1,128,3", "7,2,1,256,2", "7,1,1,128,40",
                                    "3,4,14,256,3", "2,2,14,128,5", "7,2,14,256,1", "1,4,14,128,40"])
 @pytest.mark.parametrize("k", [(2, 3, 3), (1, 1, 1), (1, 4, 1)])
 def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
@@ -240,7 +242,7 @@ def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
 
 
 @pytest.mark.parametrize("force", ["1,1,1,64,3", "2,2,1,128,5", "3,4,1,64,2", "4,1,4,128,7",
-                                   "5,2,1,64,1", "7,4,1,128,3", "1,1,4,64,2", "7,1,1,64,4"])
+                                   "5,2,1,64,1", "7,2,1,128,3", "1,1,4,64,2", "7,1,1,64,4"])
 def test_conv3d_wgrad_forced_tilings(ctx, force):
     rng = np.random.RandomState(8)
     x = rng.rand(2, 9, 4, 12, 21).astype(np.float32)
@@ -330,7 +332,7 @@ UPCONV_CASES = [(1, 8, 6, (2, 2, 2), (3, 4, 5), 'relu'), (1, 32, 16, (1, 2, 2), 
                 (2, 5, 7, (2, 1, 3), (2, 3, 4), 'lin'), (1, 64, 64, (2, 2, 2), (2, 9, 9), 'relu')]
 
 
-@pytest.mark.parametrize("force", ["4,16,2,16,1,1", "4,13,1,16,1,4,2", "4,8,4,8,2,2"])
+@pytest.mark.parametrize("force", ["4,16,1,16,1,2,2,1", "4,13,1,16,1,4,3,1", "4,4,2,16,2,2,3,2"])
 def test_upconv3d_4x4_mfma_scatter_epilogue(ctx, force):
     """UpConv forward through the 4x4x1 kernel: 1x1x1 GEMM to Cout * prod(pool) rows with the
     depth-to-space scatter in the epilogue (the backward's data gradient takes the same kernel)"""
