@@ -188,10 +188,11 @@ class Plan(object):
         return jobs
 
     # ---- second stream ----------------------------------------------------------------
-    def on_side(self, fn):
+    def on_side(self, fn, always=False):
         """run the launches of ``fn`` on the side stream, ordered after everything
-        issued on the main stream so far"""
-        if not self.use_side:
+        issued on the main stream so far.  ``always``: also when the general side-stream
+        switch is off (the weight repack: it overlaps the first layer's HBM-bound kernel)"""
+        if not (self.use_side or (always and self.use_side_pack)):
             return fn()
         ctx = self.ctx
         main = ctx.stream
@@ -247,6 +248,10 @@ class Plan(object):
         # measured (profiles/r01 notes in DESIGN.md): two MFMA-bound kernels sharing the
         # chip finish no sooner than back to back -- off unless E2_SIDE_STREAM=1
         self.use_side = os.environ.get("E2_SIDE_STREAM", "0") == "1"
+        # the repack of the weight images (index arithmetic, little memory traffic) is a
+        # parallel branch of the graph next to the first layer (VALU / HBM bound): the first
+        # kernel that reads a packed image joins it (Conv._plan_fwd -> join_side)
+        self.use_side_pack = os.environ.get("E2_SIDE_PACK", "1") == "1"
         self.out, self.grad, self.scratch = {}, {}, {}
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
@@ -271,7 +276,7 @@ class Plan(object):
     # ---- kernel sequences ----------------------------------------------------------------
     def _emit_forward(self):
         if self._pack_dev is not None:       # all packed weight images, one launch
-            self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev))
+            self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
         for n in self.nodes:
             n._plan_fwd(self)
         self.join_side()
