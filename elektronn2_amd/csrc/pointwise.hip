@@ -538,60 +538,120 @@ __global__ void malis_nll_kernel(View5 pr, const float* __restrict__ pos,
 }
 
 // ---------------------------------------------------------------------------
-// optimisers on a flat arena (hyper = {lr, mom, beta2, wd, t, factor})
+// optimisers on a flat arena (hyper = {lr, mom, beta2, wd, t, factor, -, arrivals})
 // ---------------------------------------------------------------------------
-__global__ void adam_tick_kernel(float* hyper) {
-  const float t = hyper[4] + 1.f;
-  hyper[4] = t;
-  hyper[5] = sqrtf(1.f - powf(hyper[2], t)) / (1.f - powf(hyper[1], t));
-}
-
-__device__ __forceinline__ float seg_mult(const int64_t* seg_off, const float* seg_reg,
-                                          int n_seg, size_t i) {
+// Every tensor of the arena starts on a 16-byte boundary and is padded to a multiple of
+// four elements (model.py ensure_arena), so a float4 never straddles two tensors: one
+// weight-decay multiplier per float4, found by a binary search over the segment table in
+// LDS.  Adam's step counter t lives on the device (hipGraph replay cannot pass a new
+// value): every work-group reads t_old, uses t = t_old + 1, and the LAST work-group to
+// finish -- an arrival counter, at most 256 arrivals -- publishes t for the next step.
+// No work-group can still need t_old then.  (A separate one-thread "tick" kernel took 5 us
+// per step; one arrival per work-group of a 4096-group grid serialised for 46 us.)
+constexpr int kOptMaxSeg = 1024;
+__device__ __forceinline__ float seg_mult_lds(const long* so, const float* sr, int n_seg, size_t i) {
   int lo = 0, hi = n_seg - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if ((size_t)seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+    if ((size_t)so[mid] <= i) lo = mid; else hi = mid - 1;
   }
-  return seg_reg[lo];
+  return sr[lo];
 }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                            float* __restrict__ m, float* __restrict__ s, size_t n,
-                            const int64_t* __restrict__ seg_off,
-                            const float* __restrict__ seg_reg, int n_seg,
-                            const float* __restrict__ hyper) {
-  const float lr = hyper[0], mom = hyper[1], b2 = hyper[2], wd = hyper[3], fac = hyper[5];
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ s, size_t n,
+                                                   const int64_t* __restrict__ seg_off,
+                                                   const float* __restrict__ seg_reg, int n_seg,
+                                                   float* __restrict__ hyper) {
+  __shared__ long so[kOptMaxSeg];
+  __shared__ float sr[kOptMaxSeg];
+  for (int i = threadIdx.x; i < n_seg; i += blockDim.x) { so[i] = seg_off[i]; sr[i] = seg_reg[i]; }
+  const float lr = hyper[0], mom = hyper[1], b2 = hyper[2], wd = hyper[3];
+  const float t = hyper[4] + 1.f;
+  const float fac = sqrtf(1.f - powf(b2, t)) / (1.f - powf(mom, t));
+  __syncthreads();
+  const size_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m);
+  float4* s4 = reinterpret_cast<float4*>(s);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float nm = mom * m[i] + (1.f - mom) * gi;
-    const float ns = b2 * s[i] + (1.f - b2) * gi * gi;
-    float dir = fac * nm / sqrtf(ns + E2_EPS_ADAM);
-    const float mult = seg_mult(seg_off, seg_reg, n_seg, i);
-    const float pi = p[i];
-    if (mult != 0.f) dir += wd * pi * mult;
-    m[i] = nm; s[i] = ns;
-    p[i] = pi - lr * dir;
+    const float4 gv = g4[i], mv = m4[i], sv = s4[i];
+    float4 pv = p4[i];
+    const float mult = seg_mult_lds(so, sr, n_seg, 4 * i) * wd;
+    float4 nm, ns;
+#define E2_ADAM1(c)                                                      \
+    nm.c = mom * mv.c + (1.f - mom) * gv.c;                              \
+    ns.c = b2 * sv.c + (1.f - b2) * gv.c * gv.c;                         \
+    {                                                                    \
+      float dir = fac * nm.c / sqrtf(ns.c + E2_EPS_ADAM);                \
+      if (mult != 0.f) dir += mult * pv.c;                               \
+      pv.c = pv.c - lr * dir;                                            \
+    }
+    E2_ADAM1(x) E2_ADAM1(y) E2_ADAM1(z) E2_ADAM1(w)
+#undef E2_ADAM1
+    m4[i] = nm; s4[i] = ns; p4[i] = pv;
+  }
+  if (blockIdx.x == 0)                                 // (n is a multiple of 4 in the plan's arena)
+    for (size_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float gi = g[i];
+      const float nm = mom * m[i] + (1.f - mom) * gi;
+      const float ns = b2 * s[i] + (1.f - b2) * gi * gi;
+      float dir = fac * nm / sqrtf(ns + E2_EPS_ADAM);
+      const float mult = seg_mult_lds(so, sr, n_seg, i) * wd;
+      const float pi = p[i];
+      if (mult != 0.f) dir += mult * pi;
+      m[i] = nm; s[i] = ns; p[i] = pi - lr * dir;
+    }
+  // publish t once every work-group has read the old value
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* arrivals = reinterpret_cast<unsigned*>(hyper + 7);
+    const unsigned prev = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      hyper[4] = t;
+      hyper[5] = fac;
+    }
   }
 }
 
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
-                           float* __restrict__ d, size_t n,
-                           const int64_t* __restrict__ seg_off,
-                           const float* __restrict__ seg_reg, int n_seg,
-                           const float* __restrict__ hyper) {
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ d, size_t n,
+                                                  const int64_t* __restrict__ seg_off,
+                                                  const float* __restrict__ seg_reg, int n_seg,
+                                                  const float* __restrict__ hyper) {
+  __shared__ long so[kOptMaxSeg];
+  __shared__ float sr[kOptMaxSeg];
+  for (int i = threadIdx.x; i < n_seg; i += blockDim.x) { so[i] = seg_off[i]; sr[i] = seg_reg[i]; }
   const float lr = hyper[0], mom = hyper[1], wd = hyper[3];
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+  __syncthreads();
+  const size_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* d4 = reinterpret_cast<float4*>(d);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
-    const float nd = g[i] + mom * d[i];
-    const float mult = seg_mult(seg_off, seg_reg, n_seg, i);
-    const float pi = p[i];
-    float step = nd;
-    if (mult != 0.f) step += wd * pi * mult;
-    d[i] = nd;
-    p[i] = pi - lr * step;
+    const float4 gv = g4[i], dv = d4[i];
+    float4 pv = p4[i];
+    const float mult = seg_mult_lds(so, sr, n_seg, 4 * i) * wd;
+    float4 nd;
+#define E2_SGD1(c)                                                       \
+    nd.c = gv.c + mom * dv.c;                                            \
+    pv.c = pv.c - lr * (mult != 0.f ? nd.c + mult * pv.c : nd.c);
+    E2_SGD1(x) E2_SGD1(y) E2_SGD1(z) E2_SGD1(w)
+#undef E2_SGD1
+    d4[i] = nd; p4[i] = pv;
   }
+  if (blockIdx.x == 0)
+    for (size_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+      const float nd = g[i] + mom * d[i];
+      const float mult = seg_mult_lds(so, sr, n_seg, i) * wd;
+      const float pi = p[i];
+      d[i] = nd;
+      p[i] = pi - lr * (mult != 0.f ? nd + mult * pi : nd);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -951,11 +1011,12 @@ extern "C" int e2_adam_step(e2_ctx* ctx, float* p, const float* g, float* m, flo
                             int n_seg, const float* hyper) {
   E2_REQUIRE(ctx && p && g && m && s && seg_off && seg_reg && hyper && n_seg > 0,
              "adam_step: null argument");
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, ctx->stream,
-                     const_cast<float*>(hyper));
-  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  E2_REQUIRE(n_seg <= kOptMaxSeg, "adam_step: %d parameter tensors (at most %d)", n_seg, kOptMaxSeg);
+  E2_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)s) & 15) == 0,
+             "adam_step: arenas must be 16-byte aligned");
+  const int grid = (int)std::min<size_t>(std::max<size_t>((n / 4 + 255) / 256, 1), ctx->num_cu);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, g, m, s, n,
-                     seg_off, seg_reg, n_seg, hyper);
+                     seg_off, seg_reg, n_seg, const_cast<float*>(hyper));
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -965,7 +1026,9 @@ extern "C" int e2_sgd_step(e2_ctx* ctx, float* p, const float* g, float* d, size
                            const float* hyper) {
   E2_REQUIRE(ctx && p && g && d && seg_off && seg_reg && hyper && n_seg > 0,
              "sgd_step: null argument");
-  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  E2_REQUIRE(n_seg <= kOptMaxSeg, "sgd_step: %d parameter tensors (at most %d)", n_seg, kOptMaxSeg);
+  E2_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)d) & 15) == 0, "sgd_step: arenas must be 16-byte aligned");
+  const int grid = (int)std::min<size_t>(std::max<size_t>((n / 4 + 255) / 256, 1), 2 * (size_t)ctx->num_cu);
   hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, g, d, n, seg_off,
                      seg_reg, n_seg, hyper);
   E2_CHECK_HIP(hipGetLastError());

@@ -248,10 +248,11 @@ class Plan(object):
         # measured (profiles/r01 notes in DESIGN.md): two MFMA-bound kernels sharing the
         # chip finish no sooner than back to back -- off unless E2_SIDE_STREAM=1
         self.use_side = os.environ.get("E2_SIDE_STREAM", "0") == "1"
-        # the repack of the weight images (index arithmetic, little memory traffic) is a
-        # parallel branch of the graph next to the first layer (VALU / HBM bound): the first
-        # kernel that reads a packed image joins it (Conv._plan_fwd -> join_side)
-        self.use_side_pack = os.environ.get("E2_SIDE_PACK", "1") == "1"
+        # the repack of the weight images as a parallel branch of the graph next to the first
+        # layer (the first kernel that reads a packed image joins it, Conv._plan_fwd): measured
+        # on one box, interleaved (tools/ab.sh), the fork / join costs more than the overlap
+        # saves -- lite183 1.715 vs 1.699 ms, full185 2.120 vs 2.095 ms -- so it stays off
+        self.use_side_pack = os.environ.get("E2_SIDE_PACK", "0") == "1"
         self.out, self.grad, self.scratch = {}, {}, {}
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)

@@ -281,9 +281,13 @@ int e2_malis_nll(e2_ctx*, const e2_tensor5* probs, const float* pos, const float
  *      parameter arena.  wd_mult[i] = weight-decay multiplier per element
  *      segment is given by seg tables: for segment s, elements
  *      [seg_off[s], seg_off[s+1]) use decay multiplier seg_reg[s]. --------- */
+/* hyper: 8 device floats {lr, mom, beta2, wd, t, factor, -, arrival counter}.  The
+ * kernel reads t, steps with t + 1 (bias factor sqrt(1-beta2^t)/(1-mom^t)) and stores
+ * the new t for the next call; hyper[7] must be zero before the first call; all four
+ * arenas 16-byte aligned, n_seg <= 1024. */
 int e2_adam_step(e2_ctx*, float* p, const float* g, float* m, float* s,
                  size_t n, const int64_t* seg_off, const float* seg_reg,
-                 int n_seg, const float* hyper /* device: lr,mom,beta2,wd,t */);
+                 int n_seg, const float* hyper /* device: lr,mom,beta2,wd,t,.. */);
 int e2_sgd_step(e2_ctx*, float* p, const float* g, float* d, size_t n,
                 const int64_t* seg_off, const float* seg_reg, int n_seg,
                 const float* hyper /* device: lr,mom,_,wd,_ */);

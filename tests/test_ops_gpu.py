@@ -405,15 +405,17 @@ def test_softmax_nll(ctx):
     assert abs(float(stats[1]) - (tg >= 0).sum()) < 0.5
 
 
-def test_adam_and_sgd(ctx):
+@pytest.mark.parametrize("n", [5000, 300003])
+def test_adam_and_sgd(ctx, n):
+    """(float4 body + scalar tail, several work-groups: the step counter t is published by
+    the last work-group to finish and must read 3 after three steps)"""
     rng = np.random.RandomState(16)
-    n = 5000
     p0 = rng.randn(n); g = rng.randn(n)
     seg = np.array([0, 1200, 3000, n], np.int64)
     reg = np.array([1.0, 0.0, 3.0], np.float32)
     lr, mom, b2, wd = 5e-4, 0.9, 0.999, 0.5e-4
     p = dev(p0); m = torch.zeros(n, device="cuda"); s = torch.zeros(n, device="cuda")
-    hyper = dev([lr, mom, b2, wd, 0, 0])
+    hyper = dev([lr, mom, b2, wd, 0, 0, 0, 0])
     so = torch.tensor(seg, device="cuda"); sr = dev(reg)
     pr, mr, sr_ = p0.astype(np.float32).astype(np.float64), np.zeros(n), np.zeros(n)
     for t in range(1, 4):
