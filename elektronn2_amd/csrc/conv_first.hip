@@ -211,6 +211,14 @@ __global__ __launch_bounds__(256) void first_bwd_reduce_kernel(const float* __re
 }
 
 // ---- host -------------------------------------------------------------------------
+// conv_first_mfma.hip: the same layer on the matrix cores (Cout <= 32)
+int e2i_firstm_mg(int cout);
+size_t e2i_firstm_ws_floats(long nTiles, int cout, int T);
+int e2i_firstm_fwd(e2_ctx*, int v, const e2_tensor5* x, const float* w, const float* bias, int cout,
+                   int py, int px, int act, const e2_tensor5* out);
+int e2i_firstm_bwd(e2_ctx*, int v, const e2_tensor5* x, const float* w, const float* bias,
+                   const e2_tensor5* dout, int py, int px, int act, float* part, int* nslots);
+
 static int first_supported(int kd, int kh, int kw, int pz, int py, int px) {
   if (kd != 1 || pz != 1) return 0;
   if (kh == 4 && kw == 4 && py == 2 && px == 2) return 1;
@@ -250,6 +258,8 @@ extern "C" int e2_conv1_pool_act_fwd(e2_ctx* ctx, const e2_tensor5* x, const flo
   First p{};
   if (int rc = first_fill(p, x, out, cout, kh, kw, py, px, "conv1_pool_act_fwd")) return rc;
   p.w = w; p.bias = bias; p.out = out->ptr; p.act = act;
+  if (e2i_firstm_mg(cout) && !e2_dbg_env("E2_FIRST_VALU"))
+    return e2i_firstm_fwd(ctx, v, x, w, bias, cout, py, px, act, out);
   const long nTiles = (long)p.N * p.D * p.tilesY * p.tilesX;
   const int grid = (int)std::min<long>(nTiles, ctx->num_cu * 8);
   if (v == 1)
@@ -265,7 +275,9 @@ extern "C" int e2_conv1_pool_act_fwd(e2_ctx* ctx, const e2_tensor5* x, const flo
 extern "C" size_t e2_conv1_bwd_workspace_bytes(int n, int cout, int d, int ho, int wo, int kh,
                                                int kw) {
   const long tiles = (long)n * d * e2_cdiv(ho, 8) * e2_cdiv(wo, 32);
-  return sizeof(float) * (size_t)tiles * cout * (kh * kw + 1);
+  const long tilesM = (long)n * d * e2_cdiv(ho, 4) * e2_cdiv(wo * 2, 64);     // (px <= 2)
+  const size_t valu = (size_t)tiles * cout * (kh * kw + 1);
+  return sizeof(float) * std::max(valu, e2i_firstm_ws_floats(tilesM, cout, kh * kw));
 }
 
 /* dw (cout*kh*kw) and dbias (cout) are ACCUMULATED into: zero them first.
@@ -286,6 +298,15 @@ extern "C" int e2_conv1_pool_act_bwd(e2_ctx* ctx, const e2_tensor5* x, const flo
   E2_REQUIRE(ws_bytes >= e2_conv1_bwd_workspace_bytes(p.N, p.Cout, p.D, p.Ho, p.Wo, kh, kw),
              "conv1_pool_act_bwd: workspace too small");
   float* part = (float*)ws;
+  if (e2i_firstm_mg(p.Cout) && !e2_dbg_env("E2_FIRST_VALU")) {
+    int nslots = 0;
+    if (int rc = e2i_firstm_bwd(ctx, v, x, w, bias, dout, py, px, act, part, &nslots)) return rc;
+    const int T = kh * kw, total = p.Cout * (T + 1);
+    hipLaunchKernelGGL(first_bwd_reduce_kernel, dim3(e2_cdiv(total, 256), std::min(nslots, 64)),
+                       dim3(256), 0, ctx->stream, part, nslots, p.Cout, T, dw, dbias);
+    E2_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (v == 1)
     hipLaunchKernelGGL((first_bwd_kernel<4, 4, 2, 2>), dim3((int)nTiles), dim3(256), 0, ctx->stream, p, part);
   else if (v == 2)
