@@ -51,7 +51,7 @@ CASES = [
     (200, 200, (1, 1, 1), (2, 9, 10), "7,2,8,2", "4,1,1,256,2"),   # GU = 1, split-K
     (20, 30, (1, 5, 5), (2, 17, 18), None, "2,2,14,256,3"),        # 16x16x32 form, waves split quads
     (30, 40, (1, 5, 5), (1, 47, 47), "3,4,16,1", None),
-    (24, 200, (3, 2, 3), (5, 13, 37), "4,4,24,1", "5,4,1,256,6"),
+    (24, 200, (3, 2, 3), (5, 13, 37), "4,4,24,1", "4,4,1,256,6"),
     (150, 200, (1, 3, 3), (2, 11, 12), None, "7,2,0,128,3"),        # LDS-staged wgrad kernel
     (40, 150, (2, 4, 4), (3, 12, 13), None, "5,4,0,64,4"),
     (6, 17, (1, 1, 3), (1, 1, 70), None, None),
