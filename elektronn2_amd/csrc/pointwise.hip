@@ -302,12 +302,15 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
 // backward of the FUSED conv+bias+act forward (no pooling): dy = dout * act'(out),
 // relu' read off the activated output: > 0 -> 1, +0.0 -> 0.5 (pre-activation was
 // exactly 0), -0.0 -> 0 (it was negative; see e2_conv3d_fwd_packed_act); dbias += sum
+// (four consecutive x per thread, 16-byte accesses -- the scalar form ran at 2.9 TB/s)
+typedef float pw_f4 __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out, int act,
                                                           View5 dy, float* __restrict__ dbias,
-                                                          FastDiv dw, FastDiv dh,
+                                                          FastDiv dvw, FastDiv dh,
                                                           unsigned chunk) {
   __shared__ float red[4];
-  const unsigned S = (unsigned)dout.d * dout.h * dout.w;
+  const unsigned VW = (unsigned)(dout.w + 3) >> 2;            // 4-element pieces per row
+  const unsigned S = (unsigned)dout.d * dout.h * VW;
   const unsigned s0 = blockIdx.x * chunk;
   const unsigned s1 = min(s0 + chunk, S);
   const int c = blockIdx.y, n = blockIdx.z;
@@ -316,17 +319,36 @@ __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out,
   float* dbase = dy.p + (long)n * dy.sn + (long)c * dy.sc;
   float gsum = 0.f;
   for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
-    const unsigned t = fdiv(s, dw);
-    const unsigned xo = s - t * dout.w;
+    const unsigned t = fdiv(s, dvw);
+    const unsigned xo = (s - t * VW) << 2;
     const unsigned zo = fdiv(t, dh);
     const unsigned yo = t - zo * dout.h;
-    float g = gbase[(long)zo * dout.sd + (long)yo * dout.sh + xo];
-    if (act == E2_ACT_RELU) {
-      const float o = obase[(long)zo * out.sd + (long)yo * out.sh + xo];
-      g *= (o > 0.f) ? 1.f : (__builtin_signbit(o) ? 0.f : 0.5f);
+    const float* gp = gbase + (long)zo * dout.sd + (long)yo * dout.sh + xo;
+    const float* op = obase + (long)zo * out.sd + (long)yo * out.sh + xo;
+    float* dp = dbase + (long)zo * dy.sd + (long)yo * dy.sh + xo;
+    const int nv = min(4, dout.w - (int)xo);
+    float g[4], o[4];
+    if (nv == 4) {
+      const pw_f4 gv = *reinterpret_cast<const pw_f4*>(gp);
+      const pw_f4 ov = *reinterpret_cast<const pw_f4*>(op);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[e] = gv[e]; o[e] = ov[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[e] = e < nv ? gp[e] : 0.f; o[e] = e < nv ? op[e] : 1.f; }
     }
-    gsum += g;
-    dbase[(long)zo * dy.sd + (long)yo * dy.sh + xo] = g;
+    if (act == E2_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= (o[e] > 0.f) ? 1.f : (__builtin_signbit(o[e]) ? 0.f : 0.5f);
+    }
+    gsum += (g[0] + g[1]) + (g[2] + g[3]);
+    if (nv == 4) {
+      pw_f4 v = {g[0], g[1], g[2], g[3]};
+      *reinterpret_cast<pw_f4*>(dp) = v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nv) dp[e] = g[e];
+    }
   }
   if (dbias != nullptr) {
     const float tot = block_sum256(gsum, red);
@@ -886,10 +908,11 @@ extern "C" int e2_bias_act_bwd_out(e2_ctx* ctx, const e2_tensor5* dout, const e2
                  dy->h == out->h && dy->w == out->w, "bias_act_bwd_out: shape mismatch");
   View5 vd = mk(dout), vo = mk(out), vdy = mk(dy);
   E2_REQUIRE((long)vd.d * vd.h * vd.w < (1L << 31), "bias_act_bwd_out: channel too large");
-  const FastDiv dw = mk_div(vd.w), dh = mk_div(vd.h);
-  const unsigned chunk = pw_chunk(vd);
-  hipLaunchKernelGGL(act_bwd_out_kernel, grid_chunked(vd, chunk), dim3(256), 0, ctx->stream, vd,
-                     vo, act, vdy, dbias, dw, dh, chunk);
+  View5 vq = vd; vq.w = (vd.w + 3) / 4;                 // the grid counts 4-element pieces
+  const FastDiv dvw = mk_div(vq.w), dh = mk_div(vd.h);
+  const unsigned chunk = pw_chunk(vq);
+  hipLaunchKernelGGL(act_bwd_out_kernel, grid_chunked(vq, chunk), dim3(256), 0, ctx->stream, vd,
+                     vo, act, vdy, dbias, dvw, dh, chunk);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
