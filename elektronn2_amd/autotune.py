@@ -174,6 +174,8 @@ def igemm4_candidates(cout, cin, k, out_sp, split_k=True, n_cu=256):
 def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
     """"MT,NT,WK,BP,PS": WK 1 = direct kernel (dy from global memory; BP 128/256),
     WK 14 = direct kernel whose four waves share one 16*NT n-tile and split the quads,
+    WK 101 / 114 = the same two with the XCD-grouped block order (the work-groups that read
+    the same gradient rows share one L2; needs nMT * PS % 8 == 0),
     WK 0 = LDS-staged kernel (BP 64/128), WK 4 = LDS-staged, waves split K (tiny N)."""
     mblocks = -(-cout // 16)
     T = k[0] * k[1] * k[2]
@@ -198,6 +200,12 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
                     # ... and the nearest split counts that divide the tiles evenly
                     for q in {ps} | set(_near_divisors(tiles, ps)):
                         cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, q))
+                    if wk in (1, 14) and nnt >= 4:
+                        # XCD-grouped order: position splits that make nMT * PS a multiple of 8
+                        step = 8 // math.gcd(8, nmt)
+                        for q in {max(step, ps // step * step), -(-ps // step) * step}:
+                            if q <= tiles:
+                                cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q))
     return sorted(set(cands))
 
 
@@ -262,6 +270,15 @@ def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None):
         if results:
             results.sort()
             best = results[0][1]
+            if kind == "wgrad":
+                # at (nearly) equal time prefer the XCD-grouped block order (WK >= 100): the
+                # gradient rows are then fetched once per L2 instead of once per XCD
+                for t, c in results:
+                    if t > 1.015 * results[0][0]:
+                        break
+                    if c and int(c.split(",")[2]) >= 100:
+                        best = c
+                        break
             cache[key] = best
             _dirty = True
     final = ft if tuned_now else fn

@@ -113,7 +113,7 @@ int e2i_upconv_dpre_s2d(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* yout,
                         int py, int px, int act, float* s2d, float* dbias);
 int e2i_wgrad_conv(e2_ctx*, const WgradArgs& a);
 // conv_wgrad_direct.hip: dy operand straight from global memory (needs dy_padded)
-int e2i_wgrad_direct(e2_ctx*, const WgradArgs& a, int MT, int NT, int BP, int PS, int WK);
+int e2i_wgrad_direct(e2_ctx*, const WgradArgs& a, int MT, int NT, int BP, int PS, int WK, int xcd = 0);
 int e2i_wgrad_direct_lpad(const WgradArgs& a, int BP);
 size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP, int WK);
 

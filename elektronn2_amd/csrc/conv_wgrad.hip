@@ -548,9 +548,10 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   // WK field: 1 = direct kernel when dy is padded (BP 128/256), else the LDS-staged
   // kernel; 14 = direct kernel, waves split the quads of a tile (NT 2/4);
   // 0 = LDS-staged kernel forced; 4 = LDS-staged kernel, waves split K
-  if (a.dy_padded && (c.WK == 1 || c.WK == 14) && (c.BP == 128 || c.BP == 256))
-    return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS, c.WK == 14 ? 4 : 1);
-  E2_REQUIRE(c.WK != 14, "wgrad: WK=14 needs the padded-gradient entry point and BP 128/256");
+  // WK 101 / 114: the direct kernel with the XCD-grouped block order (nMT * PS % 8 == 0)
+  if (a.dy_padded && (c.WK == 1 || c.WK == 14 || c.WK == 101 || c.WK == 114) && (c.BP == 128 || c.BP == 256))
+    return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS, (c.WK % 100) == 14 ? 4 : 1, c.WK >= 100);
+  E2_REQUIRE(c.WK != 14 && c.WK < 100, "wgrad: WK=14/101/114 need the padded-gradient entry point and BP 128/256");
   if (c.WK == 0) c.WK = 1;
   E2_REQUIRE(c.BP == 64 || c.BP == 128, "wgrad: BP must be 64 or 128");
   E2_REQUIRE(c.WK == 1 || (c.WK == 4 && c.NT == 1), "wgrad: WK=4 needs NT=1");

@@ -91,6 +91,7 @@ struct WdP {
   int bufFloats;
   int Din, N;
   int dbg;
+  int xcd;                // 1: work-groups that share gradient rows run on ONE XCD (see the kernel)
   FastDivD divDsY;
   unsigned long long* stamps;   // debug (E2_WGRAD_STAMPS): s_memtime stamps per work-group
 };
@@ -244,10 +245,27 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   const int wk = (WK == 4) ? (wave8 & 3) : 0;   // its share of the quads
   const int l15 = lane & 15, qd = lane >> 4;
 
-  int bid = blockIdx.x;
-  const int nt = bid % p.nNT; bid /= p.nNT;
-  const int mt = bid % p.nMT;
-  const int ps = bid / p.nMT;
+  // The nNT work-groups of one (row tile, position split) read the SAME dy rows.  Blocks
+  // are dealt round-robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md
+  // "Workgroup dispatch"), each with its own L2: with the plain order every XCD fetched
+  // every dy line (FETCH_SIZE 5-11x the operand bytes, profiles/r01_e_pmc_traffic.csv).
+  // xcd mode (host: nMT * nPS is a multiple of 8): group g's work-groups are the
+  // consecutive blocks of ONE residue class mod 8, so its dy lines are fetched once into
+  // that XCD's L2.  Placement only changes speed / traffic, never results.
+  int nt, mt, ps;
+  if (p.xcd) {
+    const int b = blockIdx.x;
+    const int j = b >> 3;
+    const int g = (j / p.nNT) * 8 + (b & 7);
+    nt = j % p.nNT;
+    mt = g % p.nMT;
+    ps = g / p.nMT;
+  } else {
+    int bid = blockIdx.x;
+    nt = bid % p.nNT; bid /= p.nNT;
+    mt = bid % p.nMT;
+    ps = bid / p.nMT;
+  }
 
   const int m0 = mt * BM;
   const int n0 = nt * BNn;
@@ -621,7 +639,7 @@ size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP, int WK) {
   return (size_t)(BP + 256) + (size_t)d_maxspans(a, 16 * NT * (4 / WK)) * e2i_wgrad_direct_lpad(a, BP) + 64;
 }
 
-int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, int PS, int WK) {
+int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, int PS, int WK, int xcd) {
   E2_REQUIRE(BP == 128 || BP == 256, "wgrad(direct): BP must be 128 or 256");
   E2_REQUIRE(WK == 1 || (WK == 4 && (NT == 2 || NT == 4)), "wgrad(direct): WK=4 needs NT 2 or 4");
   E2_REQUIRE(a.xsY < (1 << 20) && a.dsY < (1 << 20), "wgrad: row stride too large");
@@ -652,6 +670,9 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   p.N = a.N;
   p.divDsY = mk_divd((unsigned)a.dsY);
   p.dbg = e2_dbg_env_int("E2_WGRAD_DBG");
+  p.xcd = xcd ? 1 : 0;
+  E2_REQUIRE(!p.xcd || ((p.nMT * p.nPS) % 8 == 0 && p.nPS == std::min(PS, p.tilesTotal)),
+             "wgrad(direct): the XCD-grouped order needs nMT * PS to be a multiple of 8 (nMT = %d, PS = %d)", p.nMT, p.nPS);
   const size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "wgrad(direct): tiling needs %zu B of LDS", lds);
   const long grid = (long)p.nMT * p.nNT * p.nPS;
