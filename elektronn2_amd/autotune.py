@@ -200,12 +200,9 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
                     # ... and the nearest split counts that divide the tiles evenly
                     for q in {ps} | set(_near_divisors(tiles, ps)):
                         cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, q))
-                    if wk in (1, 14) and nnt >= 4:
-                        # XCD-grouped order: position splits that make nMT * PS a multiple of 8
-                        step = 8 // math.gcd(8, nmt)
-                        for q in {max(step, ps // step * step), -(-ps // step) * step}:
-                            if q <= tiles:
-                                cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q))
+                        if wk in (1, 14) and nnt >= 2 and nmt * q * nnt > 8:
+                            # the same launch in the XCD-grouped block order
+                            cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q))
     return sorted(set(cands))
 
 

@@ -249,9 +249,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   // are dealt round-robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md
   // "Workgroup dispatch"), each with its own L2: with the plain order every XCD fetched
   // every dy line (FETCH_SIZE 5-11x the operand bytes, profiles/r01_e_pmc_traffic.csv).
-  // xcd mode (host: nMT * nPS is a multiple of 8): group g's work-groups are the
-  // consecutive blocks of ONE residue class mod 8, so its dy lines are fetched once into
-  // that XCD's L2.  Placement only changes speed / traffic, never results.
+  // xcd mode: group g's work-groups are the consecutive blocks of ONE residue class mod 8,
+  // so its dy lines are fetched once into that XCD's L2 (the host rounds the number of
+  // groups up to a multiple of 8; the blocks of the padding groups leave at once).
+  // Placement only changes speed / traffic, never results.
   int nt, mt, ps;
   if (p.xcd) {
     const int b = blockIdx.x;
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
     nt = j % p.nNT;
     mt = g % p.nMT;
     ps = g / p.nMT;
+    if (ps >= p.nPS) return;
   } else {
     int bid = blockIdx.x;
     nt = bid % p.nNT; bid /= p.nNT;
@@ -671,11 +673,10 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   p.divDsY = mk_divd((unsigned)a.dsY);
   p.dbg = e2_dbg_env_int("E2_WGRAD_DBG");
   p.xcd = xcd ? 1 : 0;
-  E2_REQUIRE(!p.xcd || ((p.nMT * p.nPS) % 8 == 0 && p.nPS == std::min(PS, p.tilesTotal)),
-             "wgrad(direct): the XCD-grouped order needs nMT * PS to be a multiple of 8 (nMT = %d, PS = %d)", p.nMT, p.nPS);
   const size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "wgrad(direct): tiling needs %zu B of LDS", lds);
-  const long grid = (long)p.nMT * p.nNT * p.nPS;
+  const long groups = (long)p.nMT * p.nPS;
+  const long grid = (p.xcd ? (groups + 7) / 8 * 8 : groups) * p.nNT;
   p.stamps = nullptr;
   static unsigned long long* stamp_buf = nullptr;
   const bool want_stamps = e2_dbg_env("E2_WGRAD_STAMPS") != nullptr && !ctx->capturing && grid <= 65536;

@@ -212,6 +212,7 @@ def test_conv3d_1x1_forced_tilings(ctx, force):
 @pytest.mark.parametrize("force", ["1,1,1,128,3", "2,2,1,256,5", "3,4,1,128,2", "4,1,1,256,7",
                                    "5,2,1,128,1", "7,2,1,128,3", "7,2,1,256,2", "7,1,1,128,40",
                                    "7,2,101,128,8", "2,2,101,256,2", "3,2,114,128,8", "1,1,101,128,8",
+                                   "7,2,101,128,3", "2,2,101,256,5", "3,2,114,128,7",
                                    "3,4,14,256,3", "2,2,14,128,5", "7,2,14,256,1", "1,4,14,128,40"])
 @pytest.mark.parametrize("k", [(2, 3, 3), (1, 1, 1), (1, 4, 1)])
 def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
