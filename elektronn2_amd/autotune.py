@@ -227,12 +227,14 @@ def _time(ctx, fn, iters=4):
     return ctx.elapsed_ms(e0, e1) / iters
 
 
-def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None):
+def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None, fn_once=None):
     """Run ``fn`` with the best known tiling for (kind, sig); tune on first sight.
     kind: 'igemm' | 'wgrad'.  ``fn_tune`` (default ``fn``) is the IDEMPOTENT form of
     the launch used for the timing runs (e.g. wgrad that overwrites instead of
     accumulating); when tuning ran, the result is produced by one final
-    ``fn_tune`` call instead of ``fn``.  Returns the tiling string used."""
+    ``fn_tune`` call instead of ``fn`` -- or by ``fn_once`` when given (a launch whose side
+    effect must happen exactly once and that leaves the timed outputs as ``fn_tune`` does).
+    Returns the tiling string used."""
     global _dirty
     ft = fn_tune if fn_tune is not None else fn
     if kind in _forced:
@@ -278,7 +280,7 @@ def tuned_call(ctx, kind, sig, cands, fn, allow_tune=True, fn_tune=None):
                         break
             cache[key] = best
             _dirty = True
-    final = ft if tuned_now else fn
+    final = (fn_once if fn_once is not None else ft) if tuned_now else fn
     if best:
         ctx.set_tiling(kind, best)
         try:

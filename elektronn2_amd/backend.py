@@ -58,6 +58,7 @@ def _load():
         "e2_conv3d_dgrad_packed": (C.c_int, [vp, P5, vp, i, i, i, i, P5]),
         "e2_conv3d_fwd_packed_act": (C.c_int, [vp, P5, vp, i, i, i, i, fp, i, P5]),
         "e2_bias_act_bwd_out": (C.c_int, [vp, P5, P5, i, P5, fp]),
+        "e2_conv3d_dgrad_packed_actbwd": (C.c_int, [vp, P5, vp, i, i, i, i, P5, i, fp, P5, i, i, i, fp]),
         "e2_conv3d_wgrad": (C.c_int, [vp, P5, P5, fp, i, i, i]),
         "e2_conv3d_wgrad_acc": (C.c_int, [vp, P5, P5, fp, i, i, i]),
         "e2_conv3d_wgrad_pad": (C.c_int, [vp, P5, P5, fp, i, i, i, i]),
@@ -237,6 +238,18 @@ class Context:
         _chk(_lib.e2_conv3d_fwd_packed_act(self.h, C.byref(t5(x)), C.c_void_p(wp.data_ptr()),
                                            cout, k[0], k[1], k[2], _fp(bias), ACT[act],
                                            C.byref(t5(out))), "e2_conv3d_fwd_packed_act")
+
+    def conv3d_dgrad_packed_actbwd(self, dy_pad, wp, cin, k, out_prev, act_prev, dy_pad_prev,
+                                   pad_prev, dbias_prev, bias_prev=None):
+        """data gradient + activation backward of the producing layer, written into the
+        interior of that layer's zero-padded gradient buffer (e2hip.h)"""
+        _chk(_lib.e2_conv3d_dgrad_packed_actbwd(
+            self.h, C.byref(t5(dy_pad)), C.c_void_p(wp.data_ptr()), int(cin), int(k[0]),
+            int(k[1]), int(k[2]), C.byref(t5(out_prev)), ACT[act_prev],
+            _fp(bias_prev) if bias_prev is not None else None, C.byref(t5(dy_pad_prev)),
+            int(pad_prev[0]), int(pad_prev[1]), int(pad_prev[2]),
+            _fp(dbias_prev) if dbias_prev is not None else None),
+            "e2_conv3d_dgrad_packed_actbwd")
 
     def bias_act_bwd_out(self, dout, out, act, dy, dbias):
         _chk(_lib.e2_bias_act_bwd_out(self.h, C.byref(t5(dout)), C.byref(t5(out)), ACT[act],

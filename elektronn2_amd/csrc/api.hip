@@ -235,6 +235,58 @@ extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, con
   return e2i_igemm_conv(ctx, a);
 }
 
+extern "C" int e2_conv3d_dgrad_packed_actbwd(e2_ctx* ctx, const e2_tensor5* dy_pad,
+                                             const void* wp, int cin, int kd, int kh, int kw,
+                                             const e2_tensor5* out_prev, int act_prev,
+                                             const float* bias_prev,
+                                             const e2_tensor5* dy_pad_prev, int pd, int ph,
+                                             int pw, float* dbias_prev) {
+  E2_REQUIRE(ctx && wp, "conv3d_dgrad_actbwd: null argument");
+  E2_REQUIRE(act_prev == E2_ACT_LIN || act_prev == E2_ACT_RELU, "conv3d_dgrad_actbwd: bad act %d", act_prev);
+  if (int rc = view_ok(dy_pad, "conv3d_dgrad_actbwd dy_pad")) return rc;
+  if (int rc = view_ok(out_prev, "conv3d_dgrad_actbwd out_prev")) return rc;
+  if (int rc = view_ok(dy_pad_prev, "conv3d_dgrad_actbwd dy_pad_prev")) return rc;
+  E2_REQUIRE(pd >= 0 && ph >= 0 && pw >= 0, "conv3d_dgrad_actbwd: negative padding");
+  const e2_tensor5* o = out_prev; const e2_tensor5* q = dy_pad_prev;
+  E2_REQUIRE(o->n == dy_pad->n && o->c == cin && o->d == dy_pad->d - kd + 1 &&
+                 o->h == dy_pad->h - kh + 1 && o->w == dy_pad->w - kw + 1,
+             "conv3d_dgrad_actbwd: out_prev is (%d,%d,%d,%d,%d) but padded dy (%d,%d,%d,%d,%d) "
+             "with kernel %d,%d,%d gives (%d,%d,%d,%d,%d)", o->n, o->c, o->d, o->h, o->w,
+             dy_pad->n, dy_pad->c, dy_pad->d, dy_pad->h, dy_pad->w, kd, kh, kw, dy_pad->n, cin,
+             dy_pad->d - kd + 1, dy_pad->h - kh + 1, dy_pad->w - kw + 1);
+  E2_REQUIRE(q->n == o->n && q->c == o->c && q->d == o->d + 2 * pd && q->h == o->h + 2 * ph &&
+                 q->w == o->w + 2 * pw,
+             "conv3d_dgrad_actbwd: dy_pad_prev is (%d,%d,%d,%d,%d), expected (%d,%d,%d,%d,%d)",
+             q->n, q->c, q->d, q->h, q->w, o->n, o->c, o->d + 2 * pd, o->h + 2 * ph, o->w + 2 * pw);
+  e2_tensor5 dx = *q;                           // the interior view
+  dx.ptr = q->ptr + (int64_t)pd * q->sd + (int64_t)ph * q->sh + pw;
+  dx.d = o->d; dx.h = o->h; dx.w = o->w;
+  IgemmArgs a;
+  a.in = dy_pad->ptr; a.wp = (const float*)wp; a.out = dx.ptr;
+  a.N = dx.n; a.Cin = dy_pad->c; a.Cout = cin;
+  a.kd = kd; a.kh = kh; a.kw = kw;
+  a.Do = dx.d; a.Ho = dx.h; a.Wo = dx.w;
+  a.isN = dy_pad->sn; a.isC = dy_pad->sc; a.isZ = dy_pad->sd; a.isY = dy_pad->sh;
+  a.osN = dx.sn; a.osC = dx.sc; a.osZ = dx.sd; a.osY = dx.sh;
+  e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
+  a.upz = a.upy = a.upx = 1;
+  int done = 0;
+  if (o->sh == o->w) {                          // the epilogue reads dense mask rows
+    a.gm = 1; a.gm_src = (act_prev == E2_ACT_RELU) ? o->ptr : nullptr;
+    a.gsN = o->sn; a.gsC = o->sc; a.gsZ = o->sd;
+    a.gm_dbias = dbias_prev; a.gm_bias = bias_prev; a.gm_done = &done;
+  }
+  if (q->sh == q->w && q->sd == (int64_t)q->h * q->w && q->sc == (int64_t)q->d * q->sd &&
+      (q->n == 1 || q->sn == (int64_t)q->c * q->sc)) {
+    a.fill_base = q->ptr; a.fill_n = (size_t)q->n * q->c * q->d * q->h * q->w;
+  }
+  if (int rc = e2i_igemm_conv(ctx, a)) return rc;
+  if (done) return 0;
+  if (bias_prev)      // pre-activation form: a (1,1,1) "pool" backward, in place
+    return e2_pool_bias_act_bwd(ctx, &dx, out_prev, bias_prev, 1, 1, 1, act_prev, &dx, dbias_prev);
+  return e2_bias_act_bwd_out(ctx, &dx, out_prev, act_prev, &dx, dbias_prev);
+}
+
 extern "C" int e2_conv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w, int cout,
                              int kd, int kh, int kw, const e2_tensor5* y, void* ws,
                              size_t ws_bytes) {

@@ -82,6 +82,21 @@ struct IgemmArgs {
   // zero, so that the backward can tell relu'(0) = 0.5 from 0 without the pre-activation
   const float* bias = nullptr;
   int act = 0;
+  // gradient-mask epilogue (data gradient fused with the activation backward of the layer
+  // that produced this conv's input): out = conv * act'(gm_src), gm_dbias += column sums.
+  // gm_src: that layer's activated output with dense rows (nullptr = linear activation).
+  // e2i_igemm_conv reports in *gm_done whether the chosen kernel did it (else the caller
+  // runs the activation backward in place on the output).
+  int gm = 0;
+  const float* gm_src = nullptr;
+  int64_t gsN = 0, gsC = 0, gsZ = 0;
+  float* gm_dbias = nullptr;
+  const float* gm_bias = nullptr;   // non-null: gm_src is the PRE-activation, slope from gm_src + gm_bias[c]
+  int* gm_done = nullptr;
+  // split-K zero-fill of an output that is the interior of a zero-padded scratch buffer:
+  // the whole buffer may be filled flat (batched by the caller), nullptr = fill the view
+  float* fill_base = nullptr;
+  size_t fill_n = 0;
 };
 int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
 

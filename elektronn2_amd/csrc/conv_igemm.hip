@@ -348,6 +348,11 @@ int e2i_igemm4_pairs(int kw, int MG, int NT) {
 // zero-fill of a split-K output (atomics accumulate onto it); notes the region for callers
 // that batch the fills of a whole step (e2_conv_last_zero_fill / e2_set_skip_zero_fill)
 static int igemm_zero_output(e2_ctx* ctx, const IgemmArgs& a) {
+  if (a.fill_base) {
+    ctx->last_fill_ptr = a.fill_base; ctx->last_fill_n = a.fill_n;
+    if (!ctx->skip_zero_fill) return e2i_fill_flat(ctx, a.fill_base, a.fill_n, 0.f);
+    return 0;
+  }
   const int R = a.upz * a.upy * a.upx;
   const int oc = a.Cout / (R > 1 ? R : 1);
   const int od = a.Do * a.upz, oh = a.Ho * a.upy, ow = a.Wo * a.upx;
@@ -431,8 +436,11 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   IgemmCfg c = choose_cfg(ctx, a, &ok);
   E2_REQUIRE(ok, "igemm: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d W=%d)", a.Cin,
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
+  if (a.gm_done) *a.gm_done = 0;
   if (c.kind == 4) return igemm4_conv(ctx, a, c);
   const bool fast = has_fast_kw(a.kw);
+  // the gradient-mask epilogue lives in the specialised-width 16x16x4 kernel
+  const bool gm = a.gm && fast && a.upz * a.upy * a.upx == 1 && a.Wo >= 4;
   E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC <= (fast ? 64 : 32),
              "igemm: CC must be a multiple of 4, at most %d", fast ? 64 : 32);
   E2_REQUIRE(c.NT == 1 || c.NT == 2 || c.NT == 4, "igemm: NT must be 1, 2 or 4");
@@ -464,11 +472,16 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "igemm: forced tiling needs %zu B of LDS", lds);
   // wide epilogue (fast path): dense output rows, plain stores
-  const size_t tile_lds = (size_t)4 * 16 * c.MT * (16 * c.NT + 4) * 4;
-  p.wide = (fast && p.splitK == 1 && a.upz * a.upy * a.upx == 1 && a.osY == a.Wo &&
+  const size_t tile_lds = (size_t)4 * 16 * c.MT * (16 * c.NT + 4) * 4 + (gm ? 4 * 16 * c.MT * 4 : 0);
+  p.wide = (fast && p.splitK == 1 && a.upz * a.upy * a.upx == 1 && (a.osY == a.Wo || a.Wo >= 4) &&
             std::max(lds, tile_lds) <= 160 * 1024 && !e2_dbg_env("E2_IGEMM_NARROW")) ? 1 : 0;
   if (p.wide) lds = std::max(lds, tile_lds);
   p.bias = a.bias; p.act = a.act;
+  if (gm) {
+    p.gm = 1; p.gm_src = a.gm_src; p.gsN = a.gsN; p.gsC = a.gsC; p.gsZ = a.gsZ;
+    p.gm_dbias = a.gm_dbias; p.gm_bias = a.gm_bias;
+    if (a.gm_done) *a.gm_done = 1;
+  }
   E2_REQUIRE(!a.bias || p.wide, "igemm: the fused bias/act epilogue needs dense output rows, a "
              "specialised kernel width and %zu B of LDS", tile_lds);
   const long grid = (long)a.N * p.splitK * p.nMT * p.Do * p.nPT;

@@ -31,8 +31,26 @@ struct IgemmP {
   int act;
   int bf16;               // 1: operands rounded to bf16 for the matrix core (f32 sums)
   int wide;               // 1: epilogue transposes the tile through LDS and stores 16 B per lane
-                          //    (dense output rows, no split-K, no UpConv scatter)
+                          //    (no split-K, no UpConv scatter; rows of the output may be wider
+                          //    than Wo -- the interior of a zero-padded buffer)
+  // gradient-mask epilogue (data gradient fused with the activation backward of the layer
+  // that PRODUCED this conv's input): out = acc * act'(gm_src), gm_dbias[co] += sum(out).
+  // gm_src = that layer's activated output (dense rows, relu slopes read off its sign:
+  // > 0 -> 1, +0.0 -> 0.5, -0.0 -> 0), nullptr for a linear activation.
+  // gm_bias != nullptr: gm_src is that layer's PRE-activation y and the slope is taken from
+  // y + gm_bias[co] (> 0 -> 1, == 0 -> 0.5, < 0 -> 0).
+  int gm = 0;
+  const float* gm_src = nullptr;
+  long gsN = 0, gsC = 0, gsZ = 0;
+  float* gm_dbias = nullptr;
+  const float* gm_bias = nullptr;
 };
+
+// relu slope of the producing layer: o = its activated output (pre = false: the sign of a
+// zero tells 0.5 from 0) or its pre-activation plus bias (pre = true)
+__device__ __forceinline__ float e2_relu_slope(float o, bool pre) {
+  return (o > 0.f) ? 1.f : (pre ? (o == 0.f ? 0.5f : 0.f) : (__builtin_signbit(o) ? 0.f : 0.5f));
+}
 
 // async global -> LDS copies (no VGPR destination); LDS address is
 // wave-uniform base + lane*size, the global source is per lane.
@@ -466,13 +484,22 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
     // same wave reads back what it wrote: LDS operations of a wave complete in order
     const int rl_ = lane / LPR, c4 = lane - rl_ * LPR;
     const int qw = q0 + wave * (16 * NT) + 4 * c4;
-    float* ob = p.out + (long)n * p.osN + (long)z * p.osZ + qw;   // dense rows: offset = q
+    // rows of the output may be wider than Wo (interior of a zero-padded gradient
+    // buffer): a piece of 4 positions can then straddle a row end (Wo >= 4: at most one)
+    const bool dense = (p.osY == p.Wo);
+    int ro = 0, cq = qw;
+    if (!dense) { ro = qw / p.Wo; cq = qw - ro * p.Wo; }
+    const long ooff = dense ? (long)qw : (long)ro * p.osY + cq;
+    const bool whole = (qw + 3 < p.Q) && (dense || cq + 3 < p.Wo);
+    float* ob = p.out + (long)n * p.osN + (long)z * p.osZ;
+    const float* gb = (p.gm && p.gm_src) ? p.gm_src + (long)n * p.gsN + (long)z * p.gsZ + qw : nullptr;
+    float* bsum = smem + 4 * (16 * MT * STR);      // [4 waves][16*MT rows], behind the tiles
 #pragma unroll
     for (int it = 0; it < (16 * MT) / RPI; ++it) {
       const int row = it * RPI + rl_;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * STR + 4 * c4);
       const int co = m0 + row;
-      if (co < p.Cout) {
+      if (co < p.Cout) {                       // (the LPR lanes of a row decide alike)
         if (p.bias) {
           const float bv = p.bias[co];
 #pragma unroll
@@ -482,14 +509,51 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
             v[e] = t;
           }
         }
+        if (p.gm) {
+          if (gb) {
+            const float* gp = gb + (long)co * p.gsC;
+            const bool pre = p.gm_bias != nullptr;
+            const float gbv = pre ? p.gm_bias[co] : 0.f;
+            if (qw + 3 < p.Q) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(gp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= e2_relu_slope(pre ? o[e] + gbv : o[e], pre);   // (-0.0 + 0.0 would lose the sign)
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (qw + e < p.Q) v[e] *= e2_relu_slope(pre ? gp[e] + gbv : gp[e], pre);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (qw + e >= p.Q) v[e] = 0.f;
+          float sb = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+          for (int off = 1; off < LPR; off <<= 1) sb += __shfl_xor(sb, off);
+          if (c4 == 0) bsum[wave * (16 * MT) + row] = sb;
+        }
         float* dst = ob + (long)co * p.osC;
-        if (qw + 3 < p.Q) {
-          *reinterpret_cast<f32x4*>(dst) = v;            // 16 B, possibly unaligned
+        if (whole) {
+          *reinterpret_cast<f32x4*>(dst + ooff) = v;     // 16 B, possibly unaligned
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (qw + e < p.Q) dst[e] = v[e];
+            if (qw + e < p.Q) {
+              if (dense) dst[qw + e] = v[e];
+              else {
+                int cc = cq + e, r2 = ro;
+                if (cc >= p.Wo) { cc -= p.Wo; ++r2; }
+                dst[(long)r2 * p.osY + cc] = v[e];
+              }
+            }
         }
+      }
+    }
+    if (p.gm && p.gm_dbias) {
+      __syncthreads();                         // (the producer waves have left)
+      if (tid < 16 * MT && m0 + tid < p.Cout) {
+        const float sb = (bsum[tid] + bsum[16 * MT + tid]) + (bsum[2 * 16 * MT + tid] + bsum[3 * 16 * MT + tid]);
+        if (sb != 0.f) unsafeAtomicAdd(p.gm_dbias + m0 + tid, sb);
       }
     }
     if (st) {
@@ -501,11 +565,17 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   }
   // ---- epilogue: D col = position (lane&15), row = channel 4*qd+reg -------
   const int R = p.upz * p.upy * p.upx;
+  float bs[MT][4];                             // gm: column sums of this lane's elements
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) bs[mb][rr] = 0.f;
 #pragma unroll
   for (int nb = 0; nb < NT; ++nb) {
     const int q = q0 + wave * (16 * NT) + nb * 16 + l15;
     if (q >= p.Q) continue;
     const int r = q / p.Wo, c = q - r * p.Wo;
+    const float* gq = (p.gm && p.gm_src) ? p.gm_src + (long)n * p.gsN + (long)z * p.gsZ + q : nullptr;
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) {
 #pragma unroll
@@ -525,11 +595,31 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
                 (long)(z * p.upz + rz) * p.osZ + (long)(r * p.upy + ry) * p.osY +
                 (c * p.upx + rx);
         }
-        const float v = acc[mb][nb][rr];
+        float v = acc[mb][nb][rr];
+        if (p.gm) {                            // (linear in acc: split-K partial sums too)
+          if (gq) {
+            const bool pre = p.gm_bias != nullptr;
+            const float o = gq[(long)co * p.gsC];
+            v *= e2_relu_slope(pre ? o + p.gm_bias[co] : o, pre);
+          }
+          bs[mb][rr] += v;
+        }
         if (p.atomic) unsafeAtomicAdd(dst, v);
         else *dst = v;
       }
     }
+  }
+  if (p.gm && p.gm_dbias) {
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float sb = bs[mb][rr];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) sb += __shfl_xor(sb, off);
+        const int co = m0 + mb * 16 + 4 * qd + rr;
+        if (l15 == 0 && co < p.Cout && sb != 0.f) unsafeAtomicAdd(p.gm_dbias + co, sb);
+      }
   }
   if (st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -403,7 +403,9 @@ class Conv(NeuralLayer):
                                    plan.pgrad(self.b), ws=plan.scratch[self, 'ws1'])
             return
         dy = plan.scratch[self, 'dy']
-        if self._fused_act(plan):
+        if plan.scratch.get((self, 'dy_done')):
+            pass        # the consumer's data-gradient launch wrote dy and dbias (below)
+        elif self._fused_act(plan):
             ctx.bias_act_bwd_out(plan.grad[self], plan.out[self], self.activation_func, dy,
                                  plan.pgrad(self.b))
         else:
@@ -423,6 +425,32 @@ class Conv(NeuralLayer):
         if plan.needs_grad(self.parent):
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']
+            par = self.parent
+            if self._actbwd_into_parent(plan):
+                # the parent conv does not pool and feeds only this conv: its activation
+                # backward runs in this launch's epilogue, which writes the parent's
+                # zero-padded gradient buffer and bias gradient directly
+                pdyp = plan.scratch[par, 'dy_pad']
+                ppad = [kk - 1 for kk in par.filter_shape]
+                if par._fused_act(plan):
+                    src, pb = plan.out[par], None
+                else:
+                    src, pb = plan.scratch[par, 'y'], plan.param(par.b)
+                osp = plan.out_shape(par)[2:]
+                sig = (1, cin, self.n_f) + tuple(self.filter_shape) + tuple(osp) + \
+                    (dyp.stride(3),)
+                plan._grad_written.add(id(par))
+                plan.scratch[par, 'dy_done'] = True
+
+                def launch(dbias):
+                    ctx.conv3d_dgrad_packed_actbwd(dyp, wp, cin, self.filter_shape, src,
+                                                   par.activation_func, pdyp, ppad, dbias,
+                                                   bias_prev=pb)
+                plan.tuned('igemm', sig,
+                           autotune.igemm_candidates(cin, self.n_f, self.filter_shape, osp),
+                           lambda: launch(plan.pgrad(par.b)), fn_tune=lambda: launch(None),
+                           fn_once=lambda: launch(plan.pgrad(par.b)), out=pdyp)
+                return
             dst, first = plan.grad_slot(self.parent)
             out = dst if first else plan.tmp_like(dst)
             sig = (1, cin, self.n_f) + tuple(self.filter_shape) + tuple(out.shape[2:]) + \
@@ -434,6 +462,23 @@ class Conv(NeuralLayer):
                        out=out)
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
+
+    def _actbwd_into_parent(self, plan):
+        """this conv's data gradient can carry the activation backward of its parent: the
+        parent is a plain Conv without pooling (relu / lin) whose output gradient comes
+        from this node alone"""
+        par = self.parent
+        if not (plan.fuse_actbwd and type(par) is Conv and type(self) is Conv
+                and all(p == 1 for p in par.pool_shape)
+                and par.activation_func in ('relu', 'lin')
+                and (par, 'dy_pad') in plan.scratch
+                and not par._fused_first(plan) and par._fused_head(plan) is None
+                and self.filter_shape[2] in (1, 3, 4, 5)
+                and plan.out_shape(par)[4] >= 4):
+            return False
+        users = [c for c in par.children.values()
+                 if id(c) in plan._loss_anc or c is plan.loss_node]
+        return len(users) == 1 and users[0] is self
 
 
 class FragmentsToDense(Node):

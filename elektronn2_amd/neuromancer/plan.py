@@ -133,7 +133,7 @@ class Plan(object):
     def pgrad(self, p):
         return self.model.device_grad(p)
 
-    def tuned(self, kind, sig, cands, fn, fn_tune=None, out=None):
+    def tuned(self, kind, sig, cands, fn, fn_tune=None, out=None, fn_once=None):
         """launch a conv kernel with its autotuned tiling (tunes on first sight,
         never while a hipGraph capture is in progress).
 
@@ -148,7 +148,7 @@ class Plan(object):
             self.ctx.set_skip_zero_fill(True)
         try:
             autotune.tuned_call(self.ctx, kind, sig, cands, fn, allow_tune=not self._capturing,
-                                fn_tune=fn_tune)
+                                fn_tune=fn_tune, fn_once=fn_once)
         finally:
             if skip:
                 self.ctx.set_skip_zero_fill(False)
@@ -253,6 +253,11 @@ class Plan(object):
         # on one box, interleaved (tools/ab.sh), the fork / join costs more than the overlap
         # saves -- lite183 1.715 vs 1.699 ms, full185 2.120 vs 2.095 ms -- so it stays off
         self.use_side_pack = os.environ.get("E2_SIDE_PACK", "0") == "1"
+        # activation backward of an un-pooled conv inside its consumer's data-gradient launch
+        # (e2_conv3d_dgrad_packed_actbwd).  Measured (tools/ab.sh, DESIGN.md finding 17): the
+        # mask loads in the GEMM epilogue cost what the removed 10 us kernel cost, and the
+        # bias-gradient atomics of split-K grids cost more (neuro3d@185 +0.7 ms) -- off
+        self.fuse_actbwd = int(os.environ.get("E2_FUSE_ACTBWD", "0"))
         self.out, self.grad, self.scratch = {}, {}, {}
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)

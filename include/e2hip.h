@@ -125,6 +125,24 @@ int e2_conv3d_fwd_packed_act(e2_ctx*, const e2_tensor5* x, const void* wp, int c
  * buffer), dbias[oc] += sum(dy) when dbias != NULL. */
 int e2_bias_act_bwd_out(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* out, int act,
                         const e2_tensor5* dy, float* dbias);
+/* e2_conv3d_dgrad_packed FUSED with e2_bias_act_bwd_out of the layer that produced this
+ * conv's input (a conv layer without pooling whose only consumer is this conv; T.grad's
+ * chain ConvGradI -> relu', model.py:182):
+ *   dy_prev = dgrad(dy_pad, w) * act_prev'(out_prev),  dbias_prev[c] += sum(dy_prev[c])
+ * written straight into the INTERIOR of that layer's zero-padded gradient buffer
+ * dy_pad_prev (n, cin, d + 2 pd, h + 2 ph, w + 2 pw), interior at (pd, ph, pw); its border
+ * must be (and stays) zero.  out_prev (n, cin, d, h, w) = that layer's activated output
+ * as e2_conv3d_fwd_packed_act stored it (bias_prev == NULL), or -- for a layer whose forward
+ * ran as e2_conv3d_fwd_packed + e2_pool_bias_act_fwd with a (1,1,1) window -- its
+ * PRE-activation conv output, the slope then being act'(out_prev + bias_prev[c]).  The mask is applied in the GEMM's epilogue (also
+ * under split-K: it is linear in the partial sums; a contiguous dy_pad_prev is then
+ * zero-filled whole); tilings without that epilogue run the two steps one after the other,
+ * in place.  dbias_prev may be NULL. */
+int e2_conv3d_dgrad_packed_actbwd(e2_ctx*, const e2_tensor5* dy_pad, const void* wp, int cin,
+                                  int kd, int kh, int kw, const e2_tensor5* out_prev,
+                                  int act_prev, const float* bias_prev,
+                                  const e2_tensor5* dy_pad_prev, int pd, int ph, int pw,
+                                  float* dbias_prev);
 
 /* dw[cout][cin][kd][kh][kw] = d(loss)/dw (replaces GpuDnnConv3dGradW).
  * dy is the UNPADDED view (n, cout, do, ho, wo) (it may be the interior view

@@ -74,6 +74,35 @@ def test_loss_grads_and_adam_steps(name, spec, sp):
     assert m.iterations == 3
 
 
+@pytest.mark.parametrize("name,spec,sp", CASES, ids=['lite', 'full'])
+def test_activation_backward_fused_into_the_consumers_dgrad(name, spec, sp, monkeypatch):
+    """plan.fuse_actbwd (off by default, DESIGN.md finding 17): the relu backward + bias
+    gradient of an un-pooled conv produced by the next conv's data-gradient launch
+    (e2_conv3d_dgrad_packed_actbwd) -- same gradients as the separate kernels, also under
+    graph replay (training steps)."""
+    params = O.init_net(spec, 1, seed=1)
+    rng = np.random.RandomState(3)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    res = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("E2_FUSE_ACTBWD", fuse)
+        m = build(name, sp, params)
+        g = m.gradients(x, t)
+        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(3)]
+        res[fuse] = (g, losses, [p.get_value() for p in m.loss_node.all_trainable_params.values()])
+        plan = m.optimisers['Adam'].step.func
+        assert bool(plan.fuse_actbwd) == (fuse == "1")
+        fused = [k for k in plan.scratch if isinstance(k, tuple) and len(k) == 2 and k[1] == 'dy_done']
+        assert (len(fused) > 0) == (fuse == "1")
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert rel(a, b) < 1e-5
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert abs(a - b) < 1e-5 * abs(b)
+    for a, b in zip(res["0"][2], res["1"][2]):
+        assert rel(a, b) < 1e-4
+
+
 def test_sgd_step_and_lr_change_under_graph():
     spec, sp = O.NEURO3D_LITE, (7, 47, 47)
     params = O.init_net(spec, 1, seed=2)

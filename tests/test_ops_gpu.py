@@ -192,6 +192,82 @@ def test_conv3d_4x4_mfma_tap_widths_dgrad_and_fused_act(ctx, kw, force):
         ctx.set_tiling("igemm", None)
 
 
+@pytest.mark.parametrize("force", [None, "2,2,8,1", "7,2,12,1", "3,4,8,1", "2,2,8,3", "5,1,4,2",
+                                   "4,5,1,16,1,2,2,1"])
+@pytest.mark.parametrize("k", [(1, 3, 3), (2, 4, 4), (1, 1, 1), (1, 2, 2)])
+@pytest.mark.parametrize("mode", ["relu_out", "relu_pre", "lin"])
+def test_conv3d_dgrad_fused_with_the_producers_activation_backward(ctx, force, k, mode):
+    """e2_conv3d_dgrad_packed_actbwd: dgrad * act'(producer) straight into the interior of the
+    producer's zero-padded gradient buffer + its bias gradient.  Wide epilogue (rows wider
+    than Wo, pieces straddling row ends), split-K (atomics, whole-buffer zero fill), tilings
+    without the epilogue (4x4x1 form, generic tap width: two launches, in place); slopes from
+    the activated output (+0.0 -> 0.5, -0.0 -> 0) and from pre-activation + bias."""
+    if force is not None and k[2] == 2:
+        pytest.skip("generic tap width: the library's own tiling only")
+    rng = np.random.RandomState(31)
+    N, Cp, Co = 2, 23, 40                       # producer: Cp channels; this conv: Cp -> Co
+    xsp = (4, 13, 22)
+    w = (rng.randn(Co, Cp, *k) / 6).astype(np.float32)
+    osp = tuple(xsp[i] - k[i] + 1 for i in range(3))
+    dy = rng.randn(N, Co, *osp).astype(np.float32)
+    pre = rng.randn(N, Cp, *xsp).astype(np.float32)          # producer pre-activation + bias
+    bias = (rng.randn(Cp) / 4).astype(np.float32)
+    pre[:, 0] = 0.0                                            # exactly zero: slope 0.5
+    pre[:, 1] = -1.0
+    dx_ref = O.conv3d_dgrad(dy, w, (N, Cp) + xsp)
+    if mode == "lin":
+        slope = np.ones_like(pre, dtype=np.float64)
+    else:
+        slope = np.where(pre > 0, 1.0, np.where(pre == 0, 0.5, 0.0))
+    ref = dx_ref * slope
+    db_ref = ref.sum(axis=(0, 2, 3, 4))
+    # this conv's zero-padded gradient buffer
+    pshape = (N, Co) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+    flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
+    dyp = flat[:int(np.prod(pshape))].view(pshape)
+    dyp[:, :, k[0] - 1:k[0] - 1 + osp[0], k[1] - 1:k[1] - 1 + osp[1],
+        k[2] - 1:k[2] - 1 + osp[2]] = dev(dy)
+    ws = torch.empty(ctx.conv_ws_bytes(Co, Cp, k) // 4 + 64, device="cuda")
+    ctx.conv3d_pack(dev(w), 1, ws)
+    # the producer's padded gradient buffer (its own kernel was (2,3,4): pads 1,2,3)
+    pad = (1, 2, 3)
+    qshape = (N, Cp) + tuple(xsp[i] + 2 * pad[i] for i in range(3))
+    dq = torch.zeros(qshape, device="cuda")
+    inner = dq[:, :, pad[0]:pad[0] + xsp[0], pad[1]:pad[1] + xsp[1], pad[2]:pad[2] + xsp[2]]
+    inner.fill_(float("nan"))
+    if mode == "relu_out":
+        o = np.maximum(pre, 0)
+        o[pre < 0] = -0.0
+        src, act, bprev = dev(o.astype(np.float32)), "relu", None
+    elif mode == "relu_pre":
+        src, act, bprev = dev((pre - bias.reshape(1, -1, 1, 1, 1)).astype(np.float32)), "relu", dev(bias)
+        # (pre - b) + b must reproduce the constructed zeros / signs exactly
+        chk = (src.cpu().numpy() + bias.reshape(1, -1, 1, 1, 1)).astype(np.float32)
+        slope = np.where(chk > 0, 1.0, np.where(chk == 0, 0.5, 0.0))
+        ref = dx_ref * slope
+        db_ref = ref.sum(axis=(0, 2, 3, 4))
+    else:
+        src, act, bprev = dev(pre), "lin", None
+    db = torch.zeros(Cp, device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        ctx.conv3d_dgrad_packed_actbwd(dyp, ws, Cp, k, src, act, dq, pad, db, bias_prev=bprev)
+        assert relerr(inner, ref) < TOL
+        assert relerr(db, db_ref) < 1e-4
+        border = dq.clone()
+        border[:, :, pad[0]:pad[0] + xsp[0], pad[1]:pad[1] + xsp[1], pad[2]:pad[2] + xsp[2]] = 0
+        assert not border.any()                   # the padding stays zero
+        if mode == "relu_out":
+            assert relerr(inner[:, 0], 0.5 * dx_ref[:, 0]) < TOL and not inner[:, 1].any()
+        # second call accumulates the bias gradient and rewrites the same interior
+        ctx.conv3d_dgrad_packed_actbwd(dyp, ws, Cp, k, src, act, dq, pad, db, bias_prev=bprev)
+        assert relerr(inner, ref) < TOL and relerr(db, 2 * db_ref) < 1e-4
+        ctx.conv3d_dgrad_packed_actbwd(dyp, ws, Cp, k, src, act, dq, pad, None, bias_prev=bprev)
+        assert relerr(inner, ref) < TOL and relerr(db, 2 * db_ref) < 1e-4
+    finally:
+        ctx.set_tiling("igemm", None)
+
+
 @pytest.mark.parametrize("force", ["7,2,32,1", "13,1,16,2", "2,4,48,1", "5,2,64,1", "1,1,8,1"])
 def test_conv3d_1x1_forced_tilings(ctx, force):
     """1x1x1 taps (plain GEMM): GU = 4 channel groups per step when CC % 16 == 0,
