@@ -185,62 +185,117 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(View5 dout, View5 y,
 }
 
 // Fixed-window forms of the two kernels above for the pool shapes of the BASELINE nets
-// ((1,2,2), (2,1,1), (2,2,2)): the window lives in registers (read once), the loops are
-// compile-time, and with V2 (x-window of 2, 8-byte aligned rows) a thread moves its two
-// neighbours with one 8-byte access.
-template <int PX, bool V2>
-__device__ __forceinline__ void pw_load_row(const float* row, float (&w)[PX]) {
-  if constexpr (V2) {
-    const float2 v = *reinterpret_cast<const float2*>(row);
-    w[0] = v.x; w[1] = v.y;
+// ((1,2,2), (2,1,1), (2,2,2), and (1,1,1) = bias + activation of a layer that does not
+// pool): a thread owns FOUR consecutive input x (16-byte row accesses, any alignment) =
+// 4 / PX pooled outputs; the window lives in registers (read once), the loops are
+// compile-time.  (The one-output-per-thread forms with 4- and 8-byte accesses ran at
+// 2.2-3.1 TB/s.)
+typedef float pw_f4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float pw_f2 __attribute__((ext_vector_type(2), aligned(4)));
+// nv valid elements of a row piece (the others read as `pad`)
+__device__ __forceinline__ void pw_load4(const float* row, int nv, float pad, float (&w)[4]) {
+  if (nv == 4) {
+    const pw_f4 v = *reinterpret_cast<const pw_f4*>(row);
+    w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3];
   } else {
 #pragma unroll
-    for (int e = 0; e < PX; ++e) w[e] = row[e];
+    for (int e = 0; e < 4; ++e) w[e] = e < nv ? row[e] : pad;
   }
 }
-template <int PZ, int PY, int PX, bool V2, bool HAS_BIAS>
+__device__ __forceinline__ void pw_store4(float* row, int nv, const float (&v)[4]) {
+  if (nv == 4) {
+    const pw_f4 o = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<pw_f4*>(row) = o;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (e < nv) row[e] = v[e];
+  }
+}
+template <int NO>
+__device__ __forceinline__ void pw_loadN(const float* p, int nv, float (&g)[NO]) {
+  if (nv == NO) {
+    if constexpr (NO == 4) {
+      const pw_f4 v = *reinterpret_cast<const pw_f4*>(p);
+      g[0] = v[0]; g[1] = v[1]; g[2] = v[2]; g[3] = v[3];
+    } else {
+      const pw_f2 v = *reinterpret_cast<const pw_f2*>(p);
+      g[0] = v[0]; g[1] = v[1];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NO; ++e) g[e] = e < nv ? p[e] : 0.f;
+  }
+}
+template <int NO>
+__device__ __forceinline__ void pw_storeN(float* p, int nv, const float (&g)[NO]) {
+  if (nv == NO) {
+    if constexpr (NO == 4) {
+      const pw_f4 o = {g[0], g[1], g[2], g[3]};
+      *reinterpret_cast<pw_f4*>(p) = o;
+    } else {
+      const pw_f2 o = {g[0], g[1]};
+      *reinterpret_cast<pw_f2*>(p) = o;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < NO; ++e) if (e < nv) p[e] = g[e];
+  }
+}
+template <int PZ, int PY, int PX, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const float* __restrict__ bias,
-                                                             int act, View5 out, FastDiv dw,
+                                                             int act, View5 out, FastDiv dvw,
                                                              FastDiv dh, unsigned chunk) {
-  const unsigned S = (unsigned)out.d * out.h * out.w;
+  static_assert(PX == 1 || PX == 2, "x windows of 1 or 2");
+  constexpr int NO = 4 / PX;                                  // pooled outputs per thread
+  const unsigned VW = ((unsigned)out.w + NO - 1) / NO;        // pieces per output row
+  const unsigned S = (unsigned)out.d * out.h * VW;
   const unsigned s0 = blockIdx.x * chunk;
   const unsigned s1 = min(s0 + chunk, S);
   const int c = blockIdx.y, n = blockIdx.z;
   const float bv = HAS_BIAS ? bias[c] : 0.f;
   const float* __restrict__ ybase = y.p + (long)n * y.sn + (long)c * y.sc;
   float* __restrict__ obase = out.p + (long)n * out.sn + (long)c * out.sc;
-  // (restrict + unroll: the loads of four iterations are in flight together)
-#pragma unroll 4
+#pragma unroll 2
   for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
-    const unsigned t = fdiv(s, dw);
-    const unsigned xo = s - t * out.w;
+    const unsigned t = fdiv(s, dvw);
+    const unsigned xo = (s - t * VW) * NO;
     const unsigned zo = fdiv(t, dh);
     const unsigned yo = t - zo * out.h;
+    const int nvo = min(NO, out.w - (int)xo);
     const float* src = ybase + (long)(zo * PZ) * y.sd + (long)(yo * PY) * y.sh + xo * PX;
-    float m = -INFINITY;
+    float m[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) m[j] = -INFINITY;
 #pragma unroll
     for (int a = 0; a < PZ; ++a)
 #pragma unroll
       for (int b = 0; b < PY; ++b) {
-        float w[PX];
-        pw_load_row<PX, V2>(src + a * y.sd + b * y.sh, w);
+        float w[4];
+        pw_load4(src + a * y.sd + b * y.sh, nvo * PX, 0.f, w);
 #pragma unroll
-        for (int e = 0; e < PX; ++e) m = fmaxf(m, w[e]);
+        for (int e = 0; e < 4; ++e) m[e / PX] = fmaxf(m[e / PX], w[e]);
       }
-    float v = m + bv;
-    if (act == E2_ACT_RELU) v = fmaxf(v, 0.f);
-    obase[(long)zo * out.sd + (long)yo * out.sh + xo] = v;
+    float v[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      v[j] = m[j] + bv;
+      if (act == E2_ACT_RELU) v[j] = fmaxf(v[j], 0.f);
+    }
+    pw_storeN<NO>(obase + (long)zo * out.sd + (long)yo * out.sh + xo, nvo, v);
   }
 }
-template <int PZ, int PY, int PX, bool V2, bool HAS_BIAS>
+template <int PZ, int PY, int PX, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y,
                                                              const float* __restrict__ bias,
                                                              int act, View5 dy,
                                                              float* __restrict__ dbias,
-                                                             int accumulate, FastDiv dw,
+                                                             int accumulate, FastDiv dvw,
                                                              FastDiv dh, unsigned chunk) {
+  static_assert(PX == 1 || PX == 2, "x windows of 1 or 2");
+  constexpr int NO = 4 / PX;
   __shared__ float red[4];
-  const unsigned S = (unsigned)dout.d * dout.h * dout.w;
+  const unsigned VW = ((unsigned)dout.w + NO - 1) / NO;
+  const unsigned S = (unsigned)dout.d * dout.h * VW;
   const unsigned s0 = blockIdx.x * chunk;
   const unsigned s1 = min(s0 + chunk, S);
   const int c = blockIdx.y, n = blockIdx.z;
@@ -249,48 +304,53 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
   const float* __restrict__ gbase = dout.p + (long)n * dout.sn + (long)c * dout.sc;
   float* __restrict__ dbase = dy.p + (long)n * dy.sn + (long)c * dy.sc;
   float gsum = 0.f;
-  // (restrict + unroll: the loads of four iterations are in flight together)
-#pragma unroll 4
+#pragma unroll 2
   for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
-    const unsigned t = fdiv(s, dw);
-    const unsigned xo = s - t * dout.w;
+    const unsigned t = fdiv(s, dvw);
+    const unsigned xo = (s - t * VW) * NO;
     const unsigned zo = fdiv(t, dh);
     const unsigned yo = t - zo * dout.h;
+    const int nvo = min(NO, dout.w - (int)xo);
+    const int nvi = nvo * PX;
     const float* src = ybase + (long)(zo * PZ) * y.sd + (long)(yo * PY) * y.sh + xo * PX;
-    float w[PZ][PY][PX];
-    float m = -INFINITY;
+    float w[PZ][PY][4];
+    float m[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) m[j] = -INFINITY;
 #pragma unroll
     for (int a = 0; a < PZ; ++a)
 #pragma unroll
       for (int b = 0; b < PY; ++b) {
-        pw_load_row<PX, V2>(src + a * y.sd + b * y.sh, w[a][b]);
+        pw_load4(src + a * y.sd + b * y.sh, nvi, 0.f, w[a][b]);
 #pragma unroll
-        for (int e = 0; e < PX; ++e) m = fmaxf(m, w[a][b][e]);
+        for (int e = 0; e < 4; ++e) m[e / PX] = fmaxf(m[e / PX], w[a][b][e]);
       }
-    float g = gbase[(long)zo * dout.sd + (long)yo * dout.sh + xo];
-    if (act == E2_ACT_RELU) {
-      const float pre = m + bv;
-      g *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
+    float g[NO];
+    pw_loadN<NO>(gbase + (long)zo * dout.sd + (long)yo * dout.sh + xo, nvo, g);
+#pragma unroll
+    for (int j = 0; j < NO; ++j) {
+      if (act == E2_ACT_RELU) {
+        const float pre = m[j] + bv;
+        g[j] *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f);
+      }
+      if (j < nvo) gsum += g[j];
     }
-    gsum += g;
     float* dst = dbase + (long)(zo * PZ) * dy.sd + (long)(yo * PY) * dy.sh + xo * PX;
 #pragma unroll
     for (int a = 0; a < PZ; ++a)
 #pragma unroll
       for (int b = 0; b < PY; ++b) {
         float* drow = dst + a * dy.sd + b * dy.sh;
-        float v[PX];
+        float v[4];
 #pragma unroll
-        for (int e = 0; e < PX; ++e) v[e] = (w[a][b][e] == m) ? g : 0.f;
-        if constexpr (V2) {
-          float2* d2 = reinterpret_cast<float2*>(drow);
-          float2 o = make_float2(v[0], v[1]);
-          if (accumulate) { const float2 old = *d2; o.x += old.x; o.y += old.y; }
-          *d2 = o;
-        } else {
+        for (int e = 0; e < 4; ++e) v[e] = (w[a][b][e] == m[e / PX]) ? g[e / PX] : 0.f;
+        if (accumulate) {
+          float old[4];
+          pw_load4(drow, nvi, 0.f, old);
 #pragma unroll
-          for (int e = 0; e < PX; ++e) drow[e] = accumulate ? (drow[e] + v[e]) : v[e];
+          for (int e = 0; e < 4; ++e) v[e] += old[e];
         }
+        pw_store4(drow, nvi, v);
       }
   }
   if (dbias != nullptr) {
@@ -303,7 +363,6 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
 // relu' read off the activated output: > 0 -> 1, +0.0 -> 0.5 (pre-activation was
 // exactly 0), -0.0 -> 0 (it was negative; see e2_conv3d_fwd_packed_act); dbias += sum
 // (four consecutive x per thread, 16-byte accesses -- the scalar form ran at 2.9 TB/s)
-typedef float pw_f4 __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out, int act,
                                                           View5 dy, float* __restrict__ dbias,
                                                           FastDiv dvw, FastDiv dh,
@@ -705,39 +764,34 @@ static dim3 grid_chunked(const View5& v, unsigned chunk) {
   return dim3((unsigned)((S + chunk - 1) / chunk), (unsigned)v.c, (unsigned)v.n);
 }
 
-// 8-byte alignment of every row of a view (x-window of 2 read / written as float2)
-static bool rows_aligned8(const View5& v) {
-  return ((uintptr_t)v.p % 8 == 0) && (v.sn % 2 == 0) && (v.sc % 2 == 0) && (v.sd % 2 == 0) &&
-         (v.sh % 2 == 0);
-}
+// the grid of the fixed-window kernels counts pieces of 4 input x (4 / PX outputs)
 template <int PZ, int PY, int PX>
 static void launch_pool_fwd_fixed(e2_ctx* ctx, const View5& vy, const float* bias, int act,
-                                  const View5& vo, FastDiv dw, FastDiv dh, unsigned chunk) {
-  const dim3 g = grid_chunked(vo, chunk);
-  const bool v2 = (PX == 2) && rows_aligned8(vy);
-#define E2_L(V2, HB)                                                                          \
-  hipLaunchKernelGGL((pool_fwd_fixed_kernel<PZ, PY, PX, V2, HB>), g, dim3(256), 0, ctx->stream, \
-                     vy, bias, act, vo, dw, dh, chunk)
-  if constexpr (PX == 2) {
-    if (v2) { if (bias) E2_L(true, true); else E2_L(true, false); return; }
-  }
-  if (bias) E2_L(false, true); else E2_L(false, false);
-#undef E2_L
+                                  const View5& vo) {
+  View5 vq = vo; vq.w = (vo.w + 4 / PX - 1) / (4 / PX);
+  const unsigned chunk = pw_chunk(vq);
+  const dim3 g = grid_chunked(vq, chunk);
+  const FastDiv dvw = mk_div(vq.w), dh = mk_div(vo.h);
+  if (bias)
+    hipLaunchKernelGGL((pool_fwd_fixed_kernel<PZ, PY, PX, true>), g, dim3(256), 0, ctx->stream,
+                       vy, bias, act, vo, dvw, dh, chunk);
+  else
+    hipLaunchKernelGGL((pool_fwd_fixed_kernel<PZ, PY, PX, false>), g, dim3(256), 0, ctx->stream,
+                       vy, bias, act, vo, dvw, dh, chunk);
 }
 template <int PZ, int PY, int PX>
 static void launch_pool_bwd_fixed(e2_ctx* ctx, const View5& vd, const View5& vy, const float* bias,
-                                  int act, const View5& vdy, float* dbias, int accumulate,
-                                  FastDiv dw, FastDiv dh, unsigned chunk) {
-  const dim3 g = grid_chunked(vd, chunk);
-  const bool v2 = (PX == 2) && rows_aligned8(vy) && rows_aligned8(vdy);
-#define E2_L(V2, HB)                                                                          \
-  hipLaunchKernelGGL((pool_bwd_fixed_kernel<PZ, PY, PX, V2, HB>), g, dim3(256), 0, ctx->stream, \
-                     vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk)
-  if constexpr (PX == 2) {
-    if (v2) { if (bias) E2_L(true, true); else E2_L(true, false); return; }
-  }
-  if (bias) E2_L(false, true); else E2_L(false, false);
-#undef E2_L
+                                  int act, const View5& vdy, float* dbias, int accumulate) {
+  View5 vq = vd; vq.w = (vd.w + 4 / PX - 1) / (4 / PX);
+  const unsigned chunk = pw_chunk(vq);
+  const dim3 g = grid_chunked(vq, chunk);
+  const FastDiv dvw = mk_div(vq.w), dh = mk_div(vd.h);
+  if (bias)
+    hipLaunchKernelGGL((pool_bwd_fixed_kernel<PZ, PY, PX, true>), g, dim3(256), 0, ctx->stream,
+                       vd, vy, bias, act, vdy, dbias, accumulate, dvw, dh, chunk);
+  else
+    hipLaunchKernelGGL((pool_bwd_fixed_kernel<PZ, PY, PX, false>), g, dim3(256), 0, ctx->stream,
+                       vd, vy, bias, act, vdy, dbias, accumulate, dvw, dh, chunk);
 }
 
 int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
@@ -839,9 +893,10 @@ extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const floa
   const FastDiv dw = mk_div(vo.w), dh = mk_div(vo.h);
   const unsigned chunk = pw_chunk(vo);
   const int pcode = pz * 100 + py * 10 + px;
-  if (pcode == 122) launch_pool_fwd_fixed<1, 2, 2>(ctx, vy, bias, act, vo, dw, dh, chunk);
-  else if (pcode == 211) launch_pool_fwd_fixed<2, 1, 1>(ctx, vy, bias, act, vo, dw, dh, chunk);
-  else if (pcode == 222) launch_pool_fwd_fixed<2, 2, 2>(ctx, vy, bias, act, vo, dw, dh, chunk);
+  if (pcode == 122) launch_pool_fwd_fixed<1, 2, 2>(ctx, vy, bias, act, vo);
+  else if (pcode == 211) launch_pool_fwd_fixed<2, 1, 1>(ctx, vy, bias, act, vo);
+  else if (pcode == 222) launch_pool_fwd_fixed<2, 2, 2>(ctx, vy, bias, act, vo);
+  else if (pcode == 111) launch_pool_fwd_fixed<1, 1, 1>(ctx, vy, bias, act, vo);
   else if (bias)
     hipLaunchKernelGGL((pool_fwd_kernel<true>), grid_chunked(vo, chunk), dim3(256), 0,
                        ctx->stream, vy, bias, pz, py, px, act, vo, dw, dh, chunk);
@@ -871,11 +926,13 @@ static int pool_bwd_common(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5
   const unsigned chunk = pw_chunk(vd);
   const int pcode = pz * 100 + py * 10 + px;
   if (pcode == 122)
-    launch_pool_bwd_fixed<1, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk);
+    launch_pool_bwd_fixed<1, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
   else if (pcode == 211)
-    launch_pool_bwd_fixed<2, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk);
+    launch_pool_bwd_fixed<2, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
   else if (pcode == 222)
-    launch_pool_bwd_fixed<2, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, dw, dh, chunk);
+    launch_pool_bwd_fixed<2, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
+  else if (pcode == 111)
+    launch_pool_bwd_fixed<1, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
   else if (bias)
     hipLaunchKernelGGL((pool_bwd_kernel<true>), grid_chunked(vd, chunk), dim3(256), 0,
                        ctx->stream, vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate, dw,
