@@ -103,6 +103,11 @@ def _load():
         "e2_conv_last_zero_fill": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
         "e2_set_tiling": (C.c_int, [vp, C.c_int, C.c_char_p]),
+        "e2_dense_fwd": (C.c_int, [vp, fp, fp, fp, i, i, i]),
+        "e2_dense_dgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
+        "e2_dense_wgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
+        "e2_batchnorm_act_fwd": (C.c_int, [vp, P5, fp, fp, fp, fp, i, i, i, P5, fp]),
+        "e2_batchnorm_act_bwd": (C.c_int, [vp, P5, P5, fp, fp, fp, i, i, P5, fp, fp]),
         "e2_get_mfma_dtype": (C.c_int, [vp]),
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
@@ -443,6 +448,35 @@ class Context:
         p, n = C.c_void_p(), C.c_size_t()
         _chk(_lib.e2_conv_last_zero_fill(self.h, C.byref(p), C.byref(n)), "e2_conv_last_zero_fill")
         return (p.value or 0), int(n.value)
+
+    # ---- config 1 (mnist): Perceptron dot product, batch normalisation ------------------
+    def dense_fwd(self, x, w, y):
+        """y (n, m) = x (n, k) . w (k, m); contiguous 2-D views of device tensors"""
+        n, k = x.shape
+        _chk(_lib.e2_dense_fwd(self.h, _fp(x), _fp(w), _fp(y), n, k, w.shape[1]), "e2_dense_fwd")
+
+    def dense_dgrad(self, dy, w, dx, accumulate=False):
+        n, m = dy.shape
+        _chk(_lib.e2_dense_dgrad(self.h, _fp(dy), _fp(w), _fp(dx), n, w.shape[0], m,
+                                 int(accumulate)), "e2_dense_dgrad")
+
+    def dense_wgrad(self, x, dy, dw, accumulate=False):
+        n, k = x.shape
+        _chk(_lib.e2_dense_wgrad(self.h, _fp(x), _fp(dy), _fp(dw), n, k, dy.shape[1],
+                                 int(accumulate)), "e2_dense_wgrad")
+
+    def batchnorm_act_fwd(self, x, gamma, bias, run_mean, run_std, train, update_running, act,
+                          out, save=None):
+        _chk(_lib.e2_batchnorm_act_fwd(self.h, C.byref(t5(x)), _fp(gamma), _fp(bias),
+                                       _fp(run_mean), _fp(run_std), int(bool(train)),
+                                       int(bool(update_running)), ACT[act], C.byref(t5(out)),
+                                       _fp(save)), "e2_batchnorm_act_fwd")
+
+    def batchnorm_act_bwd(self, dout, x, gamma, bias, save, train, act, dx, dgamma, dbias):
+        _chk(_lib.e2_batchnorm_act_bwd(self.h, C.byref(t5(dout)), C.byref(t5(x)), _fp(gamma),
+                                       _fp(bias), _fp(save), int(bool(train)), ACT[act],
+                                       C.byref(t5(dx)) if dx is not None else None,
+                                       _fp(dgamma), _fp(dbias)), "e2_batchnorm_act_bwd")
 
     def set_tiling(self, kind, cfg):
         """force the tiling of the following 'igemm' ("MT,NT,CC,SK": conv fwd / dgrad /

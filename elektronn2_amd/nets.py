@@ -121,6 +121,29 @@ def unet3d(in_sh=(None, 1, 116, 132, 132), name=None):
     return model
 
 
+def mnist(in_sh=(None, 1, 26, 26), name=None):
+    """examples/mnist.py:29-56 (BASELINE config 1, the reference's CPU-runnable case): three
+    2-D convs with train-mode batch normalisation, two Perceptrons, 10-class softmax."""
+    from . import neuromancer as nm
+    if name is not None:
+        nm.model_manager.newmodel(name)
+    inp = nm.Input(in_sh, 'b,f,y,x', name='raw')
+    out = nm.Conv(inp, 12, (3, 3), (2, 2), batch_normalisation='train')
+    out = nm.Conv(out, 36, (3, 3), (2, 2), batch_normalisation='train')
+    out = nm.Conv(out, 64, (3, 3), (1, 1), batch_normalisation='train')
+    out = nm.Perceptron(out, 200, flatten=True)
+    out = nm.Perceptron(out, 10, activation_func='lin')
+    out = nm.Softmax(out)
+    target = nm.Input_like(out, override_f=1, name='target')
+    loss = nm.MultinoulliNLL(out, target, name='nll_', target_is_sparse=True)
+    loss = nm.AggregateLoss(loss)
+    errors = nm.Errors(out, target, target_is_sparse=True)
+    model = nm.model_manager.current if name is not None else nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, target_node=target, loss_node=loss,
+                          prediction_node=out, prediction_ext=[loss, errors, out])
+    return model
+
+
 def _pget(params):
     def P(i):
         if params is None:

@@ -4,7 +4,7 @@ from .graphutils import TaggedShape, make_func, floatX, as_floatX
 from .variables import VariableParam, VariableWeight, ConstantParam, initweights
 from .node_basic import (Node, Input, Input_like, Concat, Add, model_manager,
                          choose_name)
-from .neural import Conv, UpConv, Pool, Crop, AutoMerge, UpConvMerge, FragmentsToDense
+from .neural import Conv, UpConv, Pool, Crop, AutoMerge, UpConvMerge, FragmentsToDense, Perceptron
 from .loss import (Softmax, MultinoulliNLL, MalisNLL, AggregateLoss, Classification,
                    Errors)
 from .optimiser import Optimiser, SGD, Adam

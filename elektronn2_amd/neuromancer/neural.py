@@ -8,9 +8,15 @@ bookkeeping (elektronn2/neuromancer/neural.py), executing through libe2hip.so.
   AutoMerge neural.py:1282-1407 (= UpConvMerge)
   Pool      neural.py:1409-1559
 
+  Perceptron neural.py:258-410  dot product (+ batch norm) -> +bias -> act  (config 1)
+
+2-D convolutions ('b,f,y,x', BASELINE config 1 = examples/mnist.py) run through the same
+kernels with a unit z axis; batch normalisation ('train' / 'predict', neural.py:681-711)
+has its own kernel (csrc/dense_bn.hip).
+
 Outside the hot path and therefore rejected with NotImplementedError here:
-batch normalisation, dropout, MFP, gradnet, activations other than
-'relu' / 'lin', conv modes other than 'valid', 1-D/2-D convolutions.
+dropout, gradnet, batch_normalisation='fadeout', activations other than 'relu' / 'lin',
+conv modes other than 'valid', 1-D convolutions.
 """
 from __future__ import annotations
 
@@ -26,7 +32,7 @@ from .variables import VariableWeight, ConstantParam, VariableParam
 logger = logging.getLogger('elektronn2log')
 
 __all__ = ['Conv', 'UpConv', 'Pool', 'Crop', 'AutoMerge', 'UpConvMerge', 'NeuralLayer',
-           'FragmentsToDense']
+           'FragmentsToDense', 'Perceptron']
 
 _HIP_ACTS = ('relu', 'lin')
 
@@ -108,11 +114,30 @@ class NeuralLayer(Node):
             b_init = dict(scale=1e-6, mode='fix-uni')
         self._register_param(b, b_sh, 'b', init_kwargs=b_init, apply_train=True,
                              apply_reg=False)
-        if self.batch_normalisation:
-            raise NotImplementedError(
-                "batch_normalisation=%r: batch-norm is outside the 3-D HIP hot path "
-                "(SURVEY.md §8: mnist/CPU plumbing only)" % (self.batch_normalisation,))
+        # batch normalisation (neural.py:206-241): gamma is trained and carries three times
+        # the weight decay; mean / std hold the running statistics ('train') or the
+        # statistics to apply ('predict')
+        bn = self.batch_normalisation
         self.gamma = self.mean = self.std = None
+        if bn == 'train':
+            sh = (n_f,)
+            self._register_param(gamma, sh, 'gamma', init_kwargs=dict(scale=1.0, mode='const'),
+                                 apply_train=True, apply_reg=3.0)
+            if mean is not None or std is not None:
+                raise ValueError("Cannot pass mean and std for training, they "
+                                 "are computed in the theano graph.")
+            self._register_param(None, sh, 'mean', init_kwargs=dict(scale=0.0, mode='const'))
+            self._register_param(None, sh, 'std', init_kwargs=dict(scale=1.0, mode='const'))
+        elif bn == 'predict':
+            sh = (n_f,)
+            self._register_param(gamma, sh, 'gamma', init_kwargs=dict(scale=1.0, mode='const'))
+            self._register_param(mean, sh, 'mean', init_kwargs=dict(scale=0.0, mode='const'))
+            self._register_param(std, sh, 'std', init_kwargs=dict(scale=1.0, mode='const'))
+        elif bn == 'fadeout':
+            raise NotImplementedError("batch_normalisation='fadeout' needs gradnet, which is "
+                                      "outside the HIP hot path")
+        elif bn is not False and bn is not None:
+            raise ValueError("Unknown value %s for batchnormalisation" % (bn,))
         self.dropout_rate = None
         if dropout_rate:
             raise NotImplementedError("dropout is outside the HIP hot path")
@@ -162,10 +187,18 @@ class Conv(NeuralLayer):
         n_in = parent.shape['f']
         fail = False
         w_sh = None
-        if conv_dim in (1, 2):
-            raise NotImplementedError("Only 3-D convolutions run on the HIP hot path "
-                                      "(1-D/2-D are CPU plumbing in the reference "
-                                      "configs, SURVEY.md §8d)")
+        if conv_dim == 1:
+            raise NotImplementedError("1-D convolutions are outside the HIP hot path "
+                                      "(no reference config uses them)")
+        elif conv_dim == 2:
+            # config 1 (examples/mnist.py): 'b,f,y,x' -- the 3-D kernels with a unit z axis
+            if x_dim != 4:
+                fail = True
+            if self.spatial_axes == [2, 3]:
+                self.axis_order = 'dnn'
+                w_sh = [n_f, n_in] + list(filter_shape)
+            else:
+                fail = True
         elif conv_dim == 3:
             if x_dim != 5:
                 fail = True
@@ -268,15 +301,38 @@ class Conv(NeuralLayer):
         return UpConv(parent, self.parent.shape['f'], self.pool_shape, **defaults)
 
     # ---- device execution ------------------------------------------------------------
+    @property
+    def _k3(self):
+        """kernel as (kz, kx, ky): 2-D layers get a unit z axis"""
+        return (1,) * (3 - len(self.filter_shape)) + tuple(int(k) for k in self.filter_shape)
+
+    @property
+    def _p3(self):
+        return (1,) * (3 - len(self.pool_shape)) + tuple(int(p) for p in self.pool_shape)
+
+    @staticmethod
+    def _sp3(shape):
+        sp = tuple(int(v) for v in shape.spatial_shape)
+        return (1,) * (3 - len(sp)) + sp
+
+    @staticmethod
+    def _w5(w):
+        """device weights as (n_f, n_in, kz, kx, ky)"""
+        return w if w.dim() == 5 else w.reshape(tuple(w.shape[:2]) + (1,) * (5 - w.dim()) +
+                                                 tuple(w.shape[2:]))
+
+    def _bn(self):
+        return self.batch_normalisation in ('train', 'predict')
+
     def _fused_first(self, plan):
         """Cin = 1 first layer with a supported kernel/pool: fused conv+pool+bias+act
         kernels that never materialise the conv output (csrc/conv_first.hip)."""
-        return (self.parent.is_source and self.parent.shape['f'] == 1 and
-                plan.ctx.conv1_supported(1, self.filter_shape, self.pool_shape) and
+        return (not self._bn() and self.parent.is_source and self.parent.shape['f'] == 1 and
+                plan.ctx.conv1_supported(1, self._k3, self._p3) and
                 not plan.needs_grad(self.parent) and not self._mfp_pool())
 
     def _mfp_pool(self):
-        return bool(self.mfp) and not all(p == 1 for p in self.pool_shape)
+        return bool(self.mfp) and not all(p == 1 for p in self._p3)
 
     def _fused_head(self, plan):
         """classifier head: this (1,1,1) 'lin' conv to <= 4 features feeds nothing but a
@@ -286,8 +342,8 @@ class Conv(NeuralLayer):
         if key not in plan.scratch:
             sm = None
             kids = list(self.children.values())
-            if (type(self) is Conv and tuple(self.filter_shape) == (1, 1, 1)
-                    and all(p == 1 for p in self.pool_shape) and self.activation_func == 'lin'
+            if (type(self) is Conv and not self._bn() and tuple(self._k3) == (1, 1, 1)
+                    and all(p == 1 for p in self._p3) and self.activation_func == 'lin'
                     and len(kids) == 1 and type(kids[0]).__name__ == 'Softmax'
                     and kids[0].n_indep == 1
                     and any(n is kids[0] for n in plan.nodes)
@@ -301,19 +357,19 @@ class Conv(NeuralLayer):
     def _fused_act(self, plan):
         """no pooling and a specialised kernel width: bias + activation go into the
         conv kernel's epilogue, the pre-activation is never stored"""
-        if not (all(p == 1 for p in self.pool_shape) and self.filter_shape[2] in (1, 3, 4, 5)
-                and type(self) is Conv and not self._fused_first(plan)):
+        if not (all(p == 1 for p in self._p3) and self._k3[2] in (1, 3, 4, 5)
+                and type(self) is Conv and not self._bn() and not self._fused_first(plan)):
             return False
         # the fused epilogue cannot split K: only where the output alone yields enough
         # work-groups to fill the chip (small late layers keep split-K + pointwise pass)
-        osp = self.shape.spatial_shape
+        osp = self._sp3(self.shape)
         tiles = plan.batch * osp[0] * (-(-(osp[1] * osp[2]) // 128)) * (-(-self.n_f // 112))
         return tiles >= 160
 
     def _plan_alloc(self, plan):
         N = plan.out_shape(self.parent)[0]     # (the fragments of MFP sit on the batch axis)
-        psp = self.parent.shape.spatial_shape
-        k = self.filter_shape
+        psp = self._sp3(self.parent.shape)
+        k = self._k3
         if self.mfp and plan.training:
             raise NotImplementedError("MFP is a prediction-time rewrite of the net "
                                       "(neural.py:531-533); train without it")
@@ -330,6 +386,13 @@ class Conv(NeuralLayer):
         if not self._fused_act(plan):
             plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
         plan.alloc_out(self)
+        if self._bn():
+            pooled = any(p != 1 for p in self._p3)
+            if pooled:        # batch norm acts on the POOLED conv output (neural.py:678-681)
+                plan.scratch[self, 'lin'] = plan.empty(plan.out_shape(self))
+                if plan.training:
+                    plan.scratch[self, 'dlin'] = plan.empty(plan.out_shape(self))
+            plan.scratch[self, 'bn_save'] = plan.zeros_flat(2 * self.n_f)
         cin = self.parent.shape['f']
         nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
         plan.scratch[self, 'wp_f'] = plan.zeros_flat(nb // 4 + 64)   # padding stays zero
@@ -354,7 +417,7 @@ class Conv(NeuralLayer):
             return                            # done by the Softmax / NLL node
         x = plan.out[self.parent]
         if self._fused_first(plan):
-            ctx.conv1_pool_act_fwd(x, plan.param(self.w), plan.param(self.b), self.pool_shape,
+            ctx.conv1_pool_act_fwd(x, self._w5(plan.param(self.w)), plan.param(self.b), self._p3,
                                    self.activation_func, plan.out[self])
             return
         wp = plan.scratch[self, 'wp_f']       # packed by the plan's multi-pack launch
@@ -362,34 +425,49 @@ class Conv(NeuralLayer):
         cin = self.parent.shape['f']
         if self._fused_act(plan):
             out = plan.out[self]
-            sig = (2, self.n_f, cin) + tuple(self.filter_shape) + tuple(out.shape[2:]) + \
+            sig = (2, self.n_f, cin) + tuple(self._k3) + tuple(out.shape[2:]) + \
                 (x.stride(3),)
             plan.tuned('igemm', sig,
-                       autotune.igemm_candidates(self.n_f, cin, self.filter_shape,
+                       autotune.igemm_candidates(self.n_f, cin, self._k3,
                                                  out.shape[2:], split_k=False),
-                       lambda: ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self.filter_shape,
+                       lambda: ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self._k3,
                                                          plan.param(self.b),
                                                          self.activation_func, out))
             return
         y = plan.scratch[self, 'y']
-        sig = (0, self.n_f, cin) + tuple(self.filter_shape) + tuple(y.shape[2:]) + \
+        sig = (0, self.n_f, cin) + tuple(self._k3) + tuple(y.shape[2:]) + \
             (x.stride(3),)
         plan.tuned('igemm', sig,
-                   autotune.igemm_candidates(self.n_f, cin, self.filter_shape, y.shape[2:]),
-                   lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self.filter_shape, y), out=y)
+                   autotune.igemm_candidates(self.n_f, cin, self._k3, y.shape[2:]),
+                   lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self._k3, y), out=y)
+        if self._bn():
+            lin = y
+            if any(p != 1 for p in self._p3):
+                if self._mfp_pool():
+                    raise NotImplementedError("MFP together with batch normalisation")
+                lin = plan.scratch[self, 'lin']
+                ctx.maxpool3d_fwd(y, self._p3, lin)
+            train = self.batch_normalisation == 'train'
+            # the running statistics are extra updates of the OPTIMISER's step function
+            # (model.py:180-192), not of loss / prediction / gradient functions
+            ctx.batchnorm_act_fwd(lin, plan.param(self.gamma), plan.param(self.b),
+                                  plan.param(self.mean), plan.param(self.std), train,
+                                  train and plan.step in ('SGD', 'Adam'), self.activation_func,
+                                  plan.out[self], plan.scratch[self, 'bn_save'])
+            return
         if self._mfp_pool():
             # fragment i = max-pool of the conv output shifted by the i-th offset inside the
             # pooling window (border ignored), stacked fragment-major on the batch axis
             from itertools import product
             out, n_in = plan.out[self], y.shape[0]
-            pz, px, py = self.pool_shape
+            pz, px, py = self._p3
             D, H, W = y.shape[2:]
             for i, (iz, ix, iy) in enumerate(product(range(pz), range(px), range(py))):
                 src = y[:, :, iz:iz + D - pz + 1, ix:ix + H - px + 1, iy:iy + W - py + 1]
-                ctx.pool_bias_act_fwd(src, plan.param(self.b), self.pool_shape,
+                ctx.pool_bias_act_fwd(src, plan.param(self.b), self._p3,
                                       self.activation_func, out[i * n_in:(i + 1) * n_in])
             return
-        ctx.pool_bias_act_fwd(y, plan.param(self.b), self.pool_shape, self.activation_func,
+        ctx.pool_bias_act_fwd(y, plan.param(self.b), self._p3, self.activation_func,
                               plan.out[self])
 
     def _plan_bwd(self, plan):
@@ -398,28 +476,40 @@ class Conv(NeuralLayer):
             return
         x = plan.out[self.parent]
         if self._fused_first(plan):
-            ctx.conv1_pool_act_bwd(x, plan.param(self.w), plan.param(self.b), plan.grad[self],
-                                   self.pool_shape, self.activation_func, plan.pgrad(self.w),
+            ctx.conv1_pool_act_bwd(x, self._w5(plan.param(self.w)), plan.param(self.b), plan.grad[self],
+                                   self._p3, self.activation_func, plan.pgrad(self.w),
                                    plan.pgrad(self.b), ws=plan.scratch[self, 'ws1'])
             return
         dy = plan.scratch[self, 'dy']
-        if plan.scratch.get((self, 'dy_done')):
+        if self._bn():
+            train = self.batch_normalisation == 'train'
+            pooled = any(p != 1 for p in self._p3)
+            lin = plan.scratch[self, 'lin'] if pooled else plan.scratch[self, 'y']
+            dlin = plan.scratch[self, 'dlin'] if pooled else dy
+            ctx.batchnorm_act_bwd(plan.grad[self], lin, plan.param(self.gamma),
+                                  plan.param(self.b), plan.scratch[self, 'bn_save'], train,
+                                  self.activation_func, dlin,
+                                  plan.pgrad(self.gamma) if self.gamma.apply_train else None,
+                                  plan.pgrad(self.b))
+            if pooled:
+                ctx.maxpool3d_bwd(dlin, plan.scratch[self, 'y'], self._p3, dy)
+        elif plan.scratch.get((self, 'dy_done')):
             pass        # the consumer's data-gradient launch wrote dy and dbias (below)
         elif self._fused_act(plan):
             ctx.bias_act_bwd_out(plan.grad[self], plan.out[self], self.activation_func, dy,
                                  plan.pgrad(self.b))
         else:
             ctx.pool_bias_act_bwd(plan.grad[self], plan.scratch[self, 'y'], plan.param(self.b),
-                                  self.pool_shape, self.activation_func, dy, plan.pgrad(self.b))
+                                  self._p3, self.activation_func, dy, plan.pgrad(self.b))
         cin = self.parent.shape['f']
-        dw = plan.pgrad(self.w)
+        dw = self._w5(plan.pgrad(self.w))
         dyp = plan.scratch[self, 'dy_pad']
-        sigw = (self.n_f, cin) + tuple(self.filter_shape) + tuple(dy.shape[2:]) + \
+        sigw = (self.n_f, cin) + tuple(self._k3) + tuple(dy.shape[2:]) + \
             (x.stride(3), dy.stride(3))
         # the weight gradient is independent of the data-gradient chain below: side stream
         plan.on_side(lambda: plan.tuned(
             'wgrad', sigw,
-            autotune.wgrad_candidates(self.n_f, cin, self.filter_shape, dy.shape[2:]),
+            autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]),
             lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=True),
             fn_tune=lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=False)))
         if plan.needs_grad(self.parent):
@@ -431,34 +521,34 @@ class Conv(NeuralLayer):
                 # backward runs in this launch's epilogue, which writes the parent's
                 # zero-padded gradient buffer and bias gradient directly
                 pdyp = plan.scratch[par, 'dy_pad']
-                ppad = [kk - 1 for kk in par.filter_shape]
+                ppad = [kk - 1 for kk in par._k3]
                 if par._fused_act(plan):
                     src, pb = plan.out[par], None
                 else:
                     src, pb = plan.scratch[par, 'y'], plan.param(par.b)
                 osp = plan.out_shape(par)[2:]
-                sig = (1, cin, self.n_f) + tuple(self.filter_shape) + tuple(osp) + \
+                sig = (1, cin, self.n_f) + tuple(self._k3) + tuple(osp) + \
                     (dyp.stride(3),)
                 plan._grad_written.add(id(par))
                 plan.scratch[par, 'dy_done'] = True
 
                 def launch(dbias):
-                    ctx.conv3d_dgrad_packed_actbwd(dyp, wp, cin, self.filter_shape, src,
+                    ctx.conv3d_dgrad_packed_actbwd(dyp, wp, cin, self._k3, src,
                                                    par.activation_func, pdyp, ppad, dbias,
                                                    bias_prev=pb)
                 plan.tuned('igemm', sig,
-                           autotune.igemm_candidates(cin, self.n_f, self.filter_shape, osp),
+                           autotune.igemm_candidates(cin, self.n_f, self._k3, osp),
                            lambda: launch(plan.pgrad(par.b)), fn_tune=lambda: launch(None),
                            fn_once=lambda: launch(plan.pgrad(par.b)), out=pdyp)
                 return
             dst, first = plan.grad_slot(self.parent)
             out = dst if first else plan.tmp_like(dst)
-            sig = (1, cin, self.n_f) + tuple(self.filter_shape) + tuple(out.shape[2:]) + \
+            sig = (1, cin, self.n_f) + tuple(self._k3) + tuple(out.shape[2:]) + \
                 (dyp.stride(3),)
             plan.tuned('igemm', sig,
-                       autotune.igemm_candidates(cin, self.n_f, self.filter_shape,
+                       autotune.igemm_candidates(cin, self.n_f, self._k3,
                                                  out.shape[2:]),
-                       lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self.filter_shape, out),
+                       lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out),
                        out=out)
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
@@ -469,16 +559,116 @@ class Conv(NeuralLayer):
         from this node alone"""
         par = self.parent
         if not (plan.fuse_actbwd and type(par) is Conv and type(self) is Conv
-                and all(p == 1 for p in par.pool_shape)
+                and not par._bn() and all(p == 1 for p in par._p3)
                 and par.activation_func in ('relu', 'lin')
                 and (par, 'dy_pad') in plan.scratch
                 and not par._fused_first(plan) and par._fused_head(plan) is None
-                and self.filter_shape[2] in (1, 3, 4, 5)
+                and self._k3[2] in (1, 3, 4, 5)
                 and plan.out_shape(par)[4] >= 4):
             return False
         users = [c for c in par.children.values()
                  if id(c) in plan._loss_anc or c is plan.loss_node]
         return len(users) == 1 and users[0] is self
+
+
+class Perceptron(NeuralLayer):
+    """Perceptron layer (neural.py:258-410): ``act((gamma / std) * dot(x, w) + b - ...)``;
+    ``w`` has the reference's (n_in, n_f) shape; ``flatten=True`` joins every non-batch axis
+    of the parent (C order).  Device side: csrc/dense_bn.hip."""
+
+    def __init__(self, parent, n_f, activation_func='relu',
+                 flatten=False, batch_normalisation=False, dropout_rate=0,
+                 name="dot", print_repr=True, w=None, b=None, gamma=None,
+                 mean=None, std=None, gradnet_mode=None):
+        Node.__init__(self, parent, name, print_repr)
+        self.n_f = n_f
+        self.activation_func = activation_func
+        self.batch_normalisation = batch_normalisation
+        self.gradnet_mode = gradnet_mode
+        self.axis = parent.shape.tag2index('f')
+        self.flatten = flatten
+        self.spatial_axes = parent.shape.spatial_axes
+        if activation_func not in _HIP_ACTS:
+            raise NotImplementedError("activation_func=%r: only %s are on the HIP hot path"
+                                      % (activation_func, _HIP_ACTS))
+        if flatten:
+            if self.axis != 1:
+                raise NotImplementedError("Cannot flatten tensor for "
+                                          "Perceptron layer when batchsize is "
+                                          "not on first axis")
+            n_in = parent.shape.stripbatch_prod
+        else:
+            n_in = parent.shape['f']
+            if any(int(s) != 1 for s in parent.shape.spatial_shape):
+                raise NotImplementedError("a Perceptron over the feature axis of a spatial "
+                                          "tensor is a (1,1,1) Conv on this path")
+        w_sh = (n_in, n_f)
+        self.w_sh = w_sh
+        self._setup_params(w_sh, w, b, gamma, mean, std, dropout_rate)
+
+    def _make_output(self):
+        self.output = Sym(self, floatX)
+
+    def _calc_shape(self):
+        sh = self.parent.shape
+        if self.flatten:
+            self.shape = TaggedShape((sh['b'], self.n_f), 'b,f')
+        else:
+            self.shape = sh.updateshape('f', self.n_f)
+
+    def _calc_comp_cost(self):
+        self.computational_cost = self.parent.shape.stripnone_prod * self.n_f
+
+    def _bn(self):
+        return self.batch_normalisation in ('train', 'predict')
+
+    def _plan_alloc(self, plan):
+        plan.alloc_out(self)
+        plan.scratch[self, 'lin'] = plan.empty(plan.out_shape(self))
+        if plan.training:
+            plan.scratch[self, 'dlin'] = plan.empty(plan.out_shape(self))
+        if self._bn():
+            plan.scratch[self, 'bn_save'] = plan.zeros_flat(2 * self.n_f)
+
+    def _x2(self, plan, t):
+        """the parent's buffer as the (batch, n_in) matrix"""
+        if not t.is_contiguous():
+            raise NotImplementedError("Perceptron input must be a dense buffer")
+        return t.reshape(t.shape[0], -1)
+
+    def _plan_fwd(self, plan):
+        ctx = plan.ctx
+        lin = plan.scratch[self, 'lin']
+        ctx.dense_fwd(self._x2(plan, plan.out[self.parent]), plan.param(self.w),
+                      lin.reshape(lin.shape[0], -1))
+        if self._bn():
+            train = self.batch_normalisation == 'train'
+            ctx.batchnorm_act_fwd(lin, plan.param(self.gamma), plan.param(self.b),
+                                  plan.param(self.mean), plan.param(self.std), train,
+                                  train and plan.step in ('SGD', 'Adam'), self.activation_func,
+                                  plan.out[self], plan.scratch[self, 'bn_save'])
+        else:
+            ctx.pool_bias_act_fwd(lin, plan.param(self.b), (1, 1, 1), self.activation_func,
+                                  plan.out[self])
+
+    def _plan_bwd(self, plan):
+        ctx = plan.ctx
+        lin, dlin = plan.scratch[self, 'lin'], plan.scratch[self, 'dlin']
+        if self._bn():
+            ctx.batchnorm_act_bwd(plan.grad[self], lin, plan.param(self.gamma),
+                                  plan.param(self.b), plan.scratch[self, 'bn_save'],
+                                  self.batch_normalisation == 'train', self.activation_func,
+                                  dlin, plan.pgrad(self.gamma) if self.gamma.apply_train else None,
+                                  plan.pgrad(self.b))
+        else:
+            ctx.pool_bias_act_bwd(plan.grad[self], lin, plan.param(self.b), (1, 1, 1),
+                                  self.activation_func, dlin, plan.pgrad(self.b))
+        d2 = dlin.reshape(dlin.shape[0], -1)
+        ctx.dense_wgrad(self._x2(plan, plan.out[self.parent]), d2, plan.pgrad(self.w),
+                        accumulate=True)
+        if plan.needs_grad(self.parent):
+            dst, first = plan.grad_slot(self.parent)
+            ctx.dense_dgrad(d2, plan.param(self.w), self._x2(plan, dst), accumulate=not first)
 
 
 class FragmentsToDense(Node):

@@ -100,7 +100,25 @@ class Plan(object):
         return torch.zeros(int(n), dtype=torch.float32, device=self.ctx.device)
 
     def out_shape(self, node):
-        return tuple(self.batch if s is None else int(s) for s in node.shape.shape)
+        """DEVICE shape of a node's output: always (b, f, z, x, y).  Nodes with fewer spatial
+        axes (config 1: 'b,f,y,x' images, 'b,f' Perceptron outputs) get unit axes behind
+        'f', so every kernel sees the 5-D layout it is written for."""
+        sh = tuple(self.batch if s is None else int(s) for s in node.shape.shape)
+        if len(sh) == 5:
+            return sh
+        tags = tuple(node.shape.tags)
+        if len(sh) < 2 or len(sh) > 5 or tags[0] != 'b' or tags[1] != 'f':
+            raise NotImplementedError("axis order %s: the device layout is (b, f, spatial...)"
+                                      % (",".join(tags),))
+        return sh[:2] + (1,) * (5 - len(sh)) + sh[2:]
+
+    @staticmethod
+    def user_view(node, t):
+        """a device tensor in the rank the node declares (drops the unit axes of out_shape)"""
+        n = len(node.shape.shape)
+        if n == 5 or t.dim() != 5:
+            return t
+        return t.reshape(tuple(t.shape[:2]) + tuple(t.shape[5 - (n - 2):]))
 
     def alloc_out(self, node):
         self.out[node] = self.empty(self.out_shape(node))
@@ -129,6 +147,12 @@ class Plan(object):
 
     def param(self, p):
         return self.model.device_param(p)
+
+    @staticmethod
+    def _w5(w):
+        """conv weights as (n_f, n_in, kz, kx, ky): 2-D layers get a unit z axis"""
+        return w if w.dim() == 5 else w.reshape(tuple(w.shape[:2]) + (1,) * (5 - w.dim()) +
+                                                 tuple(w.shape[2:]))
 
     def pgrad(self, p):
         return self.model.device_grad(p)
@@ -266,7 +290,7 @@ class Plan(object):
                 n._plan_alloc(self)
             self._pack_dev = None
             if self.pack_jobs:
-                jobs = [(self.param(w), wp, mode) for (w, wp, mode) in self.pack_jobs]
+                jobs = [(self._w5(self.param(w)), wp, mode) for (w, wp, mode) in self.pack_jobs]
                 self._pack_dev = self.ctx.make_pack_jobs(jobs)
         self._graphs = None
         self._segs = None
@@ -512,10 +536,10 @@ class Plan(object):
                         continue          # written in place (input_buffer): nothing to copy
                     if a.is_cuda:
                         a.record_stream(self.stream)
-                    dst.copy_(a.to(torch.float32), non_blocking=True)
+                    dst.copy_(a.to(torch.float32).reshape(dst.shape), non_blocking=True)
                 else:
                     h = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-                    dst.copy_(h, non_blocking=False)
+                    dst.copy_(h.reshape(dst.shape), non_blocking=False)
 
     def run(self):
         """launch the plan on the already-set inputs; returns nothing (async)."""
@@ -542,7 +566,7 @@ class Plan(object):
                     raise NotImplementedError("output of node %s is not materialised"
                                               % (o.name,))
                 else:
-                    rets.append(self.out[o].detach().cpu().numpy().copy())
+                    rets.append(self.user_view(o, self.out[o]).detach().cpu().numpy().copy())
         if self.step == 'grad':
             return [g.detach().cpu().numpy().copy()
                     for g in self.model.device_grads_list()]

@@ -361,6 +361,38 @@ int e2_stream_synchronize(e2_ctx*);
 int e2_stream_fork(e2_ctx*, void* side_stream);
 int e2_stream_join(e2_ctx*, void* side_stream);
 
+/* ---- BASELINE config 1 (examples/mnist.py:29-56): Perceptron and batch normalisation ----
+ * Correctness-first kernels for the reference's CPU-runnable plumbing case.
+ *
+ * Perceptron (neural.py:258-410, computations.py:179-213 `dot`): plain row-major matrices,
+ *   y (n x m) = x (n x k) . w (k x m)              w has the reference's (n_in, n_f) layout
+ *   dx (n x k) (+)= dy (n x m) . w^T               accumulate: 0 overwrite, 1 add
+ *   dw (k x m) (+)= x^T . dy
+ * bias / activation of a Perceptron without batch norm: e2_pool_bias_act_fwd / _bwd with a
+ * (1,1,1) window on the (n, m, 1, 1, 1) view. */
+int e2_dense_fwd(e2_ctx*, const float* x, const float* w, float* y, int n, int k, int m);
+int e2_dense_dgrad(e2_ctx*, const float* dy, const float* w, float* dx, int n, int k, int m,
+                   int accumulate);
+int e2_dense_wgrad(e2_ctx*, const float* x, const float* dy, float* dw, int n, int k, int m,
+                   int accumulate);
+/* Batch normalisation + bias + activation (neural.py:352-378 Perceptron, 681-711 Conv; applied
+ * to the pooled conv output / the dot product):
+ *   train != 0: mean, std = statistics of x over every axis but the channel (population std,
+ *               + 1e-6); update_running != 0 additionally performs the training function's
+ *               extra updates  run_mean <- 0.9995 run_mean + 0.0005 mean  (same for run_std)
+ *   train == 0: mean, std = run_mean, run_std ('predict' mode)
+ *   out = act((gamma / std) * x + bias - gamma * mean / std)
+ * save (2 * c floats, may be NULL in forward-only use) receives the mean and std used.
+ * Backward: dx (may be NULL), dgamma += , dbias += (either may be NULL); in train mode the
+ * gradient flows through the batch statistics (as T.grad does), in predict mode they are
+ * constants.  relu'(0) = 0.5. */
+int e2_batchnorm_act_fwd(e2_ctx*, const e2_tensor5* x, const float* gamma, const float* bias,
+                         float* run_mean, float* run_std, int train, int update_running,
+                         int act, const e2_tensor5* out, float* save);
+int e2_batchnorm_act_bwd(e2_ctx*, const e2_tensor5* dout, const e2_tensor5* x,
+                         const float* gamma, const float* bias, const float* save, int train,
+                         int act, const e2_tensor5* dx, float* dgamma, float* dbias);
+
 #ifdef __cplusplus
 }
 #endif

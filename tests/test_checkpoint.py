@@ -84,6 +84,33 @@ def test_graph_description_round_trip(tmp_path):
     assert mu2.prediction_node.shape.fov == mu.prediction_node.shape.fov   # fixed up in designate_nodes
 
 
+def test_config1_graph_round_trip(tmp_path):
+    """the mnist graph (2-D convs with batch norm, Perceptrons, 'b,f' tensors) through
+    save -> modelload: classes, shapes, every parameter incl. the running statistics; batch
+    override"""
+    from elektronn2_amd import nets, neuromancer as nm
+    from elektronn2_amd.neuromancer.model import modelload
+    nm.model_manager.reset()
+    np.random.seed(0)
+    m = nets.mnist()
+    m.nodes['conv'].mean.set_value(np.arange(12, dtype=np.float32))
+    f = str(tmp_path / "mnist.mdl")
+    m.save(f)
+    m2 = modelload(f, name='rebuilt')
+    assert list(m2.nodes.keys()) == list(m.nodes.keys())
+    for k in m.nodes:
+        a, b = m.nodes[k], m2.nodes[k]
+        assert type(a).__name__ == type(b).__name__, k
+        assert list(a.shape.shape) == list(b.shape.shape) and list(a.shape.tags) == list(b.shape.tags)
+        for pk in a.params:
+            assert np.array_equal(a.params[pk].get_value(), b.params[pk].get_value()), (k, pk)
+            assert a.params[pk].apply_train == b.params[pk].apply_train
+            assert a.params[pk].apply_reg == b.params[pk].apply_reg
+    assert m2.nodes['conv'].batch_normalisation == 'train' and m2.nodes['dot'].flatten
+    m3 = modelload(f, name='b5', imposed_batch_size=5)
+    assert list(m3.input_node.shape.shape) == [5, 1, 26, 26]
+
+
 @pytest.mark.gpu
 def test_resume_restores_parameters_and_adam_state(tmp_path):
     """train 3 steps, save, go on for 2 steps; a FRESH model (other initial weights, no
