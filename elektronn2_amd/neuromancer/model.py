@@ -195,7 +195,11 @@ class Model(GraphManager):
         self.n_train = max([self._slots[id(p)][0] + (self._slots[id(p)][1] + 3) // 4 * 4
                             for p in params if p.apply_train] or [0])
         self.P = torch.zeros(max(off, 4), dtype=torch.float32, device=ctx.device)
-        self.G = torch.zeros(max(self.n_train, 4), dtype=torch.float32, device=ctx.device)
+        # (+4: a spare slot behind the arena -- the labelled-voxel count of the data-parallel
+        # exchange travels there, parallel.BucketedMean)
+        self._G_store = torch.zeros(max(self.n_train, 4) + 4, dtype=torch.float32,
+                                    device=ctx.device)
+        self.G = self._G_store[:max(self.n_train, 4)]
         seg_off, seg_reg = [], []
         for p in params:
             o, n, sh = self._slots[id(p)]
@@ -261,7 +265,8 @@ class Model(GraphManager):
         rank's labelled-voxel count on the device (weighted mean, see enable_data_parallel)"""
         from ..parallel import BucketedMean
         return BucketedMean(self.G, self._dp_group,
-                            count=count if getattr(self, '_dp_weighted', False) else None)
+                            count=count if getattr(self, '_dp_weighted', False) else None,
+                            spare=True)
 
     # ------------------------------------------------------------------ functions
     def save(self, file_name):

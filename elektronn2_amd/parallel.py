@@ -54,35 +54,44 @@ class BucketedMean:
     current stream (RCCL runs it on its own stream); finish() makes the current stream
     wait for every slice."""
 
-    def __init__(self, flat, group=None, count=None):
+    def __init__(self, flat, group=None, count=None, spare=False):
         """``count``: one-element tensor with this rank's number of LABELLED target voxels.
         The reference normalises the NLL by the labelled count of the WHOLE batch
         (loss.py:342-344); a rank's gradient is normalised by its own count, so with
         ragged counts the whole-batch gradient is the count-weighted mean
-        sum_r n_r g_r / sum_r n_r, not the plain mean.  With ``count`` given, every slice
-        is scaled by n_r * world / sum_r n_r before it is summed (one extra one-element
-        all-reduce per step); equal counts reduce to the plain mean."""
+        sum_r n_r g_r / sum_r n_r, not the plain mean.  With ``count`` given,
+        every slice is scaled by n_r before it is summed and the sum is divided by
+        sum_r n_r afterwards; equal counts reduce to the plain mean.
+
+        ``spare``: ``flat``'s storage holds at least one more float behind its last
+        element (the model's gradient arena does).  The count then travels IN the first
+        slice that reaches the arena's end -- no collective of its own, which at these
+        sizes is pure latency; without a spare slot it takes a one-element all-reduce."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._work, self._covered = [], 0
-        self._count, self._weight = count, None
-
-    def _scale_slice(self, lo, hi):
-        if self._count is None:
-            return
-        if self._weight is None:
-            tot = self._count.detach().clone()
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
-            self._weight = self._count.detach() * float(self.world) / torch.clamp(tot, min=1e-30)
-        self.flat[lo:hi].mul_(self._weight)
+        self._count, self._total = count, None
+        self._ext = None
+        if count is not None and spare:
+            n = flat.numel()
+            self._ext = flat.as_strided((n + 1,), (1,), flat.storage_offset())
 
     def start(self, lo, hi):
         if self.world == 1 or hi <= lo:
             return
-        self._scale_slice(lo, hi)
-        self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM,
+        buf = self.flat
+        if self._count is not None:
+            self.flat[lo:hi].mul_(self._count)               # n_r * g_r
+            if self._ext is not None:
+                if hi == self.flat.numel():                  # the count rides behind the tail
+                    self._ext[hi:hi + 1].copy_(self._count)
+                    buf, hi = self._ext, hi + 1
+            elif self._total is None:
+                self._total = self._count.detach().clone()
+                dist.all_reduce(self._total, op=dist.ReduceOp.SUM, group=self.group)
+        self._work.append(dist.all_reduce(buf[lo:hi], op=dist.ReduceOp.SUM,
                                           group=self.group, async_op=True))
-        self._covered += hi - lo
+        self._covered += min(hi, self.flat.numel()) - lo
 
     def finish(self):
         if self.world == 1:
@@ -92,8 +101,12 @@ class BucketedMean:
         if self._covered != self.flat.numel():
             raise RuntimeError("BucketedMean: slices cover %d of %d elements"
                                % (self._covered, self.flat.numel()))
-        self._work, self._covered, self._weight = [], 0, None
-        self.flat.mul_(1.0 / self.world)
+        if self._count is None:
+            self.flat.mul_(1.0 / self.world)
+        else:
+            tot = self._ext[self.flat.numel():] if self._ext is not None else self._total
+            self.flat.mul_(1.0 / torch.clamp(tot, min=1e-30))
+        self._work, self._covered, self._total = [], 0, None
         return self.flat
 
 

@@ -127,11 +127,21 @@ def _worker4(rank, world, port, q):
     ex.finish()
     plain = flat.clone()
     parallel.allreduce_mean_(plain)
-    # the single-exchange form gives the same weighted result
+    # the single-exchange form gives the same weighted result; so does the form in which
+    # the count travels in the arena's spare slot instead of a collective of its own
     one = flat.clone()
     ex1 = parallel.BucketedMean(one, count=count)
     ex1.start(0, one.numel())
     ex1.finish()
+    store = torch.full((flat.numel() + 4,), 7.0)
+    rider = store[:flat.numel()]
+    rider.copy_(flat)
+    ex2 = parallel.BucketedMean(rider, count=count, spare=True)
+    ex2.start(lo, rider.numel())
+    ex2.start(0, lo)
+    ex2.finish()
+    assert (rider - weighted).abs().max() <= 1e-6 * weighted.abs().max()
+    assert float(store[flat.numel()]) == float(sum((_ragged_data(r)[1] >= 0).sum() for r in range(world)))
     # (same numbers up to the summation order of gloo's ring over different slice sizes)
     assert (one - weighted).abs().max() <= 1e-6 * weighted.abs().max()
     q.put((rank, weighted.numpy(), plain.numpy(), float(count)))
