@@ -83,6 +83,16 @@ def _near_divisors(n, target):
     return ([lo[-1]] if lo else []) + ([hi[0]] if hi else [])
 
 
+BF16_MEMORY_TILES = ("32,1,1", "32,1,2", "32,2,1", "32,2,2", "32,1,4", "32,4,1")
+
+
+def bf16_memory_candidates(cin):
+    """"32,MB,NB": the conv kernel with bf16 operands in memory (csrc/conv_bf16.hip), a
+    candidate of the bf16 mode next to the operand-rounding tilings; it pads the reduction
+    channels to 16, so it is not offered for very few of them"""
+    return list(BF16_MEMORY_TILES) if cin >= 16 else []
+
+
 def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     mblocks = -(-cout // 16)
     q = out_sp[1] * out_sp[2]

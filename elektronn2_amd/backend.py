@@ -103,6 +103,9 @@ def _load():
         "e2_conv_last_zero_fill": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
         "e2_set_tiling": (C.c_int, [vp, C.c_int, C.c_char_p]),
+        "e2_conv3d_bf16_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
+        "e2_conv3d_fwd_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, fp, i, P5, vp, sz]),
+        "e2_conv3d_dgrad_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz]),
         "e2_dense_fwd": (C.c_int, [vp, fp, fp, fp, i, i, i]),
         "e2_dense_dgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
         "e2_dense_wgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
@@ -449,6 +452,29 @@ class Context:
         _chk(_lib.e2_conv_last_zero_fill(self.h, C.byref(p), C.byref(n)), "e2_conv_last_zero_fill")
         return (p.value or 0), int(n.value)
 
+    # ---- bf16 operands in memory (32x32x16 MFMA kernel, csrc/conv_bf16.hip) ---------------
+    @staticmethod
+    def conv_bf16_ws_bytes(x_shape, cout, k):
+        n, cin, d, h, w = (int(v) for v in x_shape)
+        return int(_lib.e2_conv3d_bf16_workspace_bytes(n, cin, d, h, w, int(cout), k[0], k[1], k[2]))
+
+    def conv3d_fwd_bf16(self, x, w, y, bias=None, act='lin', ws=None):
+        cout, cin, kd, kh, kw = w.shape
+        if ws is None:
+            ws = self.workspace("conv_bf16", self.conv_bf16_ws_bytes(x.shape, cout, (kd, kh, kw)))
+        _chk(_lib.e2_conv3d_fwd_bf16(self.h, C.byref(t5(x)), _fp(w), cout, kd, kh, kw,
+                                     _fp(bias), ACT[act], C.byref(t5(y)),
+                                     C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size()),
+             "e2_conv3d_fwd_bf16")
+
+    def conv3d_dgrad_bf16(self, dy_pad, w, dx, ws=None):
+        cout, cin, kd, kh, kw = w.shape
+        if ws is None:
+            ws = self.workspace("conv_bf16", self.conv_bf16_ws_bytes(dx.shape, cout, (kd, kh, kw)))
+        _chk(_lib.e2_conv3d_dgrad_bf16(self.h, C.byref(t5(dy_pad)), _fp(w), cin, kd, kh, kw,
+                                       C.byref(t5(dx)), C.c_void_p(ws.data_ptr()),
+                                       ws.numel() * ws.element_size()), "e2_conv3d_dgrad_bf16")
+
     # ---- config 1 (mnist): Perceptron dot product, batch normalisation ------------------
     def dense_fwd(self, x, w, y):
         """y (n, m) = x (n, k) . w (k, m); contiguous 2-D views of device tensors"""
@@ -484,6 +510,14 @@ class Context:
         the choice to the library's cost model (e2_set_tiling)"""
         code = {'igemm': 0, 'wgrad': 1}[kind]
         _chk(_lib.e2_set_tiling(self.h, code, (cfg or "").encode()), "e2_set_tiling")
+        self._tiling = getattr(self, '_tiling', {})
+        self._tiling[kind] = cfg or ""
+
+    def bf16_memory_form(self):
+        """True while the forced igemm tiling selects the kernel with bf16 operands in memory
+        ("32,MB,NB", csrc/conv_bf16.hip): the callers that hold the canonical weights then
+        call conv3d_fwd_bf16 / conv3d_dgrad_bf16 instead of the packed entry points"""
+        return getattr(self, '_tiling', {}).get('igemm', '').startswith('32,')
 
     def set_mfma_dtype(self, dtype):
         """'f32' (default) or 'bf16': operand rounding of the conv GEMMs (f32 sums)"""

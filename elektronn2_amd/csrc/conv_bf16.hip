@@ -1,0 +1,473 @@
+// conv_bf16.hip -- conv forward / data gradient with bf16 operands IN MEMORY and LDS-staged
+// input windows, built for the 32-cycle v_mfma_f32_32x32x16_bf16.
+//
+// Two conversion passes per call write
+//   Xb[n][z][kg][y][x][8]   the input as bf16: for one z-plane and one group of 8 channels the
+//                           pixels are consecutive 16-byte pieces (a "pixel" below)
+//   Wb[dz][slot][kg][oc][8] the filter rows as bf16; the taps of one dz fill the first
+//                           kh*kw*KG/2 "steps", the slab is padded with ZERO steps to a
+//                           multiple of the operand ring depth
+// and the GEMM kernel (4 waves = 2 along the channels x 2 along the positions, each with
+// MB x NB blocks of 32 x 32):
+//   * per dz, the work-group's input window -- ONE contiguous span of pixels per channel
+//     group, as in igemm_core.hpp, with 16-byte elements -- is copied into LDS by LDS-DMA
+//     (double buffered over dz); every tap reads it at a shifted pixel offset
+//     (ds_read_b128, 512 consecutive bytes per half-wave), so the input leaves L2 once per
+//     work-group instead of once per wave and tap (DESIGN.md finding 19: the LDS-free
+//     form was bound by exactly that traffic);
+//   * the filter rows come straight from L2, 16 bytes per lane, PD steps ahead in a ring
+//     of registers whose steady-state loop has no branch (the compiler then counts the
+//     loads in flight instead of draining them).
+// Arithmetic: operands rounded to bf16 (nearest even) as in the operand-rounding form of
+// igemm_core.hpp, f32 products and sums: the bounds of tests/test_bf16_gpu.py hold
+// unchanged.  Output: f32, any strided view, optional fused bias + activation.
+// Limits: all channels of one dz must fit the LDS buffer (K <= ~400 channels for the
+// neuro3d shapes); the caller falls back to the operand-rounding form otherwise.
+#include "common.hpp"
+#include <algorithm>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+namespace {
+
+// a pointer the compiler should keep in SGPRs (wave-uniform by construction)
+__device__ __forceinline__ const void* e2b_uniform(const void* q) {
+  const unsigned long long v = (unsigned long long)(uintptr_t)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+constexpr int kPD = 4;        // filter-row steps in flight per wave
+
+struct CbP {
+  const __bf16* xb;       // [N][Din][KG][Hin][Win][8]
+  const __bf16* wb;       // [kd][stepsP][2][ocP][8]   (step = (tap, channel-group pair))
+  float* out;
+  long osN, osC, osZ, osY;
+  const float* bias;      // fused bias (+ act) or nullptr
+  int act;
+  int N, Cout, KG, ocP;
+  int kd, kh, kw;
+  int Do, Ho, Wo, Q;
+  int Din, Hin, Win;
+  int nPT, nMT;
+  int Lpad;               // pixels per channel group in an LDS buffer
+  // a kernel plane's channel groups are staged in chunks of KGC (the last one kgsLast); the
+  // steps of a chunk -- (tap, pair of its channel groups) -- are padded to FL / LL (multiples
+  // of the ring depth) with zero filter rows
+  int KGC, nck, kgsLast, FL, LL;
+};
+
+// ---- f32 (strided NCDHW view) -> Xb[n][z][kg][y][x][8] --------------------------------
+struct CvP {
+  const float* x;
+  long sN, sC, sZ, sY;
+  int N, C, D, H, W, KG;
+  __bf16* xb;
+};
+// thread = (channel group, pixel): 8 coalesced row reads, one 16-byte store
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(CvP p) {
+  const long total = (long)p.N * p.D * p.KG * p.H * p.W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % p.W);
+    long r = i / p.W;
+    const int y = (int)(r % p.H);   r /= p.H;
+    const int kg = (int)(r % p.KG); r /= p.KG;
+    const int z = (int)(r % p.D);
+    const int n = (int)(r / p.D);
+    const float* src = p.x + (long)n * p.sN + (long)z * p.sZ + (long)y * p.sY + x;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = kg * 8 + j;
+      v[j] = (__bf16)(c < p.C ? src[(long)c * p.sC] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(p.xb + i * 8) = v;
+  }
+}
+
+// ---- canonical f32 weights (n_f, n_in, kd, kh, kw) -> Wb[dz][step][half][rows][8] ----------
+// step = tap2d * KC + kc (kc = pair of channel groups), half = which group of the pair;
+// steps >= T2 * KC are zero.  mode 0 (forward): rows = out channels, k = in channels, taps
+// flipped (true convolution); mode 1 (data gradient): rows = in channels, k = out
+// channels, taps as they are.
+__global__ __launch_bounds__(256) void pack_w_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wb,
+                                                          int nf, int nin, int kd, int T2, int rowsP,
+                                                          int mode, int KGC, int nck, int kgsLast,
+                                                          int FL, int LL) {
+  const int DL = (nck - 1) * FL + LL;            // steps of one kernel plane
+  // (+ kPD zero steps behind the last plane: the ring's prefetches past the end)
+  const long total = ((long)kd * DL + kPD) * 2 * rowsP * 8;
+  const int rows = mode ? nin : nf, kk = mode ? nf : nin;
+  const int T = kd * T2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int j = (int)(i & 7);
+    long r1 = i >> 3;
+    const int r = (int)(r1 % rowsP); r1 /= rowsP;
+    const int half = (int)(r1 & 1);   r1 >>= 1;
+    const int dz = (int)(r1 / DL);
+    const int rem = (int)(r1 - (long)dz * DL);
+    const int c = min(rem / FL, nck - 1);
+    const int step = rem - c * FL;
+    const int KCc = (c == nck - 1 ? kgsLast : KGC) >> 1;
+    float v = 0.f;
+    if (dz < kd && step < T2 * KCc) {
+      const int tap2 = step / KCc, kc = step - tap2 * KCc;
+      const int k = (c * KGC + 2 * kc + half) * 8 + j;
+      if (r < rows && k < kk) {
+        const int oc = mode ? k : r, ic = mode ? r : k;
+        const int tap = dz * T2 + tap2;
+        const int tsrc = mode ? tap : (T - 1 - tap);
+        v = w[((long)oc * nin + ic) * T + tsrc];
+      }
+    }
+    wb[i] = (__bf16)v;
+  }
+}
+
+// ---- the GEMM -----------------------------------------------------------------------
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void conv_bf16_kernel(CbP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int PD = kPD;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c32 = lane & 31, kh8 = lane >> 5;
+
+  // all channel tiles of one (n, z, position tile) unit on ONE XCD (blocks are dealt
+  // round-robin over the 8 XCDs): its input window is fetched into one L2
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int mt = jb % p.nMT;
+  int u = (jb / p.nMT) * 8 + xcd;
+  if (u >= p.N * p.Do * p.nPT) return;
+  const int pt = u % p.nPT; u /= p.nPT;
+  const int z = u % p.Do;
+  const int n = u / p.Do;
+  const int m0 = (mt * 2 + wm) * (32 * MB);
+  const bool idle = m0 >= p.ocP;                // (a wave beyond the padded channels still stages)
+
+  // the work-group's window: one span of pixels per channel group
+  const int Q0 = pt * (64 * NB);
+  const int qlast = min(Q0 + 64 * NB, p.Q) - 1;
+  const int r0 = Q0 / p.Wo, c0 = Q0 - r0 * p.Wo;
+  const int rl = qlast / p.Wo, cl = qlast - rl * p.Wo;
+  const int L = (rl - r0) * p.Win + (cl - c0) + (p.kh - 1) * p.Win + p.kw;     // pixels
+  const long planePix = (long)p.Hin * p.Win;
+  const long span_lo = (long)r0 * p.Win + c0;
+  const int Lpad = p.Lpad;
+  const unsigned bufBytes = (unsigned)p.KGC * Lpad * 16;
+
+  // stage chunk ci = (dz, range of channel groups) of the window into buffer buf: (channel
+  // group, 64-pixel piece) pairs dealt over the 4 waves; LDS-DMA, 16 bytes per lane, lanes
+  // past the span masked
+  const int nJ = (L + 63) >> 6;
+  const int nChunks = p.kd * p.nck;
+  auto stage = [&](int ci, int buf) {
+    const int dz = ci / p.nck, c = ci - dz * p.nck;
+    const int kgs = (c == p.nck - 1) ? p.kgsLast : p.KGC;
+    const __bf16* xp = p.xb + ((((long)n * p.Din + z + dz) * p.KG + c * p.KGC) * planePix + span_lo) * 8;
+    unsigned char* lb = lds + buf * bufBytes;
+    const int pieces = kgs * nJ;
+    for (int i = wave; i < pieces; i += 4) {
+      const int kg = i / nJ, j = i - kg * nJ;
+      const int v = 64 * j + lane;
+      if (v < L)
+        __builtin_amdgcn_global_load_lds((gbl_vp)(xp + ((long)kg * planePix + v) * 8),
+                                         (lds_vp)(lb + ((unsigned)kg * Lpad + 64 * j) * 16), 16, 0, 0);
+    }
+  };
+
+  // per-lane offsets: filter rows (elements inside a step), window pixels (inside a buffer)
+  unsigned aoff[MB], boff[NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+    aoff[mb] = (unsigned)((kh8 * p.ocP + min(m0 + mb * 32 + c32, p.ocP - 1)) * 16);   // bytes
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int q = min(Q0 + (wn * NB + nb) * 32 + c32, p.Q - 1);
+    const int y = q / p.Wo, x = q - y * p.Wo;
+    boff[nb] = (unsigned)(((y - r0) * p.Win + (x - c0)) + kh8 * Lpad) * 16u;
+  }
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  const long stepAb = 2L * p.ocP * 16;          // bytes of one step's filter rows
+  bf16x8 A[PD][MB];
+  // filter-row loads are inline asm: hipcc's wait-count pass drained ALL loads at the loop
+  // header (s_waitcnt vmcnt(0)) whatever the source order, so the ring was never in flight;
+  // the kernel retires them with its own counted waits (cdna guide 5.7 form iii), and keeps
+  // every destination allocated until then (touch).  Scalar base (one 64-bit add per step)
+  // + per-lane byte offset: no per-step vector address arithmetic.  Wb carries PD zero
+  // steps behind the last dz, so the prefetches past the end need no clamp.
+  const char* abase = reinterpret_cast<const char*>(p.wb);
+  auto loadA = [&](bf16x8 (&Ar)[MB]) {
+    const char* sb = reinterpret_cast<const char*>(e2b_uniform(abase));
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(Ar[mb]) : "v"(aoff[mb]), "s"(sb));
+    abase += stepAb;
+  };
+  auto touchA = [&](bf16x8 (&Ar)[MB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) asm volatile("" : "+v"(Ar[mb]));
+  };
+  // the oldest MB loads have landed when at most (PD - 1) * MB are outstanding
+#define E2B_WAIT_OLDEST()                                                        \
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * MB) : "memory");           \
+  __builtin_amdgcn_sched_barrier(0);
+  // the window at a step's tap shift and channel-group pair.  The byte shift advances
+  // incrementally (a few scalar adds / selects per step): decoding (tap, channel pair) from
+  // the step index cost two integer divisions -- more issue slots than a step's MFMAs
+  // leave -- and a shift table costs a scalar-load round trip per step (both measured).
+  // Zero steps past the last real one read the first pixels again (finite values times
+  // zero weights).
+  const unsigned dK = 2u * (unsigned)Lpad * 16u;                 // next channel-group pair
+  const unsigned dY = (unsigned)(p.Win - p.kw) * 16u;            // next tap row
+  unsigned sh = 0, dX = 0;
+  int cK = 0, cX = 0, cS = 0, KCc = 1, realSteps = 0;            // state of the NEXT read
+  auto resetB = [&](int kgs) {
+    KCc = kgs >> 1;
+    realSteps = p.kh * p.kw * KCc;
+    dX = 16u - (unsigned)KCc * dK;                                // next tap in the row
+    sh = 0; cK = 0; cX = 0; cS = 0;
+  };
+  auto readB = [&](unsigned bufb, bf16x8 (&Br)[NB]) {
+    const unsigned a = bufb + (cS < realSteps ? sh : 0u);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      Br[nb] = *reinterpret_cast<const bf16x8*>(lds + a + boff[nb]);
+    ++cS;
+    sh += dK;
+    if (++cK == KCc) {
+      cK = 0; sh += dX;
+      if (++cX == p.kw) { cX = 0; sh += dY; }
+    }
+  };
+  auto fma = [&](const bf16x8 (&Ar)[MB], const bf16x8 (&Br)[NB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ar[mb], Br[nb], acc[mb][nb], 0, 0, 0);
+  };
+
+  stage(0, 0);
+#pragma unroll
+  for (int j = 0; j < PD; ++j) loadA(A[j]);
+  bf16x8 B0[NB], B1[NB];
+  for (int ci = 0; ci < nChunks; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                            // chunk ci landed; the other buffer is free
+    if (ci + 1 < nChunks) stage(ci + 1, (ci + 1) & 1);
+    if (idle) continue;
+    const unsigned bufb = (ci & 1) * bufBytes;
+    const bool lastc = (ci % p.nck) == p.nck - 1;
+    const int nsteps = lastc ? p.LL : p.FL;
+    resetB(lastc ? p.kgsLast : p.KGC);
+    readB(bufb, B0);
+    // (nsteps is a multiple of PD, PD is even: no branch inside; the order below is pinned
+    // -- next step's window read, this step's MFMAs, the filter rows PD steps ahead -- so
+    // that the compiler's waits count the loads in flight instead of draining them)
+    for (int st = 0; st < nsteps; st += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; j += 2) {
+        readB(bufb, B1);
+        __builtin_amdgcn_sched_barrier(0);
+        E2B_WAIT_OLDEST()
+        touchA(A[j]);
+        fma(A[j], B0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(A[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        readB(bufb, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        E2B_WAIT_OLDEST()
+        touchA(A[j + 1]);
+        fma(A[j + 1], B1);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(A[j + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (prefetches past the last step)
+#pragma unroll
+  for (int j = 0; j < PD; ++j) touchA(A[j]);
+#undef E2B_WAIT_OLDEST
+  if (idle) return;
+
+  // ---- epilogue: D[row][col], col = lane % 32 (position), rows 8*(i/4) + 4*(lane/32) + i%4
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int q = Q0 + (wn * NB + nb) * 32 + c32;
+    if (q >= p.Q) continue;
+    const int y = q / p.Wo, x = q - y * p.Wo;
+    float* ob = p.out + (long)n * p.osN + (long)z * p.osZ + (long)y * p.osY + x;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = m0 + mb * 32 + 8 * (i >> 2) + 4 * kh8 + (i & 3);
+        if (co >= p.Cout) continue;
+        float v = acc[mb][nb][i];
+        if (p.bias) {
+          v += p.bias[co];
+          if (p.act == E2_ACT_RELU) v = (v > 0.f) ? v : ((v == 0.f) ? 0.f : -0.f);
+        }
+        ob[(long)co * p.osC] = v;
+      }
+  }
+}
+
+static int view_ok(const e2_tensor5* t, const char* name) {
+  E2_REQUIRE(t && t->ptr, "%s: null tensor", name);
+  E2_REQUIRE(t->n > 0 && t->c > 0 && t->d > 0 && t->h > 0 && t->w > 0,
+             "%s: empty tensor (%d,%d,%d,%d,%d)", name, t->n, t->c, t->d, t->h, t->w);
+  return 0;
+}
+static int pad16(int v) { return (v + 15) / 16 * 16; }
+
+template <int MB, int NB>
+static int launch(e2_ctx* ctx, const CbP& p, int grid, size_t ldsb) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<MB, NB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_bf16_kernel<MB, NB>), dim3(grid), dim3(256), ldsb, ctx->stream, p);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// upper bound of the window span (pixels) of a tile of BN positions
+static int span_pixels(int BN, int Wo, int Win, int kh, int kw) {
+  const int rows = (BN - 1 + Wo - 1) / Wo + 1;                 // image rows a tile can touch
+  return (BN - 1) + rows * (Win - Wo) + (kh - 1) * Win + kw;
+}
+
+// in: input view (forward: x; data gradient: the zero-padded dy); rows = output channels of
+// the GEMM (forward: n_f; data gradient: n_in), kk = its reduction channels
+static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, int nin, int kd,
+                     int kh, int kw, int mode, const float* bias, int act, const e2_tensor5* out,
+                     void* ws, size_t ws_bytes, int MB, int NB) {
+  const int rows = mode ? nin : nf, kk = mode ? nf : nin;
+  E2_REQUIRE(in->c == kk && out->c == rows, "conv_bf16: channel mismatch");
+  E2_REQUIRE(out->n == in->n && out->d == in->d - kd + 1 && out->h == in->h - kh + 1 &&
+                 out->w == in->w - kw + 1, "conv_bf16: out shape does not match in - k + 1");
+  const int Cp = pad16(kk), KG = Cp / 8;
+  const int ocP = (rows + 32 * MB - 1) / (32 * MB) * (32 * MB);   // whole wave tiles
+  const int T2 = kh * kw;
+  const int Lpad = (span_pixels(64 * NB, out->w, in->w, kh, kw) + 3) / 4 * 4;
+  // channel groups per LDS chunk: two buffers within ~72 KB, so that two work-groups share
+  // a CU; an even count, as equal as possible over the chunks
+  int KGC = (int)std::min<long>(KG, (36 * 1024) / ((long)Lpad * 16) / 2 * 2);
+  E2_REQUIRE(KGC >= 2, "conv_bf16: the window of one channel-group pair (%d pixels) does not fit LDS", Lpad);
+  int nck = (KG + KGC - 1) / KGC;
+  KGC = ((KG / 2 + nck - 1) / nck) * 2;         // balance the chunks
+  nck = (KG + KGC - 1) / KGC;
+  const int kgsLast = KG - (nck - 1) * KGC;
+  const int FL = (T2 * (KGC / 2) + kPD - 1) / kPD * kPD;
+  const int LL = (T2 * (kgsLast / 2) + kPD - 1) / kPD * kPD;
+  const int DL = (nck - 1) * FL + LL;
+  const size_t bufBytes = (size_t)KGC * Lpad * 16;
+  const size_t ldsb = (kd * nck > 1 ? 2 : 1) * bufBytes;
+  E2_REQUIRE(ldsb <= 160 * 1024, "conv_bf16: LDS window of %zu B", ldsb);
+  const size_t xb_bytes = (size_t)in->n * in->d * in->h * in->w * Cp * 2;
+  const size_t wb_bytes = ((size_t)kd * DL + kPD) * 2 * ocP * 8 * 2;
+  const size_t need = ((xb_bytes + 255) / 256) * 256 + wb_bytes + 256;
+  E2_REQUIRE(ws && ws_bytes >= need, "conv_bf16: workspace of %zu bytes needed, %zu given", need, ws_bytes);
+  E2_REQUIRE(((uintptr_t)ws & 15) == 0, "conv_bf16: workspace must be 16-byte aligned");
+  E2_REQUIRE((long)ocP * 32 < (1L << 31), "conv_bf16: too many channels");
+  __bf16* xb = reinterpret_cast<__bf16*>(ws);
+  __bf16* wb = reinterpret_cast<__bf16*>((char*)ws + ((xb_bytes + 255) / 256) * 256);
+  CvP c{in->ptr, in->sn, in->sc, in->sd, in->sh, in->n, in->c, in->d, in->h, in->w, KG, xb};
+  const long ctot = (long)in->n * in->d * in->h * KG * in->w;
+  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)std::min<long>((ctot + 255) / 256, 8192)),
+                     dim3(256), 0, ctx->stream, c);
+  const long wtot = ((long)kd * DL + kPD) * 2 * ocP * 8;
+  hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((unsigned)std::min<long>((wtot + 255) / 256, 2048)),
+                     dim3(256), 0, ctx->stream, w, wb, nf, nin, kd, T2, ocP, mode, KGC, nck, kgsLast,
+                     FL, LL);
+  CbP p;
+  p.xb = xb; p.wb = wb; p.out = out->ptr;
+  p.osN = out->sn; p.osC = out->sc; p.osZ = out->sd; p.osY = out->sh;
+  p.bias = bias; p.act = act;
+  p.N = in->n; p.Cout = rows; p.KG = KG; p.ocP = ocP;
+  p.kd = kd; p.kh = kh; p.kw = kw;
+  p.Do = out->d; p.Ho = out->h; p.Wo = out->w; p.Q = out->h * out->w;
+  p.Din = in->d; p.Hin = in->h; p.Win = in->w;
+  p.nPT = (p.Q + 64 * NB - 1) / (64 * NB);
+  p.nMT = (ocP + 64 * MB - 1) / (64 * MB);
+  p.Lpad = Lpad; p.KGC = KGC; p.nck = nck; p.kgsLast = kgsLast; p.FL = FL; p.LL = LL;
+  const long units = (long)p.N * p.Do * p.nPT;
+  const long grid = (units + 7) / 8 * 8 * p.nMT;
+  E2_REQUIRE(grid < (1L << 31), "conv_bf16: grid too large");
+  if (MB == 1 && NB == 1) return launch<1, 1>(ctx, p, (int)grid, ldsb);
+  if (MB == 1 && NB == 2) return launch<1, 2>(ctx, p, (int)grid, ldsb);
+  if (MB == 2 && NB == 1) return launch<2, 1>(ctx, p, (int)grid, ldsb);
+  if (MB == 2 && NB == 2) return launch<2, 2>(ctx, p, (int)grid, ldsb);
+  if (MB == 4 && NB == 1) return launch<4, 1>(ctx, p, (int)grid, ldsb);
+  if (MB == 4 && NB == 2) return launch<4, 2>(ctx, p, (int)grid, ldsb);
+  if (MB == 2 && NB == 4) return launch<2, 4>(ctx, p, (int)grid, ldsb);
+  if (MB == 1 && NB == 4) return launch<1, 4>(ctx, p, (int)grid, ldsb);
+  e2_set_error("conv_bf16: no instance MB=%d NB=%d", MB, NB);
+  return 2;
+}
+
+static void tile_from_ctx(const e2_ctx* ctx, int* MB, int* NB) {
+  *MB = 2; *NB = 2;
+  int v[3];
+  if (sscanf(ctx->tiling[E2_TILING_IGEMM], "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] == 32) {
+    *MB = v[1]; *NB = v[2];
+  }
+}
+
+}  // namespace
+
+extern "C" size_t e2_conv3d_bf16_workspace_bytes(int n, int cin, int d, int h, int w, int cout,
+                                                 int kd, int kh, int kw) {
+  // both directions: the forward converts x (cin channels), the data gradient the padded dy
+  const int cpF = pad16(cin), cpD = pad16(cout);
+  const size_t xF = (size_t)n * d * h * w * cpF * 2;
+  const size_t xD = (size_t)n * (d + kd - 1) * (h + kh - 1) * (w + kw - 1) * cpD * 2;  // (bound)
+  // (steps of one plane: kh*kw per channel-group pair, + the ring padding of every chunk)
+  const size_t sF = (size_t)(kh * kw + kPD) * (cpF / 16) + kPD, sD = (size_t)(kh * kw + kPD) * (cpD / 16) + kPD;
+  const size_t wF = ((size_t)kd * sF + kPD) * 2 * ((cout + 127) / 128 * 128) * 16;   // (any MB)
+  const size_t wD = ((size_t)kd * sD + kPD) * 2 * ((cin + 127) / 128 * 128) * 16;
+  return std::max(xF, xD) + std::max(wF, wD) + 2048;
+}
+
+extern "C" int e2_conv3d_fwd_bf16(e2_ctx* ctx, const e2_tensor5* x, const float* w, int cout,
+                                  int kd, int kh, int kw, const float* bias, int act,
+                                  const e2_tensor5* out, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && w, "conv3d_fwd_bf16: null argument");
+  if (int rc = view_ok(x, "conv3d_fwd_bf16 x")) return rc;
+  if (int rc = view_ok(out, "conv3d_fwd_bf16 out")) return rc;
+  E2_REQUIRE(!bias || act == E2_ACT_LIN || act == E2_ACT_RELU, "conv3d_fwd_bf16: bad act %d", act);
+  int MB, NB;
+  tile_from_ctx(ctx, &MB, &NB);
+  return conv_bf16(ctx, x, w, cout, x->c, kd, kh, kw, 0, bias, act, out, ws, ws_bytes, MB, NB);
+}
+
+extern "C" int e2_conv3d_dgrad_bf16(e2_ctx* ctx, const e2_tensor5* dy_pad, const float* w, int cin,
+                                    int kd, int kh, int kw, const e2_tensor5* dx, void* ws,
+                                    size_t ws_bytes) {
+  E2_REQUIRE(ctx && w, "conv3d_dgrad_bf16: null argument");
+  if (int rc = view_ok(dy_pad, "conv3d_dgrad_bf16 dy_pad")) return rc;
+  if (int rc = view_ok(dx, "conv3d_dgrad_bf16 dx")) return rc;
+  int MB, NB;
+  tile_from_ctx(ctx, &MB, &NB);
+  return conv_bf16(ctx, dy_pad, w, dy_pad->c, cin, kd, kh, kw, 1, nullptr, 0, dx, ws, ws_bytes, MB, NB);
+}

@@ -427,19 +427,30 @@ class Conv(NeuralLayer):
             out = plan.out[self]
             sig = (2, self.n_f, cin) + tuple(self._k3) + tuple(out.shape[2:]) + \
                 (x.stride(3),)
+            def fwd_act():
+                if ctx.bf16_memory_form():
+                    ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), out,
+                                        bias=plan.param(self.b), act=self.activation_func,
+                                        ws=plan.bf16_ws(self))
+                else:
+                    ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self._k3, plan.param(self.b),
+                                              self.activation_func, out)
             plan.tuned('igemm', sig,
                        autotune.igemm_candidates(self.n_f, cin, self._k3,
-                                                 out.shape[2:], split_k=False),
-                       lambda: ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self._k3,
-                                                         plan.param(self.b),
-                                                         self.activation_func, out))
+                                                 out.shape[2:], split_k=False) +
+                       plan.bf16_cands(cin), fwd_act)
             return
         y = plan.scratch[self, 'y']
         sig = (0, self.n_f, cin) + tuple(self._k3) + tuple(y.shape[2:]) + \
             (x.stride(3),)
+        def fwd_plain():
+            if ctx.bf16_memory_form():
+                ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), y, ws=plan.bf16_ws(self))
+            else:
+                ctx.conv3d_fwd_packed(x, wp, self.n_f, self._k3, y)
         plan.tuned('igemm', sig,
-                   autotune.igemm_candidates(self.n_f, cin, self._k3, y.shape[2:]),
-                   lambda: ctx.conv3d_fwd_packed(x, wp, self.n_f, self._k3, y), out=y)
+                   autotune.igemm_candidates(self.n_f, cin, self._k3, y.shape[2:]) +
+                   plan.bf16_cands(cin), fwd_plain, out=y)
         if self._bn():
             lin = y
             if any(p != 1 for p in self._p3):
@@ -545,11 +556,15 @@ class Conv(NeuralLayer):
             out = dst if first else plan.tmp_like(dst)
             sig = (1, cin, self.n_f) + tuple(self._k3) + tuple(out.shape[2:]) + \
                 (dyp.stride(3),)
+            def dgrad():
+                if ctx.bf16_memory_form():
+                    ctx.conv3d_dgrad_bf16(dyp, self._w5(plan.param(self.w)), out,
+                                          ws=plan.bf16_ws(self))
+                else:
+                    ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out)
             plan.tuned('igemm', sig,
-                       autotune.igemm_candidates(cin, self.n_f, self._k3,
-                                                 out.shape[2:]),
-                       lambda: ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out),
-                       out=out)
+                       autotune.igemm_candidates(cin, self.n_f, self._k3, out.shape[2:]) +
+                       plan.bf16_cands(self.n_f), dgrad, out=out)
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
 

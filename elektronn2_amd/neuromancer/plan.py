@@ -148,6 +148,26 @@ class Plan(object):
     def param(self, p):
         return self.model.device_param(p)
 
+    # ---- bf16 mode: the kernel with bf16 operands in memory (csrc/conv_bf16.hip) ----------
+    def bf16_cands(self, k_channels):
+        """extra tuner candidates of a conv launch in bf16 mode"""
+        from .. import autotune
+        if getattr(self.ctx, 'mfma_dtype', 'f32') != 'bf16':
+            return []
+        return autotune.bf16_memory_candidates(k_channels)
+
+    def bf16_ws(self, node):
+        """ONE scratch buffer for the bf16 planes / filter rows of every conv of the plan (the
+        launches are ordered on one stream), sized for the largest layer"""
+        need = self.ctx.conv_bf16_ws_bytes(self.out_shape(node.parent), node.n_f, node._k3)
+        ws = self.scratch.get('bf16_ws')
+        if ws is None or ws.numel() < need:
+            if self._capturing:
+                raise RuntimeError("bf16 workspace must exist before capture")
+            ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+            self.scratch['bf16_ws'] = ws
+        return ws
+
     @staticmethod
     def _w5(w):
         """conv weights as (n_f, n_in, kz, kx, ky): 2-D layers get a unit z axis"""

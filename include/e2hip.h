@@ -361,6 +361,27 @@ int e2_stream_synchronize(e2_ctx*);
 int e2_stream_fork(e2_ctx*, void* side_stream);
 int e2_stream_join(e2_ctx*, void* side_stream);
 
+/* ---- conv forward / data gradient with bf16 operands in memory ----------
+ * Same arithmetic as E2_MFMA_BF16 (operands rounded to bf16, nearest even; f32 products and
+ * sums; f32 tensors in and out) on a kernel built for v_mfma_f32_32x32x16_bf16: the call
+ * converts its input to bf16 planes of 16-byte pixels (8 channels each) and the canonical
+ * weights w (n_f, n_in, kd, kh, kw) to bf16 filter rows in the caller's workspace
+ * (e2_conv3d_bf16_workspace_bytes for the layer: covers both directions); the GEMM stages a
+ * work-group's input window in LDS once per kernel plane (LDS-DMA) and reads every tap from
+ * it at a shifted pixel, filter rows come from L2.  fwd: optional fused bias + activation
+ * (bias NULL: plain conv), out any strided view.  dgrad: dy_pad zero-padded as for
+ * e2_conv3d_dgrad.  All reduction channels of one kernel plane must fit LDS (an error says
+ * so; the operand-rounding form of E2_MFMA_BF16 has no such limit).  Tiling:
+ * e2_set_tiling(E2_TILING_IGEMM, "32,MB,NB") = MB x NB blocks of 32 channels x 32 positions
+ * per wave (default 2 x 2).  No reference counterpart (the reference is f32). */
+size_t e2_conv3d_bf16_workspace_bytes(int n, int cin, int d, int h, int w, int cout, int kd,
+                                      int kh, int kw);
+int e2_conv3d_fwd_bf16(e2_ctx*, const e2_tensor5* x, const float* w, int cout, int kd, int kh,
+                       int kw, const float* bias, int act, const e2_tensor5* out, void* ws,
+                       size_t ws_bytes);
+int e2_conv3d_dgrad_bf16(e2_ctx*, const e2_tensor5* dy_pad, const float* w, int cin, int kd,
+                         int kh, int kw, const e2_tensor5* dx, void* ws, size_t ws_bytes);
+
 /* ---- BASELINE config 1 (examples/mnist.py:29-56): Perceptron and batch normalisation ----
  * Correctness-first kernels for the reference's CPU-runnable plumbing case.
  *

@@ -156,3 +156,54 @@ def test_training_step_bf16_close_to_f32_oracle(process_bf16):
         assert cos > 0.995, cos
     losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(30)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("tile", [None, "32,1,1", "32,1,2", "32,2,1", "32,4,1", "32,4,2", "32,2,4", "32,1,4"])
+@pytest.mark.parametrize("case", [(20, 40, (3, 3, 3), (2, 5, 14, 19)), (150, 200, (1, 3, 3), (1, 2, 11, 12)),
+                                  (40, 150, (2, 4, 4), (1, 3, 12, 13)), (200, 70, (1, 1, 1), (2, 2, 9, 10)),
+                                  (33, 17, (1, 5, 2), (1, 1, 9, 70))])
+def test_conv_with_bf16_operands_in_memory(ctx, case, tile):
+    """csrc/conv_bf16.hip (e2_conv3d_fwd_bf16 / e2_conv3d_dgrad_bf16): bf16 planes of 16-byte
+    pixels, input windows staged in LDS once per kernel plane, filter rows from L2, 32x32x16
+    MFMA.  Same bounds as the operand-rounding form: 2e-5 against the f64 oracle on
+    bf16-rounded operands; fused bias + relu with signed zeros; strided output view (the
+    interior of a padded buffer); every wave tile; kd = 1 / 2 / 3 (single and double
+    buffered windows), ragged channel counts, step counts that need zero padding."""
+    Ci, Co, k, (N, D, H, W) = case
+    rng = np.random.RandomState(Ci + Co)
+    x = rng.rand(N, Ci, D, H, W).astype(np.float32)
+    w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k))).astype(np.float32)
+    b = (rng.randn(Co) * 0.1).astype(np.float32)
+    xr, wr = bf16_round(x), bf16_round(w)
+    y_ref = O.conv3d_fwd(xr, wr)
+    ctx.set_tiling("igemm", tile)
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device="cuda")
+        ctx.conv3d_fwd_bf16(dev(x), dev(w), y)
+        assert relerr(y, y_ref) < TOL
+        e = relerr(y, O.conv3d_fwd(x, w))
+        assert 1e-4 < e < 2e-2, e                       # bf16 really ran
+        # fused bias + relu into a strided view
+        big = torch.zeros((N, Co, y_ref.shape[2] + 1, y_ref.shape[3] + 2, y_ref.shape[4] + 3), device="cuda")
+        yv = big[:, :, 1:, 1:-1, 2:-1]
+        ctx.conv3d_fwd_bf16(dev(x), dev(w), yv, bias=dev(b), act='relu')
+        pre = y_ref + b.reshape(1, -1, 1, 1, 1)
+        assert relerr(yv, np.maximum(pre, 0)) < TOL
+        neg = torch.signbit(yv).cpu().numpy()
+        assert neg[pre < -1e-5].all() and not neg[pre > 1e-5].any()
+        # data gradient on the zero-padded gradient buffer
+        dy = rng.randn(*y_ref.shape).astype(np.float32)
+        osp = y_ref.shape[2:]
+        pshape = (N, Co) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+        dyp = torch.zeros(pshape, device="cuda")
+        dyp[:, :, k[0] - 1:k[0] - 1 + osp[0], k[1] - 1:k[1] - 1 + osp[1],
+            k[2] - 1:k[2] - 1 + osp[2]] = dev(dy)
+        dx = torch.full(x.shape, float("nan"), device="cuda")
+        try:
+            ctx.conv3d_dgrad_bf16(dyp, dev(w), dx)
+        except Exception as err:      # the widest tile x most channels: refused, never wrong
+            assert "does not fit LDS" in str(err) and tile in ("32,2,4", "32,1,4") and Co >= 150
+            return
+        assert relerr(dx, O.conv3d_dgrad(bf16_round(dy), wr, x.shape)) < TOL
+    finally:
+        ctx.set_tiling("igemm", None)
