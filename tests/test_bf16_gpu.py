@@ -181,6 +181,13 @@ def test_conv_with_bf16_operands_in_memory(ctx, case, tile):
         y = torch.full(y_ref.shape, float("nan"), device="cuda")
         ctx.conv3d_fwd_bf16(dev(x), dev(w), y)
         assert relerr(y, y_ref) < TOL
+        # a strided input view (a crop of a larger buffer, channel slice of a concat buffer)
+        host = torch.full((N, Ci + 3, D + 1, H + 2, W + 5), float("nan"), device="cuda")
+        xv = host[:, 2:2 + Ci, 1:, 1:-1, 3:-2]
+        xv.copy_(dev(x))
+        y.fill_(float("nan"))
+        ctx.conv3d_fwd_bf16(xv, dev(w), y)
+        assert relerr(y, y_ref) < TOL
         e = relerr(y, O.conv3d_fwd(x, w))
         assert 1e-4 < e < 2e-2, e                       # bf16 really ran
         # fused bias + relu into a strided view
