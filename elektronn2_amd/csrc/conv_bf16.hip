@@ -70,9 +70,9 @@ struct CvP {
   __bf16* xb;
 };
 // thread = (channel group, pixel): 8 coalesced row reads, one 16-byte store
-__global__ __launch_bounds__(256) void cvt_bf16_kernel(CvP p) {
+__device__ __forceinline__ void cvt_bf16_part(const CvP& p, int blk, int nblk) {
   const long total = (long)p.N * p.D * p.KG * p.H * p.W;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = blk * 256L + threadIdx.x; i < total; i += (long)nblk * 256) {
     const int x = (int)(i % p.W);
     long r = i / p.W;
     const int y = (int)(r % p.H);   r /= p.H;
@@ -95,16 +95,22 @@ __global__ __launch_bounds__(256) void cvt_bf16_kernel(CvP p) {
 // steps >= T2 * KC are zero.  mode 0 (forward): rows = out channels, k = in channels, taps
 // flipped (true convolution); mode 1 (data gradient): rows = in channels, k = out
 // channels, taps as they are.
-__global__ __launch_bounds__(256) void pack_w_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wb,
-                                                          int nf, int nin, int kd, int T2, int rowsP,
-                                                          int mode, int KGC, int nck, int kgsLast,
-                                                          int FL, int LL) {
+struct PwP {
+  const float* w;
+  __bf16* wb;
+  int nf, nin, kd, T2, rowsP, mode, KGC, nck, kgsLast, FL, LL;
+};
+__device__ __forceinline__ void pack_w_bf16_part(const PwP& q, int blk, int nblk) {
+  const float* __restrict__ w = q.w;
+  __bf16* __restrict__ wb = q.wb;
+  const int nf = q.nf, nin = q.nin, kd = q.kd, T2 = q.T2, rowsP = q.rowsP, mode = q.mode;
+  const int KGC = q.KGC, nck = q.nck, kgsLast = q.kgsLast, FL = q.FL, LL = q.LL;
   const int DL = (nck - 1) * FL + LL;            // steps of one kernel plane
   // (+ kPD zero steps behind the last plane: the ring's prefetches past the end)
   const long total = ((long)kd * DL + kPD) * 2 * rowsP * 8;
   const int rows = mode ? nin : nf, kk = mode ? nf : nin;
   const int T = kd * T2;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = blk * 256L + threadIdx.x; i < total; i += (long)nblk * 256) {
     const int j = (int)(i & 7);
     long r1 = i >> 3;
     const int r = (int)(r1 % rowsP); r1 /= rowsP;
@@ -127,6 +133,12 @@ __global__ __launch_bounds__(256) void pack_w_bf16_kernel(const float* __restric
     }
     wb[i] = (__bf16)v;
   }
+}
+
+// both conversion passes in ONE launch (they are tiny; a launch apiece cost more than the work)
+__global__ __launch_bounds__(256) void prep_bf16_kernel(CvP c, PwP q, int cblocks) {
+  if ((int)blockIdx.x < cblocks) cvt_bf16_part(c, blockIdx.x, cblocks);
+  else pack_w_bf16_part(q, blockIdx.x - cblocks, gridDim.x - cblocks);
 }
 
 // ---- the GEMM -----------------------------------------------------------------------
@@ -394,12 +406,12 @@ static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, 
   __bf16* wb = reinterpret_cast<__bf16*>((char*)ws + ((xb_bytes + 255) / 256) * 256);
   CvP c{in->ptr, in->sn, in->sc, in->sd, in->sh, in->n, in->c, in->d, in->h, in->w, KG, xb};
   const long ctot = (long)in->n * in->d * in->h * KG * in->w;
-  hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)std::min<long>((ctot + 255) / 256, 8192)),
-                     dim3(256), 0, ctx->stream, c);
   const long wtot = ((long)kd * DL + kPD) * 2 * ocP * 8;
-  hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((unsigned)std::min<long>((wtot + 255) / 256, 2048)),
-                     dim3(256), 0, ctx->stream, w, wb, nf, nin, kd, T2, ocP, mode, KGC, nck, kgsLast,
-                     FL, LL);
+  const int cblocks = (int)std::min<long>((ctot + 255) / 256, 8192);
+  const int wblocks = (int)std::min<long>((wtot + 255) / 256, 2048);
+  PwP q{w, wb, nf, nin, kd, T2, ocP, mode, KGC, nck, kgsLast, FL, LL};
+  hipLaunchKernelGGL(prep_bf16_kernel, dim3((unsigned)(cblocks + wblocks)), dim3(256), 0, ctx->stream,
+                     c, q, cblocks);
   CbP p;
   p.xb = xb; p.wb = wb; p.out = out->ptr;
   p.osN = out->sn; p.osC = out->sc; p.osZ = out->sd; p.osY = out->sh;
