@@ -465,6 +465,7 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
       const int nMT = e2_cdiv(mblocks, MT);
       for (int NT = 1; NT <= 4; NT *= 2) {
         if (16 * NT * 4 > 16 * nblocks && NT > 1) continue;
+        if (NT == 4 && MT * 4 >= 20) continue;      // no such instance (it would spill)
         const int nNT = e2_cdiv(nblocks, NT * 4);
         for (int BP = ctx->mfma_bf16 ? 256 : 128; BP <= 256; BP *= 2) {   // bf16 form: BP 256 only
           if (BP == 256 && S <= 128 && !ctx->mfma_bf16) continue;

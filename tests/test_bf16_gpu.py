@@ -214,3 +214,4 @@ def test_conv_with_bf16_operands_in_memory(ctx, case, tile):
         assert relerr(dx, O.conv3d_dgrad(bf16_round(dy), wr, x.shape)) < TOL
     finally:
         ctx.set_tiling("igemm", None)
+

@@ -285,6 +285,26 @@ def test_conv3d_1x1_forced_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
+@pytest.mark.parametrize("ci,co,k", [(200, 200, (1, 3, 3)), (150, 200, (1, 3, 3)), (40, 150, (2, 4, 4)),
+                                     (100, 100, (3, 4, 4)), (80, 100, (3, 4, 4))])
+def test_wgrad_pad_with_the_librarys_own_tiling(ctx, ci, co, k):
+    """no tiling forced, nothing tuned: the cost model must only pick tilings that have an
+    instance (it once chose 5..7 x 4 blocks, whose spilling instances had been removed)"""
+    rng = np.random.RandomState(ci)
+    x = rng.rand(1, ci, 3, 12, 14).astype(np.float32)
+    osp = tuple(s - kk + 1 for s, kk in zip((3, 12, 14), k))
+    dy = rng.randn(1, co, *osp).astype(np.float32)
+    dw_ref = O.conv3d_wgrad(dy, x, (co, ci) + tuple(k))
+    pad = [kk - 1 for kk in k]
+    pshape = (1, co) + tuple(osp[i] + 2 * pad[i] for i in range(3))
+    flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
+    dyp = flat[:int(np.prod(pshape))].view(pshape)
+    dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
+    dw = torch.full(dw_ref.shape, float("nan"), device="cuda")
+    ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
+    assert relerr(dw, dw_ref) < TOL
+
+
 @pytest.mark.parametrize("force", ["1,1,1,128,3", "2,2,1,256,5", "3,4,1,128,2", "4,1,1,256,7",
                                    "5,2,1,128,1", "7,2,1,128,3", "7,2,1,256,2", "7,1,1,128,40",
                                    "7,2,101,128,8", "2,2,101,256,2", "3,2,114,128,8", "1,1,101,128,8",
