@@ -698,3 +698,48 @@ def test_fill_multi_and_skip_zero_fill(ctx):
         assert relerr(y, ref) < TOL
     finally:
         ctx.set_tiling("igemm", None)
+
+
+def _random_conv_problems(n, seed):
+    rng = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        ci = int(rng.choice([1, 2, 3, 5, 8, 17, 20, 31, 40, 64, 100, 150, 200, 257]))
+        co = int(rng.choice([1, 2, 4, 7, 16, 20, 33, 40, 80, 150, 200, 208, 259]))
+        k = tuple(int(v) for v in rng.choice([1, 2, 3, 4, 5], 3))
+        sp = tuple(int(k[i] + rng.randint(0, 9 if i else 3)) for i in range(3))
+        nb = int(rng.choice([1, 1, 2, 3]))
+        if ci * co * np.prod(k) * np.prod(sp) * nb > 3e8:
+            continue
+        out.append((nb, ci, co, k, sp))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_conv_problems(24, 2026), ids=lambda c: "n%d_%d-%d_k%dx%dx%d_s%dx%dx%d" % (
+    (c[0], c[1], c[2]) + c[3] + c[4]))
+def test_conv3d_random_shapes_with_the_librarys_own_tilings(ctx, case):
+    """drop-in means any shape a caller brings: odd channel counts (1 .. 259), every kernel
+    extent 1 .. 5 (specialised and generic tap rows), outputs as small as one voxel, batch
+    1 .. 3 -- forward, data gradient and the padded-buffer weight gradient with NO tiling
+    forced and nothing tuned, against the f64 oracle"""
+    N, Ci, Co, k, sp = case
+    rng = np.random.RandomState(Ci * 7 + Co)
+    x = rng.rand(N, Ci, *sp).astype(np.float32)
+    w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k))).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    y = torch.full(y_ref.shape, float("nan"), device="cuda")
+    ctx.conv3d_fwd(dev(x), dev(w), y)
+    assert relerr(y, y_ref) < TOL
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    osp = y_ref.shape[2:]
+    pad = [kk - 1 for kk in k]
+    pshape = (N, Co) + tuple(osp[i] + 2 * pad[i] for i in range(3))
+    flat = torch.zeros(int(np.prod(pshape)) + 32, device="cuda")
+    dyp = flat[:int(np.prod(pshape))].view(pshape)
+    dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
+    dx = torch.full(x.shape, float("nan"), device="cuda")
+    ctx.conv3d_dgrad(dyp, dev(w), dx)
+    assert relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < TOL
+    dw = torch.full(w.shape, float("nan"), device="cuda")
+    ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
+    assert relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < TOL
