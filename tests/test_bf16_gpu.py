@@ -215,3 +215,4 @@ def test_conv_with_bf16_operands_in_memory(ctx, case, tile):
     finally:
         ctx.set_tiling("igemm", None)
 
+
