@@ -93,6 +93,18 @@ def bf16_memory_candidates(cin):
     return list(BF16_MEMORY_TILES) if cin >= 16 else []
 
 
+def bf16_wgrad_candidates(cin, k):
+    """"32,MB,NB,0,S": the weight-gradient kernel with bf16 operands in memory
+    (csrc/wgrad_bf16.hip): MB x NB blocks of 32 out channels x (32 input channels of one
+    tap) per wave, NB taps of one kernel row, S position splits (0: one work-group per CU;
+    multiples of 8 run XCD-grouped).  A work-group spans 128 input channels: not offered
+    when three quarters of that would be padding."""
+    if cin < 24:
+        return []
+    nbs = sorted({min(k[2], n) for n in (1, 2, 3, 4)})
+    return ["32,%d,%d,0,%d" % (mb, nb, s) for mb in (1, 2) for nb in nbs for s in (0, 8, 16)]
+
+
 def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     mblocks = -(-cout // 16)
     q = out_sp[1] * out_sp[2]

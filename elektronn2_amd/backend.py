@@ -106,6 +106,8 @@ def _load():
         "e2_conv3d_bf16_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
         "e2_conv3d_fwd_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, fp, i, P5, vp, sz]),
         "e2_conv3d_dgrad_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz]),
+        "e2_conv3d_wgrad_bf16_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
+        "e2_conv3d_wgrad_bf16": (C.c_int, [vp, P5, P5, fp, i, i, i, i, vp, sz]),
         "e2_dense_fwd": (C.c_int, [vp, fp, fp, fp, i, i, i]),
         "e2_dense_dgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
         "e2_dense_wgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
@@ -474,6 +476,23 @@ class Context:
         _chk(_lib.e2_conv3d_dgrad_bf16(self.h, C.byref(t5(dy_pad)), _fp(w), cin, kd, kh, kw,
                                        C.byref(t5(dx)), C.c_void_p(ws.data_ptr()),
                                        ws.numel() * ws.element_size()), "e2_conv3d_dgrad_bf16")
+
+    @staticmethod
+    def wgrad_bf16_ws_bytes(x_shape, cout, k):
+        n, cin, d, h, w = (int(v) for v in x_shape)
+        return int(_lib.e2_conv3d_wgrad_bf16_workspace_bytes(n, cin, d, h, w, int(cout), k[0], k[1], k[2]))
+
+    def conv3d_wgrad_bf16(self, x, dy, dw, accumulate=False, ws=None):
+        """dw (n_f, n_in, kd, kh, kw) from x and the UNPADDED gradient view dy"""
+        cout, cin, kd, kh, kw = dw.shape
+        if ws is None:
+            ws = self.workspace("wgrad_bf16", self.wgrad_bf16_ws_bytes(x.shape, cout, (kd, kh, kw)))
+        _chk(_lib.e2_conv3d_wgrad_bf16(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw), kd, kh, kw,
+                                       int(accumulate), C.c_void_p(ws.data_ptr()),
+                                       ws.numel() * ws.element_size()), "e2_conv3d_wgrad_bf16")
+
+    def bf16_memory_wgrad(self):
+        return getattr(self, '_tiling', {}).get('wgrad', '').startswith('32,')
 
     # ---- config 1 (mnist): Perceptron dot product, batch normalisation ------------------
     def dense_fwd(self, x, w, y):

@@ -517,12 +517,19 @@ class Conv(NeuralLayer):
         dyp = plan.scratch[self, 'dy_pad']
         sigw = (self.n_f, cin) + tuple(self._k3) + tuple(dy.shape[2:]) + \
             (x.stride(3), dy.stride(3))
+        wcands = plan.bf16_wgrad_cands(cin, self._k3)
+        wws = plan.bf16_wgrad_ws(self) if wcands else None
+
+        def wgrad(accumulate):
+            if ctx.bf16_memory_wgrad():     # "32,MB,NB,0,S": bf16 operands in memory
+                ctx.conv3d_wgrad_bf16(x, dy, dw, accumulate=accumulate, ws=wws)
+            else:
+                ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=accumulate)
         # the weight gradient is independent of the data-gradient chain below: side stream
         plan.on_side(lambda: plan.tuned(
             'wgrad', sigw,
-            autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]),
-            lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=True),
-            fn_tune=lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=False)))
+            autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]) + wcands,
+            lambda: wgrad(True), fn_tune=lambda: wgrad(False)))
         if plan.needs_grad(self.parent):
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

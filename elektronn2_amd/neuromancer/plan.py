@@ -156,6 +156,26 @@ class Plan(object):
             return []
         return autotune.bf16_memory_candidates(k_channels)
 
+    def bf16_wgrad_cands(self, cin, k):
+        """extra tuner candidates of a weight-gradient launch in bf16 mode"""
+        from .. import autotune
+        if getattr(self.ctx, 'mfma_dtype', 'f32') != 'bf16':
+            return []
+        return autotune.bf16_wgrad_candidates(cin, k)
+
+    def bf16_wgrad_ws(self, node):
+        """the scratch of csrc/wgrad_bf16.hip (bf16 copies of x and dy, the f32 sums): its own
+        buffer, because the weight gradient runs on the side stream next to the data
+        gradient that uses ``bf16_ws``; one for the plan, sized for the largest layer"""
+        need = self.ctx.wgrad_bf16_ws_bytes(self.out_shape(node.parent), node.n_f, node._k3)
+        ws = self.scratch.get('bf16_wgrad_ws')
+        if ws is None or ws.numel() < need:
+            if self._capturing:
+                raise RuntimeError("bf16 weight-gradient workspace must exist before capture")
+            ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
+            self.scratch['bf16_wgrad_ws'] = ws
+        return ws
+
     def bf16_ws(self, node):
         """ONE scratch buffer for the bf16 planes / filter rows of every conv of the plan (the
         launches are ordered on one stream), sized for the largest layer"""

@@ -381,6 +381,18 @@ int e2_conv3d_fwd_bf16(e2_ctx*, const e2_tensor5* x, const float* w, int cout, i
                        size_t ws_bytes);
 int e2_conv3d_dgrad_bf16(e2_ctx*, const e2_tensor5* dy_pad, const float* w, int cin, int kd,
                          int kh, int kw, const e2_tensor5* dx, void* ws, size_t ws_bytes);
+/* The weight gradient in the same arithmetic (operands rounded to bf16, f32 sums), K = the
+ * positions: dy (the UNPADDED gradient view, any strides) is converted to bf16 channel-major
+ * planes at the input's row pitch, x to bf16 channels-last pixels, both staged in LDS per
+ * 64 positions; dy rows are read with ds_read_b128, the shifted input windows with the
+ * transposed LDS read ds_read_b64_tr_b16; the tile is flushed into dw with f32 atomics
+ * (accumulate 0: dw is zeroed first).  Tiling: e2_set_tiling(E2_TILING_WGRAD,
+ * "32,MB,NB,0,S"): MB (1..2) blocks of 32 out channels x NB (1..4) taps of a kernel row per
+ * wave, S position splits (0 = one work-group per CU). */
+size_t e2_conv3d_wgrad_bf16_workspace_bytes(int n, int cin, int d, int h, int w, int cout,
+                                            int kd, int kh, int kw);
+int e2_conv3d_wgrad_bf16(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy, float* dw, int kd,
+                         int kh, int kw, int accumulate, void* ws, size_t ws_bytes);
 
 /* ---- BASELINE config 1 (examples/mnist.py:29-56): Perceptron and batch normalisation ----
  * Correctness-first kernels for the reference's CPU-runnable plumbing case.

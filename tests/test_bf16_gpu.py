@@ -216,3 +216,37 @@ def test_conv_with_bf16_operands_in_memory(ctx, case, tile):
         ctx.set_tiling("igemm", None)
 
 
+
+
+@pytest.mark.parametrize("tile", [None, "32,1,1,0,0", "32,1,2,0,3", "32,2,1,0,1", "32,2,2,0,7",
+                                  "32,1,4,0,2", "32,2,3,0,5", "32,2,4,0,0"])
+@pytest.mark.parametrize("case", [(20, 40, (3, 3, 3), (2, 5, 14, 19)), (150, 200, (1, 3, 3), (1, 2, 11, 12)),
+                                  (40, 150, (2, 4, 4), (1, 3, 12, 13)), (200, 70, (1, 1, 1), (2, 2, 9, 10)),
+                                  (33, 17, (1, 5, 2), (1, 1, 9, 70)), (70, 130, (1, 2, 5), (1, 1, 20, 21))])
+def test_wgrad_with_bf16_operands_in_memory(ctx, case, tile):
+    """csrc/wgrad_bf16.hip (e2_conv3d_wgrad_bf16): K = positions; dy rows by ds_read_b128, the
+    tap-shifted input windows from channels-last LDS pixels by the transposed read
+    ds_read_b64_tr_b16; 2e-5 against the f64 oracle on bf16-rounded operands; overwrite and
+    accumulate; the gradient as a strided interior view of its padded buffer; channel counts
+    that are not multiples of 8 / 32 / 128, kernel rows shorter and longer than the tap group."""
+    Ci, Co, k, (N, D, H, W) = case
+    rng = np.random.RandomState(Ci * 3 + Co)
+    x = rng.rand(N, Ci, D, H, W).astype(np.float32)
+    osp = (D - k[0] + 1, H - k[1] + 1, W - k[2] + 1)
+    dy = rng.randn(N, Co, *osp).astype(np.float32)
+    ref = O.conv3d_wgrad(bf16_round(dy), bf16_round(x), (Co, Ci) + tuple(k))
+    pshape = (N, Co) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+    dyp = torch.zeros(pshape, device="cuda")
+    dyv = dyp[:, :, k[0] - 1:k[0] - 1 + osp[0], k[1] - 1:k[1] - 1 + osp[1], k[2] - 1:k[2] - 1 + osp[2]]
+    dyv.copy_(dev(dy))
+    dw = torch.full((Co, Ci) + tuple(k), float("nan"), device="cuda")
+    ctx.set_tiling("wgrad", tile)
+    try:
+        ctx.conv3d_wgrad_bf16(dev(x), dyv, dw)
+        assert relerr(dw, ref) < TOL
+        e = relerr(dw, O.conv3d_wgrad(dy, x, (Co, Ci) + tuple(k)))
+        assert 1e-5 < e < 2e-2, e
+        ctx.conv3d_wgrad_bf16(dev(x), dyv, dw, accumulate=True)
+        assert relerr(dw, 2 * ref) < TOL
+    finally:
+        ctx.set_tiling("wgrad", None)
