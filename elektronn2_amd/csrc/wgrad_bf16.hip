@@ -113,7 +113,7 @@ struct WbP {
   int unitsPerPlane, units, per;      // K units of kKU positions; per work-group
   int nMT, nIT, nTG;                  // tiles: out channels, input-channel blocks, tap groups per dz
   int NS;                             // stages of the LDS ring (2..4)
-  int xcd;                            // XCD-aware order of the work-groups (splits a multiple of 8)
+  int nWG, perXcd;                    // work-groups; per XCD (the grid is 8 * perXcd)
 };
 
 constexpr int kLpix = 76;             // pixels per channel group of the x window in LDS: >= 64 + 3,
@@ -129,14 +129,11 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
   const int c32 = lane & 31, kh8 = lane >> 5;
   constexpr int CNT = MB + 4;                    // LDS-DMA instructions per wave and unit
 
-  // XCD x (blockIdx % 8) takes the position splits x, x + 8, ...: all tiles of a split run on
-  // one XCD at the same time and share its slice of dy and x in that XCD's L2
-  int b = blockIdx.x;
-  if (p.xcd) {
-    const int tiles = p.nTG * p.kd * p.nIT * p.nMT;
-    const int idx = b >> 3, grp = idx / tiles;
-    b = (idx - grp * tiles) + ((b & 7) + 8 * grp) * tiles;
-  }
+  // Work-groups are numbered split-major (all tiles of a split are neighbours) and XCD x
+  // (blockIdx % 8) takes the x-th eighth of that order: the tiles of a split run on one XCD
+  // at the same time and share their slice of dy and x in that XCD's L2
+  int b = (blockIdx.x & 7) * p.perXcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= p.perXcd || b >= p.nWG) return;
   const int tg = b % p.nTG; b /= p.nTG;          // group of NB taps in one kernel-plane row
   const int dz = b % p.kd;  b /= p.kd;
   const int it = b % p.nIT; b /= p.nIT;          // 128 input channels
@@ -443,15 +440,14 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   p.NS = (int)std::min<size_t>(4, (160 * 1024) / bufb);
   const size_t ldsb = p.NS * bufb;
   const long tiles = (long)p.nMT * p.nIT * kd * p.nTG;
-  if (S <= 0) {
-    S = (int)std::max<long>(1, (1L * ctx->num_cu + tiles - 1) / tiles);
-    if (S >= 6) S = (S + 7) / 8 * 8;
-  }
+  if (S <= 0) S = (int)std::max<long>(1, ctx->num_cu / tiles);      // at most one work-group per CU
   S = std::min(S, p.units);
   p.per = (p.units + S - 1) / S;
   S = (p.units + p.per - 1) / p.per;
-  p.xcd = S >= 8;
-  const long grid = tiles * (p.xcd ? (S + 7) / 8 * 8 : S);        // (work-groups past the last split exit)
+  E2_REQUIRE(tiles * S < (1L << 30), "conv3d_wgrad_bf16: grid too large");
+  p.nWG = (int)(tiles * S);
+  p.perXcd = (p.nWG + 7) / 8;
+  const long grid = 8L * p.perXcd;                                 // (work-groups past the last one exit)
   E2_REQUIRE(grid < (1L << 31), "conv3d_wgrad_bf16: grid too large");
   E2_REQUIRE((size_t)T * 33 * 4 <= 64 * 1024, "conv3d_wgrad_bf16: %d taps exceed the output pass's LDS tile", T);
   int rc = 2;

@@ -26,7 +26,7 @@ ctx.set_mfma_dtype('f32')
 nbs = sorted({min(kw, n) for n in (1, 2, 3, 4)})
 for mb in (1, 2):
     for nb in nbs:
-        for s in (0, 8, 16, 24):
+        for s in (0, 8, 10, 12, 16):
             tile = "32,%d,%d,0,%d" % (mb, nb, s)
             ctx.set_tiling("wgrad", tile)
             t = autotune._time(ctx, lambda: ctx.conv3d_wgrad_bf16(x, dyv, dw, accumulate=True), iters=10)
