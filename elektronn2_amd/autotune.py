@@ -127,7 +127,20 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
             for cc in ccs:
                 for sk in sks:
                     cands.append("%d,%d,%d,%d" % (mt, nt, cc, sk))
-    return cands + igemm4_candidates(cout, cin, k, out_sp, split_k)
+    return cands + igemm4_candidates(cout, cin, k, out_sp, split_k) + pointwise_candidates(cout, k)
+
+
+PW_MTS = (4, 5, 6, 7, 8, 10, 13, 16)
+
+
+def pointwise_candidates(cout, k):
+    """"1,MT,NT": the 1x1x1 GEMM with LDS-staged weights (csrc/conv_pw.hip): all 16*MT
+    channels of an M tile x 64*NT positions per work-group"""
+    if tuple(k) != (1, 1, 1) or cout < 48:
+        return []
+    mblocks = -(-cout // 16)
+    return ["1,%d,%d" % (mt, nt) for mt in _best_mts(mblocks, PW_MTS, keep=3) for nt in (1, 2)
+            if not (mt == 16 and nt == 2)]
 
 
 IGEMM4_INSTANCES = [(4, 2), (5, 1), (5, 2), (7, 1), (7, 2), (8, 1), (10, 1), (13, 1), (16, 1)]

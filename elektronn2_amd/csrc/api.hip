@@ -70,9 +70,9 @@ extern "C" int e2_set_tiling(e2_ctx* ctx, int kind, const char* cfg) {
     int v[5], n = sscanf(cfg, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
     int v5 = 0, v6 = 0, v7 = 0;
     if (n == 5 && kind == E2_TILING_IGEMM) n += sscanf(cfg, "%*d,%*d,%*d,%*d,%*d,%d,%d,%d", &v5, &v6, &v7);
-    E2_REQUIRE(kind == E2_TILING_IGEMM ? (n == 4 || (n == 3 && v[0] == 32) || (n == 8 && v[0] == 4)) : n == 5,
+    E2_REQUIRE(kind == E2_TILING_IGEMM ? (n == 4 || (n == 3 && (v[0] == 32 || v[0] == 1)) || (n == 8 && v[0] == 4)) : n == 5,
                "e2_set_tiling: '%s' is not %s", cfg,
-               kind == E2_TILING_IGEMM ? "\"MT,NT,CC,SK\", \"4,MG,NT,CC,SK,WM,WN,G\" or \"32,MB,NB\"" : "\"MT,NT,WK,BP,PS\"");
+               kind == E2_TILING_IGEMM ? "\"MT,NT,CC,SK\", \"4,MG,NT,CC,SK,WM,WN,G\", \"1,MT,NT\" or \"32,MB,NB\"" : "\"MT,NT,WK,BP,PS\"");
   }
   strcpy(ctx->tiling[kind], cfg);
   return 0;

@@ -99,6 +99,7 @@ struct IgemmArgs {
   size_t fill_n = 0;
 };
 int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
+int e2i_pw_conv(e2_ctx*, const IgemmArgs& a, int MT, int NT);   // 1x1x1 GEMM with LDS-staged weights (conv_pw.hip)
 
 // Wp[dz][t][ic(ciP)][oc(coP)] = w[(oc/Rout)*wsO + (ic/Rin)*wsI + tap + oc%Rout + ic%Rin],
 // tap = (dz*kh*kw+t), reversed when flip.  Zero in the padding.  Cout/Cin are

@@ -273,6 +273,7 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
     int v[8];
     const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
     if (nf == 4) { f.MT = v[0]; f.NT = v[1]; f.CC = v[2]; f.SK = v[3]; *ok = 1; return f; }
+    if (nf == 3 && v[0] == 1) { f.kind = 1; f.MT = v[1]; f.NT = v[2]; *ok = 1; return f; }
     if (nf == 8 && v[0] == 4) {
       f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5]; f.WN = v[6];
       f.G = v[7]; *ok = 1; return f;
@@ -438,6 +439,10 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
   if (a.gm_done) *a.gm_done = 0;
   if (c.kind == 4) return igemm4_conv(ctx, a, c);
+  if (c.kind == 1) {                                             // "1,MT,NT": conv_pw.hip
+    E2_REQUIRE(!ctx->mfma_bf16, "pointwise conv: an f32 kernel, not offered in bf16 mode");
+    return e2i_pw_conv(ctx, a, c.MT, c.NT);
+  }
   const bool fast = has_fast_kw(a.kw);
   // the gradient-mask epilogue lives in the specialised-width 16x16x4 kernel
   const bool gm = a.gm && fast && a.upz * a.upy * a.upx == 1 && a.Wo >= 4;

@@ -192,6 +192,46 @@ def test_conv3d_4x4_mfma_tap_widths_dgrad_and_fused_act(ctx, kw, force):
         ctx.set_tiling("igemm", None)
 
 
+@pytest.mark.parametrize("force", ["1,4,1", "1,4,2", "1,5,1", "1,5,2", "1,6,1", "1,6,2", "1,7,1", "1,7,2",
+                                   "1,8,1", "1,8,2", "1,10,1", "1,10,2", "1,13,1", "1,13,2", "1,16,1"])
+@pytest.mark.parametrize("Ci,Co,sp", [(70, 100, (4, 12, 21)), (200, 200, (2, 9, 37)), (33, 250, (1, 5, 70))])
+def test_conv3d_pointwise_gemm(ctx, force, Ci, Co, sp):
+    """csrc/conv_pw.hip ("1,MT,NT"): the 1x1x1 conv as a GEMM with LDS-staged weights --
+    forward (batch of 2, input a strided interior view), the fused bias + relu epilogue with
+    its signed zeros, the data gradient; channel counts that are not multiples of the 32-row
+    chunks / 16-row blocks, position counts that are not multiples of the tile"""
+    rng = np.random.RandomState(Ci + Co)
+    k = (1, 1, 1)
+    N = 2
+    x = rng.rand(N, Ci, *sp).astype(np.float32)
+    w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci)).astype(np.float32)
+    b = rng.randn(Co).astype(np.float32) * 0.1
+    y_ref = O.conv3d_fwd(x, w)
+    big = torch.zeros(N, Ci, sp[0] + 1, sp[1] + 2, sp[2] + 3, device="cuda")
+    xv = big[:, :, 1:, 1:-1, 2:-1]
+    xv.copy_(dev(x))
+    ws = torch.empty(ctx.conv_ws_bytes(max(Co, Ci), max(Co, Ci), k) // 4 + 64, device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        ctx.conv3d_pack(dev(w), 0, ws)
+        y = torch.full(y_ref.shape, float("nan"), device="cuda")
+        ctx.conv3d_fwd_packed(xv, ws, Co, k, y)
+        assert relerr(y, y_ref) < TOL
+        ya = torch.full(y_ref.shape, float("nan"), device="cuda")
+        ctx.conv3d_fwd_packed_act(xv, ws, Co, k, dev(b), 'relu', ya)
+        pre = y_ref + b.reshape(1, -1, 1, 1, 1)
+        assert relerr(ya, np.maximum(pre, 0)) < TOL
+        neg = torch.signbit(ya).cpu().numpy()               # -0.0 marks a NEGATIVE pre-activation
+        assert neg[pre < -1e-6].all() and not neg[pre > 1e-6].any()
+        dy = rng.randn(*y_ref.shape).astype(np.float32)
+        ctx.conv3d_pack(dev(w), 1, ws)
+        dx = torch.full(x.shape, float("nan"), device="cuda")
+        ctx.conv3d_dgrad_packed(dev(dy), ws, Ci, k, dx)
+        assert relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < TOL
+    finally:
+        ctx.set_tiling("igemm", None)
+
+
 @pytest.mark.parametrize("force", [None, "2,2,8,1", "7,2,12,1", "3,4,8,1", "2,2,8,3", "5,1,4,2",
                                    "4,5,1,16,1,2,2,1"])
 @pytest.mark.parametrize("k", [(1, 3, 3), (2, 4, 4), (1, 1, 1), (1, 2, 2)])
