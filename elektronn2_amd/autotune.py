@@ -94,15 +94,17 @@ def bf16_memory_candidates(cin):
 
 
 def bf16_wgrad_candidates(cin, k):
-    """"32,MB,NB,0,S": the weight-gradient kernel with bf16 operands in memory
+    """"32,MB,NB,R,S": the weight-gradient kernel with bf16 operands in memory
     (csrc/wgrad_bf16.hip): MB x NB blocks of 32 out channels x (32 input channels of one
-    tap) per wave, NB taps of one kernel row, S position splits (0: one work-group per CU;
-    multiples of 8 run XCD-grouped).  A work-group spans 128 input channels: not offered
-    when three quarters of that would be padding."""
-    if cin < 24:
+    tap) per wave, NB taps of one kernel row, S position splits (0: one work-group per CU).
+    R = 0: a work-group spans 128 input channels and one kernel row; R = 1: 32 input channels
+    and four kernel rows (layers with few input channels)."""
+    if cin < 12:
         return []
     nbs = sorted({min(k[2], n) for n in (1, 2, 3, 4)})
-    return ["32,%d,%d,0,%d" % (mb, nb, s) for mb in (1, 2) for nb in nbs for s in (0, 8, 16)]
+    forms = ([0] if cin >= 48 else []) + ([1] if cin <= 112 else [])
+    return ["32,%d,%d,%d,%d" % (mb, nb, r, s) for r in forms for mb in (1, 2) for nb in nbs
+            for s in (0, 8, 16)]
 
 
 def igemm_candidates(cout, cin, k, out_sp, split_k=True):

@@ -35,6 +35,7 @@ namespace {
 
 constexpr int kKU = 64;       // positions per unit (4 steps of 16)
 constexpr int kKGW = 16;      // channel groups (of 8) per work-group: 4 wave columns x 32 channels
+                              // (row form: 4 -- the wave columns are kernel rows)
 
 struct WcP {                  // the conversion pass
   const float* x; long xsN, xsC, xsZ, xsY;
@@ -113,21 +114,26 @@ struct WbP {
   int unitsPerPlane, units, per;      // K units of kKU positions; per work-group
   int nMT, nIT, nTG;                  // tiles: out channels, input-channel blocks, tap groups per dz
   int NS;                             // stages of the LDS ring (2..4)
+  int Lpix, Lwin, nJ, TB;             // x window: LDS pixels per channel group, pixels read, 64-pixel
+                                      // DMA pieces, DMA instructions per wave and unit
   int nWG, perXcd;                    // work-groups; per XCD (the grid is 8 * perXcd)
 };
 
-constexpr int kLpix = 76;             // pixels per channel group of the x window in LDS: >= 64 + 3,
-                                      // 12 mod 16 so that the four groups of a transposed read
-                                      // fall into different banks
+constexpr int kTBmax = 4;             // DMA instructions of the x window per wave and unit, at most
 
-template <int MB, int NB>
+// ROWS = false: the four wave columns are four blocks of 32 input channels (128 per work-group)
+// and the work-group owns NB taps of ONE kernel row.  ROWS = true (layers with few input
+// channels): the wave columns are four ROWS of the kernel plane, the work-group owns 32 input
+// channels and one window that spans the rows -- 40 channels pad to 64 instead of 128.
+template <int MB, int NB, bool ROWS>
 __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int c32 = lane & 31, kh8 = lane >> 5;
-  constexpr int CNT = MB + 4;                    // LDS-DMA instructions per wave and unit
+  constexpr int KGW = ROWS ? 4 : kKGW;
+  const int CNT = MB + p.TB;                     // LDS-DMA instructions per wave and unit
 
   // Work-groups are numbered split-major (all tiles of a split are neighbours) and XCD x
   // (blockIdx % 8) takes the x-th eighth of that order: the tiles of a split run on one XCD
@@ -136,22 +142,26 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
   if ((int)(blockIdx.x >> 3) >= p.perXcd || b >= p.nWG) return;
   const int tg = b % p.nTG; b /= p.nTG;          // group of NB taps in one kernel-plane row
   const int dz = b % p.kd;  b /= p.kd;
-  const int it = b % p.nIT; b /= p.nIT;          // 128 input channels
+  const int it = b % p.nIT; b /= p.nIT;          // 128 (32) input channels
   const int mt = b % p.nMT;                      // 64*MB out channels
   const int sp = b / p.nMT;
   const int u0 = sp * p.per, u1 = min(u0 + p.per, p.units);
   if (u0 >= u1) return;                          // (whole work-group)
   const int tgPerRow = (p.kw + NB - 1) / NB;
-  const int ty = tg / tgPerRow, tx0 = (tg - ty * tgPerRow) * NB;
+  const int tyg = tg / tgPerRow, tx0 = (tg - tyg * tgPerRow) * NB;
+  const int ty0 = ROWS ? 4 * tyg : tyg;          // first kernel row of the work-group
+  const int tyw = ROWS ? ty0 + wn : ty0;         // this wave's kernel row (>= kh: an idle wave column)
   // true convolution: weight tap (dz, ty, tx) meets the input at the FLIPPED shift
-  const int sz = p.kd - 1 - dz, sy = p.kh - 1 - ty;
-  const int shiftLo = sy * p.Win + (p.kw - 1 - min(tx0 + NB - 1, p.kw - 1));     // smallest shift of the group
+  const int sz = p.kd - 1 - dz, sy = p.kh - 1 - min(tyw, p.kh - 1);
+  const int syLo = p.kh - 1 - min(ROWS ? ty0 + 3 : ty0, p.kh - 1);
+  const int shiftLo = syLo * p.Win + (p.kw - 1 - min(tx0 + NB - 1, p.kw - 1));   // smallest shift of the group
   const int M0 = mt * 64 * MB;                   // first out channel of the work-group
-  const int kg0 = it * kKGW;                     // first channel group of the work-group
-  const int kgs = min(kKGW, p.KG - kg0);
-  // a stage: [64*MB dy rows][128 B, 16-byte pieces XOR-swizzled by the row] + [16 kg][kLpix][16 B]
+  const int kg0 = it * KGW;                      // first channel group of the work-group
+  const int kgs = min(KGW, p.KG - kg0);
+  // a stage: [64*MB dy rows][128 B, 16-byte pieces XOR-swizzled by the row] + [KGW kg][Lpix][16 B];
+  // Lpix = 12 mod 16 so that the four groups of a transposed read fall into different banks
   constexpr unsigned bytesA = 64 * MB * kKU * 2;
-  constexpr unsigned bufBytes = bytesA + (unsigned)kKGW * kLpix * 16;
+  const unsigned bufBytes = bytesA + (unsigned)KGW * p.Lpix * 16;
 
   // ---- per-lane read addresses ------------------------------------------------------
   // A (ds_read_b128): row = out channel of the wave's block, piece (2 st + lane/32) of the
@@ -168,13 +178,13 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
   // 16*(g & 1) .. +15 of the wave's 32-channel block and positions 8*(g >> 1) .. +7 of the
   // step; lane 4q+p of the group supplies pixel q, channels 4p..4p+3
   const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
-  const int kgl = wn * 4 + 2 * (g & 1) + (p4 >> 1);          // channel group inside the window
+  const int kgl = (ROWS ? 0 : wn * 4) + 2 * (g & 1) + (p4 >> 1);          // channel group inside the window
   unsigned baddr[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int tx = min(tx0 + nb, p.kw - 1);
     const int shift = sy * p.Win + (p.kw - 1 - tx) - shiftLo;  // pixels, relative to the window
-    baddr[nb] = (unsigned)(uintptr_t)(lds_vp)(lds + bytesA + (kgl * kLpix + shift + 8 * (g >> 1) + q4) * 16 +
+    baddr[nb] = (unsigned)(uintptr_t)(lds_vp)(lds + bytesA + (kgl * p.Lpix + shift + 8 * (g >> 1) + q4) * 16 +
                                               (p4 & 1) * 8);
   }
   f32x16 acc[MB][NB];
@@ -197,19 +207,20 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
     aoff[c] = (long)oc * p.Do * p.planeD + (((lane & 7) ^ (row & 7)) << 3);
     adst[c] = (unsigned)(8 * (wave + 8 * c)) * (kKU * 2);
   }
-  // x window: 16 channel groups x 2 pieces of 64 pixels = 32 DMAs, 4 per wave (piece = wave & 1);
-  // channel groups past the last one re-read it (their columns are never flushed)
-  constexpr int Lwin = kKU + (NB > 1 ? NB - 1 : 1);   // pixels of the window a unit reads (the second
-                                                 // piece never empty: every wave issues CNT DMAs per unit)
-  long boff[4];
-  unsigned bdst[4];
-  const int pj = wave & 1;
-  const bool bact = 64 * pj + lane < Lwin;
+  // x window: KGW channel groups x nJ pieces of 64 pixels, TB DMAs per wave (item = wave + 8 t;
+  // items past the last one repeat it, so that EVERY wave issues CNT DMAs per unit -- the
+  // counted waits below rely on it); channel groups past the last one re-read it (their
+  // columns are never flushed)
+  long boff[kTBmax];
+  unsigned bdst[kTBmax];
+  bool bact[kTBmax];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int kg = (wave + 8 * t) >> 1;
+  for (int t = 0; t < kTBmax; ++t) {
+    const int i = min(wave + 8 * t, KGW * p.nJ - 1);
+    const int kg = i / p.nJ, pj = i - kg * p.nJ;
     boff[t] = ((long)min(kg, kgs - 1) * p.planePix + 64 * pj + lane) * 8;
-    bdst[t] = bytesA + (unsigned)(kg * kLpix + 64 * pj) * 16;
+    bdst[t] = bytesA + (unsigned)(kg * p.Lpix + 64 * pj) * 16;
+    bact[t] = 64 * pj + lane < p.Lwin;           // (the last piece of a window is never empty)
   }
   // unit u -> plane (n, z), unit of the plane
   int su = u0, spl = u0 / p.unitsPerPlane, squ = u0 - spl * p.unitsPerPlane;
@@ -226,8 +237,9 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
     const __bf16* xp = p.xcl + ((((long)n * p.Din + z + sz) * p.KG + kg0) * p.planePix +
                                 (long)squ * kKU + shiftLo) * 8;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (bact) __builtin_amdgcn_global_load_lds((gbl_vp)(xp + boff[t]), (lds_vp)(lb + bdst[t]), 16, 0, 0);
+    for (int t = 0; t < kTBmax; ++t)
+      if (t < p.TB && bact[t])
+        __builtin_amdgcn_global_load_lds((gbl_vp)(xp + boff[t]), (lds_vp)(lb + bdst[t]), 16, 0, 0);
     ++su;
     if (++squ == p.unitsPerPlane) { squ = 0; ++spl; }
   };
@@ -267,11 +279,12 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
   for (int u = u0; u < u1; ++u) {
     // unit u has landed when only the stages issued after it are outstanding (the ring is
     // full in the steady state; the tail simply drains)
-    const int ahead = su - u - 1;
-    if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CNT) : "memory");
-    else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CNT) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    switch ((su - u - 1) * CNT) {                // (MB + TB <= 6 instructions, <= 3 units ahead)
+#define E2W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+      E2W(2) E2W(3) E2W(4) E2W(5) E2W(6) E2W(8) E2W(9) E2W(10) E2W(12) E2W(15) E2W(18)
+#undef E2W
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                // everyone's part of unit u; slot of unit u-1 is free
     asm volatile("" ::: "memory");               // (not __syncthreads: its fence drains the whole DMA ring)
     if (su < u1) stage();
@@ -306,9 +319,9 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int tx = tx0 + nb;
-    const int ic = kg0 * 8 + wn * 32 + c32;
-    if (tx >= p.kw || ic >= p.Cin) continue;
-    const int tap = (dz * p.kh + ty) * p.kw + tx;
+    const int ic = kg0 * 8 + (ROWS ? 0 : wn * 32) + c32;
+    if (tx >= p.kw || tyw >= p.kh || ic >= p.Cin) continue;
+    const int tap = (dz * p.kh + tyw) * p.kw + tx;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -362,16 +375,16 @@ static Geo geo(int n, int cin, int d, int h, int w, int cout, int kd, int kh, in
   return g;
 }
 
-template <int MB, int NB>
+template <int MB, int NB, bool ROWS>
 static int launch(e2_ctx* ctx, const WbP& p, long grid, size_t ldsb) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MB, NB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_kernel<MB, NB, ROWS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((wgrad_bf16_kernel<MB, NB>), dim3((unsigned)grid), dim3(512), ldsb, ctx->stream, p);
+  hipLaunchKernelGGL((wgrad_bf16_kernel<MB, NB, ROWS>), dim3((unsigned)grid), dim3(512), ldsb, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -400,11 +413,11 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   E2_REQUIRE(ws && ws_bytes >= need, "conv3d_wgrad_bf16: workspace of %zu bytes needed, %zu given",
              need, ws_bytes);
   E2_REQUIRE(((uintptr_t)ws & 15) == 0, "conv3d_wgrad_bf16: workspace must be 16-byte aligned");
-  int MB = 2, NB = 0, S = 0;
+  int MB = 2, NB = 0, S = 0, rows = Cin <= 64 ? 1 : 0;
   {
     int v[5];
     if (sscanf(ctx->tiling[E2_TILING_WGRAD], "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5 &&
-        v[0] == 32) { MB = v[1]; NB = v[2]; S = v[4]; }
+        v[0] == 32) { MB = v[1]; NB = v[2]; rows = v[3] != 0; S = v[4]; }
   }
   if (NB <= 0) NB = kw >= 4 ? 4 : (kw == 3 ? 3 : kw);        // taps of a kernel row per wave
   E2_REQUIRE((MB == 1 || MB == 2) && NB >= 1 && NB <= 4, "conv3d_wgrad_bf16: MB 1..2, NB 1..4");
@@ -434,10 +447,17 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   p.unitsPerPlane = g.planeD / kKU;
   p.units = x->n * dy->d * p.unitsPerPlane;
   p.nMT = (Cout + 64 * MB - 1) / (64 * MB);
-  p.nIT = (g.KG + kKGW - 1) / kKGW;
-  p.nTG = kh * ((kw + NB - 1) / NB);
-  const size_t bufb = (size_t)64 * MB * kKU * 2 + (size_t)kKGW * kLpix * 16;
+  const int KGW = rows ? 4 : kKGW;
+  p.nIT = (g.KG + KGW - 1) / KGW;
+  p.nTG = (rows ? (kh + 3) / 4 : kh) * ((kw + NB - 1) / NB);
+  p.Lwin = kKU + (rows ? std::min(kh - 1, 3) * x->w : 0) + NB - 1;
+  p.Lpix = (p.Lwin + 3) / 16 * 16 + 12;                  // smallest >= Lwin that is 12 mod 16
+  p.nJ = (p.Lwin + 63) / 64;
+  p.TB = (KGW * p.nJ + 7) / 8;
+  E2_REQUIRE(p.TB <= kTBmax, "conv3d_wgrad_bf16: rows of %d pixels are too long for the row form", x->w);
+  const size_t bufb = (size_t)64 * MB * kKU * 2 + (size_t)KGW * p.Lpix * 16;
   p.NS = (int)std::min<size_t>(4, (160 * 1024) / bufb);
+  E2_REQUIRE(p.NS >= 2, "conv3d_wgrad_bf16: a stage of %zu B does not fit LDS twice", bufb);
   const size_t ldsb = p.NS * bufb;
   const long tiles = (long)p.nMT * p.nIT * kd * p.nTG;
   if (S <= 0) S = (int)std::max<long>(1, ctx->num_cu / tiles);      // at most one work-group per CU
@@ -451,7 +471,7 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   E2_REQUIRE(grid < (1L << 31), "conv3d_wgrad_bf16: grid too large");
   E2_REQUIRE((size_t)T * 33 * 4 <= 64 * 1024, "conv3d_wgrad_bf16: %d taps exceed the output pass's LDS tile", T);
   int rc = 2;
-#define E2_L(M, N_) if (MB == M && NB == N_) rc = launch<M, N_>(ctx, p, grid, ldsb);
+#define E2_L(M, N_) if (MB == M && NB == N_) rc = rows ? launch<M, N_, true>(ctx, p, grid, ldsb) : launch<M, N_, false>(ctx, p, grid, ldsb);
   E2_L(1, 1) E2_L(1, 2) E2_L(1, 3) E2_L(1, 4) E2_L(2, 1) E2_L(2, 2) E2_L(2, 3) E2_L(2, 4)
 #undef E2_L
   if (rc) return rc;

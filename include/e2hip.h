@@ -387,8 +387,9 @@ int e2_conv3d_dgrad_bf16(e2_ctx*, const e2_tensor5* dy_pad, const float* w, int 
  * 64 positions; dy rows are read with ds_read_b128, the shifted input windows with the
  * transposed LDS read ds_read_b64_tr_b16; the tile is flushed into dw with f32 atomics
  * (accumulate 0: dw is zeroed first).  Tiling: e2_set_tiling(E2_TILING_WGRAD,
- * "32,MB,NB,0,S"): MB (1..2) blocks of 32 out channels x NB (1..4) taps of a kernel row per
- * wave, S position splits (0 = one work-group per CU). */
+ * "32,MB,NB,R,S"): MB (1..2) blocks of 32 out channels x NB (1..4) taps of a kernel row per
+ * wave; R = 0: the work-group spans 128 input channels of one kernel row, R = 1: 32 input
+ * channels of four kernel rows; S position splits (0 = one work-group per CU). */
 size_t e2_conv3d_wgrad_bf16_workspace_bytes(int n, int cin, int d, int h, int w, int cout,
                                             int kd, int kh, int kw);
 int e2_conv3d_wgrad_bf16(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy, float* dw, int kd,

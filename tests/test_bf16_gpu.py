@@ -219,7 +219,9 @@ def test_conv_with_bf16_operands_in_memory(ctx, case, tile):
 
 
 @pytest.mark.parametrize("tile", [None, "32,1,1,0,0", "32,1,2,0,3", "32,2,1,0,1", "32,2,2,0,7",
-                                  "32,1,4,0,2", "32,2,3,0,5", "32,2,4,0,0"])
+                                  "32,1,4,0,2", "32,2,3,0,5", "32,2,4,0,0",
+                                  "32,1,1,1,0", "32,1,2,1,3", "32,2,1,1,1", "32,2,2,1,7",
+                                  "32,1,4,1,2", "32,2,3,1,5", "32,2,4,1,0", "32,1,3,1,16"])
 @pytest.mark.parametrize("case", [(20, 40, (3, 3, 3), (2, 5, 14, 19)), (150, 200, (1, 3, 3), (1, 2, 11, 12)),
                                   (40, 150, (2, 4, 4), (1, 3, 12, 13)), (200, 70, (1, 1, 1), (2, 2, 9, 10)),
                                   (33, 17, (1, 5, 2), (1, 1, 9, 70)), (70, 130, (1, 2, 5), (1, 1, 20, 21))])
@@ -228,7 +230,9 @@ def test_wgrad_with_bf16_operands_in_memory(ctx, case, tile):
     tap-shifted input windows from channels-last LDS pixels by the transposed read
     ds_read_b64_tr_b16; 2e-5 against the f64 oracle on bf16-rounded operands; overwrite and
     accumulate; the gradient as a strided interior view of its padded buffer; channel counts
-    that are not multiples of 8 / 32 / 128, kernel rows shorter and longer than the tap group."""
+    that are not multiples of 8 / 32 / 128, kernel rows shorter and longer than the tap group;
+    both wave layouts (fourth tiling field: 0 = four blocks of 32 input channels of one kernel
+    row, 1 = 32 input channels of four kernel rows -- kernel planes of 1, 2, 3, 4 and 5 rows)."""
     Ci, Co, k, (N, D, H, W) = case
     rng = np.random.RandomState(Ci * 3 + Co)
     x = rng.rand(N, Ci, D, H, W).astype(np.float32)

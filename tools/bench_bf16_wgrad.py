@@ -24,10 +24,11 @@ t = autotune._time(ctx, lambda: ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=Fals
 print("   bf16 operand rounding (own tiling)        %8.1f us" % (t * 1e3))
 ctx.set_mfma_dtype('f32')
 nbs = sorted({min(kw, n) for n in (1, 2, 3, 4)})
-for mb in (1, 2):
-    for nb in nbs:
-        for s in (0, 8, 10, 12, 16):
-            tile = "32,%d,%d,0,%d" % (mb, nb, s)
+forms = ([0] if cin >= 48 else []) + ([1] if cin <= 112 else [])
+for mb, nb, r in [(mb, nb, r) for r in forms for mb in (1, 2) for nb in nbs]:
+    if True:
+        for s in (0, 8, 16):
+            tile = "32,%d,%d,%d,%d" % (mb, nb, r, s)
             ctx.set_tiling("wgrad", tile)
             t = autotune._time(ctx, lambda: ctx.conv3d_wgrad_bf16(x, dyv, dw, accumulate=True), iters=10)
             print("   bf16 in memory %-12s %8.1f us (%5.1f%% of 2.5 PF)" % (tile, t * 1e3, gf / t / 2500 * 100))
