@@ -166,3 +166,33 @@ def test_choose_name_and_call_arity():
     x = np.zeros((1, 1, 7, 47, 47), np.float32)
     with pytest.raises(TypeError, match="inputs required"):
         m.prediction_node(x, x)          # (a call without arguments only compiles)
+
+
+def test_tiling_candidate_lists():
+    """the tuner's candidate strings are what e2_set_tiling accepts (csrc/api.hip) and what the
+    kernels have instances for; host logic only -- the shipped choices must be among them"""
+    import json
+    import os
+    import re
+    from elektronn2_amd import autotune
+    # 1x1x1 GEMM with LDS-staged weights: "1,MT,NT", only for 1x1x1 kernels with enough channels
+    pw = autotune.pointwise_candidates(200, (1, 1, 1))
+    assert pw and all(re.fullmatch(r"1,(4|5|6|7|8|10|13|16),(1|2)", c) for c in pw)
+    assert "1,13,1" in pw and "1,7,2" in pw
+    assert autotune.pointwise_candidates(200, (1, 3, 3)) == []
+    assert autotune.pointwise_candidates(2, (1, 1, 1)) == []
+    assert set(pw) <= set(autotune.igemm_candidates(200, 200, (1, 1, 1), (10, 37, 37)))
+    # bf16 weight gradient: "32,MB,NB,R,S"; the row form (R = 1) for few input channels only,
+    # the column form (R = 0) when at least 48
+    for cin, forms in ((20, {"1"}), (40, {"1"}), (100, {"0", "1"}), (200, {"0"}), (8, set())):
+        c = autotune.bf16_wgrad_candidates(cin, (1, 3, 3))
+        assert {x.split(",")[3] for x in c} == forms, (cin, c)
+        assert all(re.fullmatch(r"32,[12],[1-3],[01],(0|8|16)", x) for x in c)
+    assert max(int(x.split(",")[2]) for x in autotune.bf16_wgrad_candidates(64, (2, 4, 4))) == 4
+    # every shipped choice is a well-formed string of one of the known forms
+    shipped = json.load(open(os.path.join(os.path.dirname(autotune.__file__), "tuned.json")))
+    forms = {"igemm": r"\d+,\d+,\d+,\d+|4(,\d+){7}|1,\d+,[12]|32,\d+,\d+",
+             "wgrad": r"\d+,\d+,\d+,\d+,\d+"}
+    for key, val in shipped.items():
+        kind = key.split("|")[0].replace("_bf16", "")
+        assert val == "" or re.fullmatch(forms[kind], val), (key, val)
