@@ -309,9 +309,14 @@ class Plan(object):
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
         import os
-        # measured (profiles/r01 notes in DESIGN.md): two MFMA-bound kernels sharing the
-        # chip finish no sooner than back to back -- off unless E2_SIDE_STREAM=1
-        self.use_side = os.environ.get("E2_SIDE_STREAM", "0") == "1"
+        # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
+        # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
+        # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
+        # branch pays there (lite183 0.884 -> 0.855 ms, neuro3d 1.223 -> 1.198, unet3d 7.23 ->
+        # 7.05).  E2_SIDE_STREAM=0/1 overrides.
+        env_side = os.environ.get("E2_SIDE_STREAM")
+        self.use_side = (env_side == "1") if env_side is not None else \
+            (getattr(self.ctx, 'mfma_dtype', 'f32') == 'bf16')
         # the repack of the weight images as a parallel branch of the graph next to the first
         # layer (the first kernel that reads a packed image joins it, Conv._plan_fwd): measured
         # on one box, interleaved (tools/ab.sh), the fork / join costs more than the overlap
