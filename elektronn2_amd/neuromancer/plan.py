@@ -293,7 +293,7 @@ class Plan(object):
             return
         dst, first = self.grad_slot(node)
         if first:
-            self.ctx.fill(dst, 0.0)
+            self.zero_early(dst)      # (a gradient buffer: nothing touches it before its first writer)
         self.ctx.copy5(src, dst[slicer], accumulate=True)
 
     # ---- build ------------------------------------------------------------------------
