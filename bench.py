@@ -44,16 +44,16 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak 
 # --pmc WRITE_SIZE runs of this script, profiles/r01_e_pmc_traffic.csv):
 # 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
 # It cannot be measured inside the timed run; null for workloads not profiled.
-PMC_TRAFFIC_BYTES = {"lite183": (2 * 668.2 + 404.5) * 1024 * 1024,
-                     "full185": (2 * 557.9 + 557.7) * 1024 * 1024,
+PMC_TRAFFIC_BYTES = {"lite183": (2 * 650.7 + 400.8) * 1024 * 1024,
+                     "full185": (2 * 552.7 + 551.5) * 1024 * 1024,
                      "unet132": (2 * 10933.3 + 5241.1) * 1024 * 1024}
-PMC_TRAFFIC_SOURCE = "profiles/r02_t_bench_<workload>_pmc_traffic.csv (unet132: r02_m)"
+PMC_TRAFFIC_SOURCE = "profiles/r02_v_bench_<workload>_pmc_traffic.csv (unet132: r02_m)"
 # Matrix-pipe utilisation of the whole step from the rocprofv3 PMC pass of this script
 # (tools/gpu_round.sh -> tools/pmc_mfma.py): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel
 # cycles at the clock the chip held), summed over the kernels of a step; None = not profiled.
-PMC_MFMA_UTIL = {"lite183": 0.4833, "full185": 0.3919, "unet132": 0.5797}
-PMC_MFMA_SOURCE = ("profiles/r02_t_bench_<workload>_pmc_mfma.csv (unet132: r02_m; eager launches under rocprofv3; executed "
-                   "MFMA FLOPs / algorithmic: 1.27 lite183, 1.35 full185, 1.14 unet132)")
+PMC_MFMA_UTIL = {"lite183": 0.4797, "full185": 0.3852, "unet132": 0.5797}
+PMC_MFMA_SOURCE = ("profiles/r02_v_bench_<workload>_pmc_mfma.csv (unet132: r02_m; eager launches under rocprofv3; executed "
+                   "MFMA FLOPs / algorithmic: 1.25 lite183, 1.32 full185, 1.14 unet132)")
 
 
 def algorithmic_gflop(model):
