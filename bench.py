@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- training throughput of the hot path on N MI355X GPUs of one node.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1], SURVEY.md §8d "C-lite@183"): the
@@ -213,12 +213,90 @@ def warp_bench(args, rank, world):
         print(json.dumps(out))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, extra_env=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh processes of
+    this script (one per GPU: RANK = LOCAL_RANK = 0..N-1, WORLD_SIZE = N, rendezvous on
+    127.0.0.1) and hand back (exit code, rank 0's stdout).  The parent never touches the
+    GPU -- a process that has initialised HIP must not be replaced or forked -- and never
+    retries: if any rank fails, the others are terminated and the code is non-zero."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n),
+                    "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port)})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    out0, rc = "", 0
+    t_end = None if timeout is None else time.time() + timeout
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                pending.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+            if rc != 0 or (t_end is not None and time.time() > t_end):
+                rc = rc or 124
+                break
+            if pending:
+                # rank 0 prints one line at its very end: reading it here cannot block the others
+                time.sleep(0.05)
+        if rc == 0:
+            out0 = procs[0].stdout.read()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=20)
+            except Exception:
+                pr.kill()
+    return rc, out0
+
+
+def selftest_bench(args, rank, world):
+    """`--workload selftest`: the multi-rank plumbing of this script WITHOUT a GPU (gloo on
+    the CPU): rendezvous, barrier, MAX over ranks, the rank list in `config.ranks`.  Not a
+    measurement; tests/test_bench_launcher.py runs it."""
+    import torch.distributed as dist
+    v = torch.tensor([float(rank)], dtype=torch.float64)
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()}
+    ranks = [me]
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    if os.environ.get("E2_SELFTEST_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": float(v.item()), "unit": "rank",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "selftest (no GPU)", "ranks": ranks}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "warp183"])
+    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "warp183", "selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mfma", default=os.environ.get("E2_MFMA_DTYPE", "f32"), choices=["f32", "bf16"],
@@ -227,16 +305,35 @@ def main():
                          "tolerance path -- never the headline number)")
     args = ap.parse_args()
 
-    from elektronn2_amd import parallel, nets
-    from elektronn2_amd import neuromancer as nm
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (nothing has touched the GPU yet)
+        rc, line = launch_ranks(args.gpus, sys.argv[1:])
+        if rc == 0:
+            # rank 0's ONE JSON line goes to stdout; anything else a library printed there
+            # (gloo's "[Gloo] Rank 0 is connected ..." banner) goes to stderr
+            for l in line.splitlines():
+                (sys.stdout if l.lstrip().startswith("{") else sys.stderr).write(l + "\n")
+            sys.stdout.flush()
+        sys.exit(rc)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks, or none: "
+                 "`python bench.py --gpus N` starts its own)" % (args.gpus, world))
+    if args.workload == "selftest":
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return selftest_bench(args, rank, world)
+
+    from elektronn2_amd import parallel, nets
+    from elektronn2_amd import neuromancer as nm
+
     if world > 1:
         # RCCL ("nccl") on the GPU node; E2_DIST_BACKEND=gloo only to rehearse the
         # multi-rank flow where the ranks have to share one GPU
         parallel.init_from_env(os.environ.get("E2_DIST_BACKEND", "nccl"))
-    assert world == args.gpus or world == 1, "launch with torchrun for --gpus > 1"
 
     bf16 = args.mfma == "bf16"
     if bf16:

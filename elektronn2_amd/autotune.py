@@ -125,7 +125,7 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
             if nt == 4 and mt > 5:
                 continue
             base = out_sp[0] * (-(-q // (64 * nt))) * nmt
-            sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 6)
+            sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 5, 6, 8)
             for cc in ccs:
                 for sk in sks:
                     cands.append("%d,%d,%d,%d" % (mt, nt, cc, sk))

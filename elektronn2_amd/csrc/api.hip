@@ -232,6 +232,7 @@ extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, con
   a.osN = dx->sn; a.osC = dx->sc; a.osZ = dx->sd; a.osY = dx->sh;
   e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
   a.upz = a.upy = a.upx = 1;
+  a.zpad = kd - 1;
   return e2i_igemm_conv(ctx, a);
 }
 
@@ -270,6 +271,7 @@ extern "C" int e2_conv3d_dgrad_packed_actbwd(e2_ctx* ctx, const e2_tensor5* dy_p
   a.osN = dx.sn; a.osC = dx.sc; a.osZ = dx.sd; a.osY = dx.sh;
   e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
   a.upz = a.upy = a.upx = 1;
+  a.zpad = kd - 1;
   int done = 0;
   if (o->sh == o->w) {                          // the epilogue reads dense mask rows
     a.gm = 1; a.gm_src = (act_prev == E2_ACT_RELU) ? o->ptr : nullptr;

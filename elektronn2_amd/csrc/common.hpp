@@ -97,6 +97,9 @@ struct IgemmArgs {
   // the whole buffer may be filled flat (batched by the caller), nullptr = fill the view
   float* fill_base = nullptr;
   size_t fill_n = 0;
+  // data gradient: `in` is dy zero-padded by kd - 1 planes at both ends of z (the contract
+  // of e2_conv3d_dgrad*): the kernels skip the tap planes that read only that border
+  int zpad = 0;
 };
 int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
 int e2i_pw_conv(e2_ctx*, const IgemmArgs& a, int MT, int NT);   // 1x1x1 GEMM with LDS-staged weights (conv_pw.hip)

@@ -401,7 +401,7 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
     p.splitK = e2_cdiv(nChunks, per);
   }
   p.atomic = (p.splitK > 1) ? 1 : 0;
-  p.upz = a.upz; p.upy = a.upy; p.upx = a.upx;
+  p.upz = a.upz; p.upy = a.upy; p.upx = a.upx; p.zpad = a.zpad;
   p.bufFloats = c.CC * p.Lpad + 64;
   p.stamps = nullptr; p.bias = a.bias; p.act = a.act; p.bf16 = 0; p.wide = 0;
   // channels past Cin are staged as copies of the last one: their weight rows must exist and be zero
@@ -469,7 +469,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   p.nChunkC = e2_cdiv(a.Cin, c.CC);
   p.splitK = a.bias ? 1 : std::min(c.SK, a.kd * p.nChunkC);     // the fused epilogue cannot split K
   p.atomic = (p.splitK > 1) ? 1 : 0;
-  p.upz = a.upz; p.upy = a.upy; p.upx = a.upx;
+  p.upz = a.upz; p.upy = a.upy; p.upx = a.upx; p.zpad = a.zpad;
   p.bufFloats = (int)buf_floats(a, c.MT, BN, c.CC);
   E2_REQUIRE(p.nMT * 16 * c.MT <= a.coP, "igemm: packed coP too small");
   if (fast) E2_REQUIRE(((a.Cin + 15) / 16) * 16 <= a.ciP, "igemm: packed ciP too small");

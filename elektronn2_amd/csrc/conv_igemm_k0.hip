@@ -54,9 +54,11 @@ __global__ __launch_bounds__(256, 2) void igemm_generic_kernel(IgemmP p) {
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nChunks = p.kd * p.nChunkC;
-  const int per = (nChunks + p.splitK - 1) / p.splitK;
-  const int cb = ks * per, ce = min(cb + per, nChunks);
+  int c_lo, c_hi;
+  e2_chunk_range(p, z, c_lo, c_hi);             // (data gradient: border-only tap planes skipped)
+  const int per = (c_hi - c_lo + p.splitK - 1) / p.splitK;
+  const int cb = c_lo + ks * per, ce = min(cb + per, c_hi);
+  if (cb >= ce) return;
   const int aBase = qd * BMpad + l15;
   const int nRows = p.THW * CC;
   const int nPieces = (nRows * BMp4 + 63) >> 6;

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
   const bool producer = wave8 >= WM * WN;
   const int isY = (int)p.isY;
   const int Lpad = p.Lpad;
-  const int nChunks = p.kd * p.nChunkC;
-  const int per = (nChunks + p.splitK - 1) / p.splitK;    // (the host keeps every split non-empty)
+  // (with a clipped K range -- IgemmP::zpad -- a split of a border plane may be EMPTY: such a
+  // tile has no items; both the staging cursor and the compute loop skip it)
 
   auto decode = [&](int t, G4Tile& T) {
     const int pt = t % p.nPT; t /= p.nPT;
@@ -170,7 +170,10 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
     const int rl = qlast / p.Wo, cl = qlast - rl * p.Wo;
     T.span_lo = (long)T.r0 * p.isY + T.c0;
     T.L = (rl - T.r0) * isY + (cl - T.c0) + (p.kh - 1) * isY + p.kw;
-    T.cb = T.ks * per; T.ce = min(T.cb + per, nChunks);
+    int c_lo, c_hi;
+    e2_chunk_range(p, T.z, c_lo, c_hi);
+    const int per = (c_hi - c_lo + p.splitK - 1) / p.splitK;
+    T.cb = c_lo + T.ks * per; T.ce = max(T.cb, min(T.cb + per, c_hi));
   };
 
   if (producer) {
@@ -209,15 +212,18 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
       nItems += T.ce - T.cb;
     }
     G4Tile S; int st = blockIdx.x, sch = 0, staged = 0;      // the staging cursor
-    if (st < x.tilesTotal) { decode(st, S); sch = S.cb; }
+    auto seek = [&]() {                                      // ... rests on a tile that has items
+      for (; st < x.tilesTotal; st += gridDim.x) {
+        decode(st, S); sch = S.cb;
+        if (S.cb < S.ce) break;
+      }
+    };
+    seek();
     auto stage_next = [&]() {
       if (staged >= nItems) return;
       stage(S, sch, staged % NBUF);
       ++staged;
-      if (++sch == S.ce) {
-        st += gridDim.x;
-        if (st < x.tilesTotal) { decode(st, S); sch = S.cb; }
-      }
+      if (++sch == S.ce) { st += gridDim.x; seek(); }
     };
     stage_next();
     stage_next();
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
 
   for (int t = blockIdx.x; t < x.tilesTotal; t += gridDim.x) {
     G4Tile T; decode(t, T);
+    if (T.cb >= T.ce) continue;                       // empty split of a clipped K range
     const int m0w = T.mt * BM + wm * (4 * MG);        // the wave's first output channel
     const int qw = T.q0 + wn * (64 * NT);             // ... and first position
     unsigned posoffB[NT];

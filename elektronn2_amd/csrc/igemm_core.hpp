@@ -44,7 +44,20 @@ struct IgemmP {
   long gsN = 0, gsC = 0, gsZ = 0;
   float* gm_dbias = nullptr;
   const float* gm_bias = nullptr;
+  // data gradient: the first and last `zpad` z-planes of `in` are the zero border of the
+  // padded gradient buffer.  A tap plane dz that reads only border for this tile's output
+  // plane z is skipped (exact: it would add 0 * w); the K range of the tile shrinks to
+  // dz in [max(0, zpad - z), min(kd - 1, Din - 1 - zpad - z)].
+  int zpad = 0;
 };
+
+// K range (in channel chunks) of output plane z: [lo, hi)
+__device__ __forceinline__ void e2_chunk_range(const IgemmP& p, int z, int& lo, int& hi) {
+  const int dzlo = max(0, p.zpad - z);
+  const int dzhi = min(p.kd - 1, p.Din - 1 - p.zpad - z);
+  lo = dzlo * p.nChunkC;
+  hi = (dzhi + 1) * p.nChunkC;
+}
 
 // relu slope of the producing layer: o = its activated output (pre = false: the sign of a
 // zero tells 0.5 from 0) or its pre-activation plus bias (pre = true)
@@ -287,9 +300,12 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   const int L = (rl - r0) * isY + (cl - c0) + (p.kh - 1) * isY + p.kw;
   const int Lpad = p.Lpad;
 
-  const int nChunks = p.kd * p.nChunkC;
-  const int per = (nChunks + p.splitK - 1) / p.splitK;
-  const int cb = ks * per, ce = min(cb + per, nChunks);
+  int c_lo, c_hi;
+  e2_chunk_range(p, z, c_lo, c_hi);
+  const int per = (c_hi - c_lo + p.splitK - 1) / p.splitK;
+  const int cb = c_lo + ks * per, ce = min(cb + per, c_hi);
+  if (cb >= ce) return;        // (split-K over a clipped range: nothing left for this split;
+                               //  every wave decides alike, the output is accumulated atomically)
   const int nCG = (p.Cin + 3) >> 2;          // channel groups that carry data
   const int CG = CC >> 2;
 

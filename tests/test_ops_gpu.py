@@ -94,6 +94,61 @@ def test_conv3d_fwd_forced_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
+def _padded_dy(dy, k):
+    pad = [kk - 1 for kk in k]
+    dyp = torch.zeros(dy.shape[0], dy.shape[1], *[dy.shape[2 + i] + 2 * pad[i] for i in range(3)],
+                      device="cuda")
+    dyp[:, :, pad[0]:pad[0] + dy.shape[2], pad[1]:pad[1] + dy.shape[3],
+        pad[2]:pad[2] + dy.shape[4]].copy_(dev(dy))
+    return dyp
+
+
+@pytest.mark.parametrize("kw", [1, 3, 4, 5])
+@pytest.mark.parametrize("force", ["5,4,8,1", "5,4,16,2", "5,4,24,3"])
+def test_conv3d_5x4_block_tiling_fwd_and_dgrad(ctx, kw, force):
+    """the widest 16x16x4 tile that ships (5 x 4 blocks: 80 accumulator registers, the
+    instance the round-2 stream-K sweep faulted on) in its PLAIN form, every tap width,
+    forward and data gradient, with and without split-K"""
+    rng = np.random.RandomState(100 + kw)
+    k = (2, 2, kw)
+    x = rng.rand(1, 72, 4, 11, 40).astype(np.float32)
+    w = (rng.randn(72, 72, *k) / np.sqrt(72 * np.prod(k))).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    y = torch.full(y_ref.shape, float("nan"), device="cuda")
+    dx = torch.full(x.shape, float("nan"), device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        ctx.conv3d_fwd(dev(x), dev(w), y)
+        ctx.conv3d_dgrad(_padded_dy(dy, k), dev(w), dx)
+    finally:
+        ctx.set_tiling("igemm", None)
+    assert relerr(y, y_ref) < TOL
+    assert relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < TOL
+
+
+@pytest.mark.parametrize("force", [None, "2,1,8,1", "2,1,8,4", "3,2,8,6", "2,4,16,3", "1,2,4,8",
+                                   "4,5,1,8,1,1,4,1", "4,5,1,8,4,1,4,1", "4,4,2,8,2,2,2,2"])
+@pytest.mark.parametrize("k,do", [((4, 3, 3), 3), ((3, 2, 4), 1), ((2, 1, 5), 6)])
+def test_conv3d_dgrad_skips_border_planes(ctx, force, k, do):
+    """data gradient with kd > 1: the tap planes that read only the zero border of the
+    padded gradient buffer are skipped per output plane (IgemmP::zpad) -- every dx plane
+    still equals the oracle's, incl. split-K ranges that come out SHORTER or EMPTY on the
+    border planes, one single real dy plane (do = 1), and the 4x4x1 kernel's item ring"""
+    rng = np.random.RandomState(5 + do)
+    ci, co = 20, 24
+    dy = rng.randn(1, co, do, 7, 19).astype(np.float32)
+    w = (rng.randn(co, ci, *k) / np.sqrt(ci * np.prod(k))).astype(np.float32)
+    xshape = (1, ci, do + k[0] - 1, 7 + k[1] - 1, 19 + k[2] - 1)
+    dx = torch.full(xshape, float("nan"), device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        ctx.conv3d_dgrad(_padded_dy(dy, k), dev(w), dx)
+    finally:
+        ctx.set_tiling("igemm", None)
+    assert relerr(dx, O.conv3d_dgrad(dy, w, xshape)) < TOL
+
+
 @pytest.mark.parametrize("act", ["relu", "lin"])
 @pytest.mark.parametrize("k", [(1, 3, 3), (1, 1, 1), (2, 4, 4)])
 def test_conv3d_fused_bias_act(ctx, act, k):
