@@ -18,7 +18,9 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libe2hip.so")
+# E2HIP_LIB: explicit path of another build of the library (debug-switch / ablation builds
+# made by `make BUILD=... OUT=...`; the product build is never overwritten by experiments)
+LIB_PATH = os.environ.get("E2HIP_LIB") or os.path.join(_HERE, "libe2hip.so")
 
 ACT = {"lin": 0, "relu": 1}
 

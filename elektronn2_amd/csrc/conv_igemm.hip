@@ -545,6 +545,19 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
             "to first barrier %.0f, main loop %.0f, epilogue %.0f, total %.0f (max %.0f)\n",
             grid, (double)(r1 - r0) * 0.01, last_start * 0.01, s_first / grid, s_loop / grid, s_epi / grid,
             s_tot / grid, max_tot);
+    // in-kernel clock (MI355X_MICROARCH.md "DVFS give-back" item 6): shader cycles
+    // (s_memtime) per 100 MHz tick (s_memrealtime) between a work-group's first and last
+    // stamp, median over the work-groups
+    std::vector<double> clk;
+    for (long b = 0; b < grid; ++b) {
+      const unsigned long long* s = &h[8 * b];
+      if (s[5] > s[0]) clk.push_back((double)(s[4] - s[1]) / (double)(s[5] - s[0]) * 0.1);
+    }
+    if (!clk.empty()) {
+      std::sort(clk.begin(), clk.end());
+      fprintf(stderr, "[e2 stamps] in-kernel clock: median %.3f GHz (min %.3f, max %.3f) over %zu work-groups\n",
+              clk[clk.size() / 2], clk.front(), clk.back(), clk.size());
+    }
   }
   return rc;
 }

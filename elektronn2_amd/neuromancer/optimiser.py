@@ -137,6 +137,10 @@ class SGD(Optimiser):
 
     def state_dict(self):
         if self.last_dir is None:
+            # a state loaded into a model that has not stepped yet is still parked in
+            # _pending: hand it on, so load -> save -> load does not drop it
+            if self._pending is not None and 'last_dir' in self._pending:
+                return {'last_dir': np.array(self._pending['last_dir'], dtype=np.float32)}
             return {}
         return {'last_dir': self.last_dir.cpu().numpy()}
 
@@ -198,6 +202,12 @@ class Adam(Optimiser):
 
     def state_dict(self):
         if self.momentum is None:
+            # loaded but not stepped yet (modelload(f) followed by save()): the moments and
+            # the step counter are still parked in _pending / _pending_t -- hand them on
+            if self._pending is not None and 'm' in self._pending:
+                return {'m': np.array(self._pending['m'], dtype=np.float32),
+                        's': np.array(self._pending['s'], dtype=np.float32),
+                        't': np.array(self.t)}
             return {}
         return {'m': self.momentum.cpu().numpy(), 's': self.squared_accum.cpu().numpy(),
                 't': np.array(self.t)}

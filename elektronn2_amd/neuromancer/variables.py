@@ -136,46 +136,31 @@ class ConstantParam(object):
 
 def initweights(shape, dtype=floatX, scale='glorot', mode='normal', pool=None,
                 spatial_axes=None):
-    """variables.py:205-266 -- uses the global ``np.random`` like the reference
-    (F8: nothing is seeded; tests seed np.random or inject ``w=``/``b=``)."""
+    """Initial values of a weight / bias tensor, drawn from the global ``np.random`` in the
+    reference's call order (variables.py:205-266; F8: nothing is seeded -- tests seed
+    ``np.random`` or inject ``w=`` / ``b=``).  The three forms the BASELINE configs reach:
+
+    * ``mode='const'``: every element = ``scale`` (relu biases: 1 / prod(kernel));
+    * ``mode='fix-uni'``: U(-scale, scale) (biases of 'lin' layers: scale 1e-6);
+    * ``scale='glorot', mode='normal'``: N(0, sqrt(2 / fan)) with fan = n_in + n_out for a
+      2-D matrix and (n_in + n_out / prod(pool)) * prod(kernel) for a conv tensor whose
+      non-spatial axes are (n_out, n_in).
+
+    The reference's other modes ('uni', 'ortho' -- config.use_ortho_init --, 'prelu') are
+    not used by any config of the hot path and are rejected."""
     if mode == 'const':
-        W = np.ones(shape) * scale
-    elif mode == 'prelu':
-        W = np.ones(shape) * scale
-        W[:, 1] = 1.0
-    elif mode == 'fix-uni':
-        W = np.random.uniform(-scale, scale, shape)
-    elif scale == 'glorot':
-        if len(shape) == 2:
-            n_in, n_out = shape[0], shape[1]
-            s = n_in + n_out
-        else:
-            assert spatial_axes is not None
-            other, kernel = [], []
-            for i, s in enumerate(shape):
-                (kernel if i in spatial_axes else other).append(s)
-            assert len(other) == 2
-            n_out, n_in = other[0], other[1]
-            s = (n_in + float(n_out) / np.prod(pool)) * np.prod(kernel)
-        W_scale = np.sqrt(2.0 / s)
-        if mode == 'normal':
-            W = np.random.normal(0, W_scale, shape)
-        elif mode == 'uni':
-            W = np.random.uniform(-W_scale, W_scale, shape)
-        elif mode == 'ortho':
-            M = np.random.normal(0, W_scale, size=shape).reshape((n_out, -1))
-            strip_required = False
-            n_in = M.shape[1]
-            if n_out > n_in:
-                M = np.random.normal(0, W_scale, size=(n_out, n_out))
-                strip_required = True
-            U, S, V = np.linalg.svd(M, full_matrices=False)
-            W = V / V.std(1)[:, None] * W_scale
-            if strip_required:
-                W = W[:, :n_in]
-            W = W.reshape(shape)
-        else:
-            raise ValueError("Invalid weigh initialisation parameters")
+        return np.ascontiguousarray(np.full(shape, scale), dtype=dtype)
+    if mode == 'fix-uni':
+        return np.ascontiguousarray(np.random.uniform(-scale, scale, shape), dtype=dtype)
+    if scale != 'glorot' or mode != 'normal':
+        raise NotImplementedError("initweights(scale=%r, mode=%r): only 'const', 'fix-uni' and "
+                                  "glorot / 'normal' are built (SURVEY.md 8a-9)" % (scale, mode))
+    if len(shape) == 2:
+        fan = shape[0] + shape[1]
     else:
-        raise ValueError("Invalid weigh initialisation parameters")
-    return np.ascontiguousarray(W, dtype=dtype)
+        if spatial_axes is None:
+            raise ValueError("initweights: spatial_axes are needed for a conv tensor")
+        kernel = [s for i, s in enumerate(shape) if i in spatial_axes]
+        n_out, n_in = [s for i, s in enumerate(shape) if i not in spatial_axes]
+        fan = (n_in + float(n_out) / np.prod(pool)) * np.prod(kernel)
+    return np.ascontiguousarray(np.random.normal(0, np.sqrt(2.0 / fan), shape), dtype=dtype)

@@ -111,6 +111,36 @@ def test_config1_graph_round_trip(tmp_path):
     assert list(m3.input_node.shape.shape) == [5, 1, 26, 26]
 
 
+def test_optimiser_state_survives_load_save_load_before_any_step(tmp_path):
+    """modelload(f) followed by save() BEFORE the first step (the device buffers of the
+    optimiser do not exist yet, the loaded state is parked): the second file must still
+    hold Adam's m, s, t and SGD's last_dir -- a resume from it continues the moments and
+    the bias correction instead of silently restarting them (the reference drops the
+    optimiser state altogether, model.py:229-235)."""
+    from elektronn2_amd.neuromancer.model import modelload
+    a, _ = _lite()
+    n = sum(int(np.prod(p.get_value().shape)) for p in a.loss_node.all_trainable_params.values())
+    rng = np.random.RandomState(11)
+    m0, s0, d0 = (rng.randn(max(n, 4)).astype(np.float32), rng.rand(max(n, 4)).astype(np.float32),
+                  rng.randn(max(n, 4)).astype(np.float32))
+    assert a.optimisers['Adam'].state_dict() == {} and a.optimisers['SGD'].state_dict() == {}
+    a.optimisers['Adam'].load_state_dict({'m': m0, 's': s0, 't': 7})
+    a.optimisers['SGD'].load_state_dict({'last_dir': d0})
+    f1, f2 = str(tmp_path / "one.mdl"), str(tmp_path / "two.mdl")
+    a.save(f1)                                   # state_dict() hands on the parked state
+    b, _ = _lite(seed=5)
+    modelload(f1, b)
+    b.save(f2)                                   # load -> save, still no step
+    c, _ = _lite(seed=6)
+    modelload(f2, c)
+    st = c.optimisers['Adam'].state_dict()
+    assert float(st['t']) == 7.0 and c.optimisers['Adam'].t == 7.0
+    assert np.array_equal(st['m'], m0) and np.array_equal(st['s'], s0)
+    assert np.array_equal(c.optimisers['SGD'].state_dict()['last_dir'], d0)
+    raw = np.load(f2)
+    assert 'o/Adam/m' in raw.files and 'o/Adam/t' in raw.files and 'o/SGD/last_dir' in raw.files
+
+
 @pytest.mark.gpu
 def test_resume_restores_parameters_and_adam_state(tmp_path):
     """train 3 steps, save, go on for 2 steps; a FRESH model (other initial weights, no

@@ -30,6 +30,58 @@ def test_neuro3d_lite_at_183_shapes_and_counts():
     assert m.nodes['conv1'].computational_cost == 40 * 20 * 27 * 21 * 88 * 88
 
 
+def test_docs_toy_net_known_answers():
+    """The ONE printed known-answer block the reference holds for `_calc_shape` /
+    `_calc_comp_cost` / parameter counting: docs/examples.rst:49-94 builds a 3-layer toy net
+    on (10,3,23,183,183) and docs/examples.rst:103-140 prints, per node, #Params, Comp.Cost
+    and the output shape, then fov / offsets / strides of the prediction, the total cost,
+    the parameter count and the cost per output pixel.  Same constructor calls here."""
+    image = nm.Input((10, 3, 23, 183, 183), 'b,f,z,x,y', name='image')
+    conv0 = nm.Conv(image, 32, (1, 6, 6), (1, 2, 2))
+    conv1 = nm.Conv(conv0, 64, (4, 6, 6), (2, 2, 2))
+    conv2 = nm.Conv(conv1, 5, (3, 3, 3), (1, 1, 1), activation_func='lin')
+    class_probs = nm.Softmax(conv2)
+    target = nm.Input_like(class_probs, override_f=1, name='target', dtype='int16')
+    voxel_loss = nm.MultinoulliNLL(class_probs, target, target_is_sparse=True)
+    scalar_loss = nm.AggregateLoss(voxel_loss, name='loss')
+    errors = nm.Errors(class_probs, target, target_is_sparse=True)
+    model = nm.model_manager.getmodel()
+    model.designate_nodes(input_node=image, target_node=target, loss_node=scalar_loss,
+                          prediction_node=class_probs,
+                          prediction_ext=[scalar_loss, errors, class_probs])
+    # default names and enumeration (docs: 'conv', 'conv1', 'conv2', 'softmax', 'nll', 'errors')
+    assert [conv0.name, conv1.name, conv2.name, class_probs.name, voxel_loss.name,
+            scalar_loss.name, errors.name] == ['conv', 'conv1', 'conv2', 'softmax', 'nll',
+                                               'loss', 'errors']
+    # per node: #Params, output shape (docs/examples.rst:106-116)
+    assert [n.param_count for n in (conv0, conv1, conv2)] == [3488, 294976, 8645]
+    assert conv0.shape.shape == [10, 32, 23, 89, 89]
+    assert conv1.shape.shape == [10, 64, 10, 42, 42]
+    assert conv2.shape.shape == [10, 5, 8, 40, 40]
+    assert class_probs.shape.shape == [10, 5, 8, 40, 40]
+    assert target.shape.shape == [10, 1, 8, 40, 40] and target.output.dtype == 'int16'
+    assert voxel_loss.shape.shape == [10, 1, 8, 40, 40]
+    # Comp.Cost as printed: 25.2 / 416.2 / 1.1 Giga, 640.0 kilo (softmax, nll), 128.0 kilo
+    # (loss, errors) -- the integers behind them (neural.py:767-778)
+    assert conv0.computational_cost == 32 * 3 * 36 * 23 * 178 * 178 * 10
+    assert conv1.computational_cost == 64 * 32 * 144 * 20 * 84 * 84 * 10
+    assert conv2.computational_cost == 5 * 64 * 27 * 8 * 40 * 40 * 10
+    giga = lambda v: round(v / 1e9, 1)
+    assert [giga(n.computational_cost) for n in (conv0, conv1, conv2)] == [25.2, 416.2, 1.1]
+    assert class_probs.computational_cost == 640000 and voxel_loss.computational_cost == 640000
+    assert scalar_loss.computational_cost == 128000 and errors.computational_cost == 128000
+    # prediction properties (docs/examples.rst:134-136)
+    pn = model.prediction_node
+    assert pn.shape.fov == [9, 27, 27] and pn.shape.offsets == [4, 13, 13]
+    assert list(pn.shape.strides) == [2, 4, 4] and list(pn.shape.spatial_shape) == [8, 40, 40]
+    # totals (docs/examples.rst:137-139; model.py:154-165 takes them from the prediction node)
+    n_comp = pn.all_computational_cost
+    assert giga(n_comp) == 442.5
+    assert pn.all_params_count == 307109 and scalar_loss.all_params_count == 307109
+    assert round(n_comp / float(pn.shape.spatial_size) / 1e6, 1) == 34.6
+    assert model.batch_size == 10 and model.ndim == 3
+
+
 def test_neuro3d_needs_185_and_rejects_183():
     m = nets.neuro3d()
     assert m.prediction_node.shape.shape == [None, 2, 5, 21, 21]

@@ -17,8 +17,9 @@ signed terms) by 1e-3 of its size.  That is a discontinuity of the function, not
 arithmetic error, so the U-Net tests do what the statement "within 1e-4 of the reference"
 can mean there: they read the decisions the HIP forward pass took -- which relu units are
 on (sign of the stored activations) and which element of every Pool window was the
-maximum -- count how many relu decisions differ from float64 (must be < 1e-5 of the units,
-each with a float64 pre-activation below 1e-4 of the layer's scale) and compare the
+maximum -- count how many decisions of EITHER kind differ from float64's (relu: < 1e-5 of
+the units, each with a float64 pre-activation below 1e-4 of the layer's scale; Pool: <= 1e-5
+of the windows, the two candidates within 1e-4 of the layer's scale in float64) and compare the
 gradients with the float64 evaluation THAT TAKES THE SAME DECISIONS -- at 1e-4 (measured:
 6e-6 worst for unet3d, 4.4e-5 for unet3d_lite, against 2e-3 / 2.5e-4 raw).  The raw
 comparison is kept as a second bound: the worst HIP tensor must not be worse than the
@@ -43,13 +44,14 @@ def relmax(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def mirror(model, x, t, dtype, masks=None, pre=None, pool_idx=None):
+def mirror(model, x, t, dtype, masks=None, pre=None, pool_idx=None, pool_in=None):
     """(loss, {param: grad}) of the model's graph evaluated with torch-CPU closed forms
     (the formulas of oracle/torch_step.py).  ``masks``: {node name: bool array}: relu
     units are switched by these decisions instead of by the sign of the pre-activation.
     ``pool_idx``: {Pool node name: argmax indices}: the pooled value is gathered from that
     element of the window instead of from the float64 argmax.
-    ``pre``: dict that receives every relu node's pre-activation."""
+    ``pre``: dict that receives every relu node's pre-activation; ``pool_in``: dict that
+    receives every Pool node's input."""
     P = {k: torch.tensor(p.get_value(), dtype=dtype, requires_grad=True)
          for k, p in model.loss_node.all_trainable_params.items()}
     val, logits = {}, None
@@ -78,6 +80,8 @@ def mirror(model, x, t, dtype, masks=None, pre=None, pool_idx=None):
                 y = F.max_pool3d(y, tuple(node.pool_shape))
             val[node] = act(node, y + b.view(1, -1, 1, 1, 1))
         elif cls == 'Pool':
+            if pool_in is not None:
+                pool_in[node.name] = val[node.parent].detach()
             if pool_idx is not None:
                 u, idx = val[node.parent], torch.as_tensor(pool_idx[node.name])
                 val[node] = u.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
@@ -129,10 +133,50 @@ def hip_pool_decisions(model):
     return out
 
 
+def decisions_bounded(model, pre64, poolin64):
+    """The decisions the HIP pass of the LAST gradient call took, each kind bounded against
+    float64's: (relu masks, pool indices, #relu flips, #relu units, #pool windows decided
+    differently, #pool windows).  A relu unit decided differently must have a float64
+    pre-activation below 1e-4 of its layer's largest; a Pool window whose HIP arg-max is not
+    float64's must hold two candidates whose float64 values differ by less than 1e-4 of
+    the layer's largest value (a tie within rounding, not a wrong maximum); both kinds are
+    capped at 1e-5 of their population."""
+    masks = hip_relu_decisions(model)
+    n_units = n_flip = 0
+    for k, mk in masks.items():
+        p64 = pre64[k].numpy()
+        diff = (mk > 0) != (p64 > 0)
+        n_units += mk.size
+        n_flip += int(diff.sum())
+        if diff.any():       # every unit decided differently sits at f32 noise level
+            assert np.abs(p64[diff]).max() < 1e-4 * np.abs(p64).max(), k
+    assert n_flip < 1e-5 * n_units, (n_flip, n_units)
+    pools = hip_pool_decisions(model)
+    plan = model._grad_func.func
+    n_win = n_pdiff = 0
+    for node in model.loss_node.all_parents.values():
+        if type(node).__name__ != 'Pool':
+            continue
+        u64 = poolin64[node.name]
+        _, idx64 = F.max_pool3d(u64, node.pool_shape, return_indices=True)
+        idx = pools[node.name]
+        differ = idx != idx64
+        n_win += idx.numel()
+        n_pdiff += int(differ.sum())
+        if differ.any():
+            flat = u64.flatten(2)
+            v_hip = flat.gather(2, idx.flatten(2))[differ.flatten(2)]
+            v_64 = flat.gather(2, idx64.flatten(2))[differ.flatten(2)]
+            gap = float((v_64 - v_hip).abs().max())      # (v_64 is the float64 maximum: >= v_hip)
+            assert gap < 1e-4 * float(u64.abs().max()), (node.name, gap)
+    assert n_pdiff <= 1e-5 * n_win, (n_pdiff, n_win)
+    return masks, pools, n_flip, n_units, n_pdiff, n_win
+
+
 def check_against_f64(model, x, t, adam=True, same_decisions=False):
     torch.set_num_threads(16)
-    pre64 = {}
-    L64, G64 = mirror(model, x, t, torch.float64, pre=pre64)
+    pre64, poolin64 = {}, {}
+    L64, G64 = mirror(model, x, t, torch.float64, pre=pre64, pool_in=poolin64)
     loss = float(model.loss(x, t))
     assert abs(loss - L64) / abs(L64) < TOL, (loss, L64)
     g = model.gradients(x, t)
@@ -143,17 +187,7 @@ def check_against_f64(model, x, t, adam=True, same_decisions=False):
             assert raw[nme] < TOL, "%s: %.2e" % (nme, raw[nme])
         print("worst gradient tensor vs float64: %.2e" % max(raw.values()))
     else:
-        masks = hip_relu_decisions(model)
-        n_units = n_flip = 0
-        for k, mk in masks.items():
-            p64 = pre64[k].numpy()
-            diff = (mk > 0) != (p64 > 0)
-            n_units += mk.size
-            n_flip += int(diff.sum())
-            if diff.any():       # every unit decided differently sits at f32 noise level
-                assert np.abs(p64[diff]).max() < 1e-4 * np.abs(p64).max(), k
-        assert n_flip < 1e-5 * n_units, (n_flip, n_units)
-        pools = hip_pool_decisions(model)
+        masks, pools, n_flip, n_units, n_pdiff, n_win = decisions_bounded(model, pre64, poolin64)
         _, G64m = mirror(model, x, t, torch.float64, masks=masks, pool_idx=pools)
         _, G32 = mirror(model, x, t, torch.float32)
         same = {nme: relmax(g[i], G64m[nme]) for i, nme in enumerate(names)}
@@ -161,12 +195,14 @@ def check_against_f64(model, x, t, adam=True, same_decisions=False):
         for nme in names:
             print("%-10s same-decisions %.2e | raw %.2e | f32-CPU raw %.2e" % (nme, same[nme], raw[nme], cpu[nme]))
         print("relu units decided differently from float64: %d of %d" % (n_flip, n_units))
+        print("Pool windows whose arg-max differs from float64's: %d of %d" % (n_pdiff, n_win))
         for nme in names:
             assert same[nme] < TOL, "%s: %.2e vs float64 with the same relu decisions" % (nme, same[nme])
         # with the decisions left free, the worst tensor is off by what a float32 CPU run of the
         # same step is off by (flipped units; both are noise around the same value -- measured
         # 1.31747e-3 against 1.31742e-3 --, hence the factor)
         assert max(raw.values()) <= 1.5 * max(TOL, max(cpu.values())), (max(raw.values()), max(cpu.values()))
+        check_against_f64.f64_state = (pre64, poolin64)
     if not adam:
         return
     # one Adam step from zero state (the reference's rule, float64, on the float64 gradients)
@@ -223,15 +259,25 @@ def test_unet3d_lite_native_size():
     x = rng.rand(1, 1, 22, 140, 140).astype(np.float32)
     t = rng.randint(0, 2, (1, 1, 10, 52, 52)).astype(np.float32)
     check_against_f64(model, x, t, adam=False, same_decisions=True)
-    g = model.gradients(x, t)
+    pre64, poolin64 = check_against_f64.f64_state
+    names = list(model.loss_node.all_trainable_params.keys())
     L0 = float(model.loss(x, t))
-    for _ in range(6):                       # call 2 captures, calls 3.. replay
+    for it in range(4):                      # call 2 captures, calls 3.. replay
         g2 = model.gradients(x, t)
         assert abs(float(model.loss(x, t)) - L0) / L0 < 1e-5
-        for a, b in zip(g, g2):
-            # two runs differ by the order of the f32 atomics, i.e. by a few relu / pool
-            # decisions: the same discontinuity as above (upconv1_w moves by up to 1.3e-3)
-            assert relmax(a, b) < 2e-3
+        if it < 2:
+            continue
+        # A replay differs from the eager run by the order of the f32 atomics, i.e. it may
+        # take a few other relu / pool decisions (upconv1_w then moves by up to 1.3e-3 between
+        # two runs).  So each replay is held to the same standard as the eager run: ITS
+        # decisions bounded against float64's, its gradients within 1e-4 of the float64
+        # evaluation that takes THOSE decisions.
+        masks, pools, n_flip, n_units, n_pdiff, n_win = decisions_bounded(model, pre64, poolin64)
+        _, G64m = mirror(model, x, t, torch.float64, masks=masks, pool_idx=pools)
+        worst = max(relmax(g2[i], G64m[nme]) for i, nme in enumerate(names))
+        print("replay %d: worst gradient tensor vs float64 with its decisions %.2e "
+              "(relu flips %d, pool differences %d)" % (it, worst, n_flip, n_pdiff))
+        assert worst < TOL
 
 
 def test_unet3d_full_native_size():
