@@ -147,7 +147,8 @@ class Model(GraphManager):
                     raise ValueError("FOV is not centered. In_sh=%s, out_sh*strides=%s, "
                                      "diff=%s" % (in_sh, out_sh, diff))
                 self.prediction_node.shape._fov = np.array(diff)     # model.py:151-152
-                self.target_node.shape._fov = np.array(diff)
+                if self.target_node is not None:      # (prediction-only designation: the
+                    self.target_node.shape._fov = np.array(diff)   # reference needs a target here)
             elif not self.prediction_node.shape.fov_all_centered:
                 logger.warning("Not all field of views are centered (odd) "
                                "this might cause problems for many setups")
@@ -362,9 +363,10 @@ class Model(GraphManager):
     def predict(self, *args, **kwargs):
         return self.prediction_node(*args, **kwargs)
 
-    def predict_dense(self, raw_img, as_uint8=False, pad_raw=False):
+    def predict_dense(self, raw_img, as_uint8=False, pad_raw=False, tile_batch=None):
         """model.py:658-713 (without MFP): dense prediction of a whole volume"""
-        return self.prediction_node.predict_dense(raw_img, as_uint8=as_uint8, pad_raw=pad_raw)
+        return self.prediction_node.predict_dense(raw_img, as_uint8=as_uint8, pad_raw=pad_raw,
+                                                  tile_batch=tile_batch)
 
     def predict_ext(self, *args, **kwargs):
         return self._prediction_ext_func(*args, **kwargs)

@@ -21,6 +21,8 @@ import uuid
 from collections import OrderedDict
 from functools import reduce
 
+import os
+
 import numpy as np
 
 from . import graphutils
@@ -360,7 +362,7 @@ class Node(object, metaclass=MetaNode):
         return y
 
     # ---- dense inference (node_basic.py:805-1012) ------------------------------------
-    def predict_dense(self, raw_img, as_uint8=False, pad_raw=False):
+    def predict_dense(self, raw_img, as_uint8=False, pad_raw=False, tile_batch=None):
         """Dense (stride-1) prediction of a whole image / volume by block tiling plus
         stride-offset interleaving: a net with output strides ``s`` predicts every
         s-th voxel, so each block is predicted ``prod(s)`` times from inputs shifted
@@ -371,10 +373,20 @@ class Node(object, metaclass=MetaNode):
         ``(n_lab, z, x, y)`` of extent ``raw - 2*offsets`` (``pad_raw`` mirrors the
         borders first so that the full image domain is predicted).
 
+        Nets with UpConvs (U-Nets): the reference refuses a node whose field of view is
+        unknown (node_basic.py:899-902); the PREDICTION node of a designated model has it
+        (``designate_nodes`` derives fov = input - output extent for UpConv nets,
+        model.py:141-152), and such nets predict at stride 1: plain tiles that overlap by
+        ``input - output`` extent, one pass per tile.
+
         MI355X design: the volume is uploaded once, tiles are device views, each
         shifted patch is copied into the static input buffer of the captured forward
         graph, and the interleave is a strided device copy -- no host round trip per
-        block (the reference pays one per offset)."""
+        block (the reference pays one per offset).  ``tile_batch`` passes (tile x offset)
+        share one launch of the forward graph on the batch axis (None: as many as fit
+        ``E2_DENSE_ACT_GIB`` = 48 GiB of activations, at most 16; nets whose input node
+        fixes the batch size use that size): small tiles alone leave most of the 256 CUs
+        idle, and 288 GB of HBM hold many tiles' activations at once."""
         import time
         import torch
         if self.shape.ndim != 3:
@@ -414,11 +426,24 @@ class Node(object, metaclass=MetaNode):
         t0 = time.time()
         self()                                  # compile (zero-argument call)
         plan = self._output_func.func
-        x_sh = (1, raw.shape[0]) + tuple(int(v) for v in ps)
-        plan.set_inputs([np.zeros(x_sh, np.float32)])      # builds the plan for batch 1
+        n_t = [int(-(-int(pred_sh[i]) // int(prob_sh[i]))) for i in range(3)]
+        sz, sx, sy = (int(v) for v in strides)
+        n_pass = int(np.prod(n_t)) * sz * sx * sy
+        b_decl = inp.shape['b']
+        if b_decl is not None:
+            B = int(b_decl)
+        elif tile_batch is not None:
+            B = max(1, min(int(tile_batch), n_pass))
+        else:
+            # activations of one sample: every node's output, conv nodes twice (pre-activation)
+            per = sum(4.0 * float(np.prod([1 if v is None else v for v in n.shape.shape]))
+                      * (2 if hasattr(n, 'filter_shape') else 1) for n in plan.nodes)
+            budget = float(os.environ.get("E2_DENSE_ACT_GIB", "48")) * 2.0 ** 30
+            B = int(max(1, min(16, n_pass, budget // max(per, 1.0))))
+        x_sh = (B, raw.shape[0]) + tuple(int(v) for v in ps)
+        plan.set_inputs([np.zeros(x_sh, np.float32)])      # builds the plan for batch B
         dev = plan.ctx.device
         # the volume, zero-padded on the far side up to a whole number of blocks
-        n_t = [int(-(-int(pred_sh[i]) // int(prob_sh[i]))) for i in range(3)]
         need = [int((n_t[i] - 1) * prob_sh[i] + tile_sh[i]) for i in range(3)]
         vol = torch.zeros((raw.shape[0],) + tuple(max(need[i], int(raw_sh[i])) for i in range(3)),
                           dtype=torch.float32, device=dev)
@@ -430,7 +455,7 @@ class Node(object, metaclass=MetaNode):
         plan.stream.wait_stream(torch.cuda.current_stream(dev))
         vol.record_stream(plan.stream)
         dense.record_stream(plan.stream)
-        sz, sx, sy = (int(v) for v in strides)
+        passes = []                              # (input view, output view) of every pass
         for zt in range(n_t[0]):
             for xt in range(n_t[1]):
                 for yt in range(n_t[2]):
@@ -440,22 +465,27 @@ class Node(object, metaclass=MetaNode):
                     for oz in range(sz):
                         for ox in range(sx):
                             for oy in range(sy):
-                                with torch.cuda.stream(plan.stream):
-                                    x_buf[0].copy_(vol[:, z0 + oz:z0 + oz + int(ps[0]),
-                                                       x0 + ox:x0 + ox + int(ps[1]),
-                                                       y0 + oy:y0 + oy + int(ps[2])],
-                                                   non_blocking=True)
-                                plan.run()
-                                with torch.cuda.stream(plan.stream):
-                                    block[:, oz::sz, ox::sx, oy::sy] = plan.out[self][0]
+                                passes.append((vol[:, z0 + oz:z0 + oz + int(ps[0]),
+                                                   x0 + ox:x0 + ox + int(ps[1]),
+                                                   y0 + oy:y0 + oy + int(ps[2])],
+                                               block[:, oz::sz, ox::sx, oy::sy]))
+        for i0 in range(0, len(passes), B):
+            chunk = passes[i0:i0 + B]            # (a short last chunk leaves stale slots: ignored)
+            with torch.cuda.stream(plan.stream):
+                for i, (src, _) in enumerate(chunk):
+                    x_buf[i].copy_(src, non_blocking=True)
+            plan.run()
+            with torch.cuda.stream(plan.stream):
+                for i, (_, dst) in enumerate(chunk):
+                    dst.copy_(plan.out[self][i], non_blocking=True)
         plan.stream.synchronize()
         pred = dense[:, :int(pred_sh[0]), :int(pred_sh[1]), :int(pred_sh[2])]
         if as_uint8:
             pred = (pred * 255.0).to(torch.uint8)
         pred = pred.cpu().numpy()
         dt = max(time.time() - t0, 1e-9)
-        logger.info(" Inference speed: %.3f MPix/s, %i blocks x %i offsets, %.2f s",
-                    float(np.prod(pred_sh)) / 1e6 / dt, int(np.prod(n_t)), sz * sx * sy, dt)
+        logger.info(" Inference speed: %.3f MPix/s, %i blocks x %i offsets, %i per launch, %.2f s",
+                    float(np.prod(pred_sh)) / 1e6 / dt, int(np.prod(n_t)), sz * sx * sy, B, dt)
         if strip_z:
             pred = pred[:, 0]
         return pred

@@ -1,0 +1,257 @@
+"""BASELINE configs[4] in the form it is stated -- "examples/unet3d.py bf16 MFMA path +
+MALIS loss, 512^3 tiled dense prediction" -- piece by piece on the GPU:
+
+* tiled dense prediction of a stride-1 UpConv net (plain tiles overlapping by input - output
+  extent, several tiles per launch): tiled == one big pass of the same weights == the
+  float64 CPU evaluation (reference: node_basic.py:860-1012; its refusal at :899-902 hits
+  nodes of unknown fov only -- the prediction node of a designated U-Net has one,
+  model.py:141-152);
+* one training step of ``nets.unet3d`` (examples/unet3d.py:61-100) with bf16 operands
+  against the float64 evaluation, at the bounds of tests/test_bf16_gpu.py;
+* ``MalisNLL`` (loss.py:560-690) on a small U-Net against oracle/malis_oracle.py.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import malis_oracle as MO
+from oracle import torch_step as TS
+
+pytestmark = pytest.mark.gpu
+
+
+def small_unet(in_sp, n_out=2, batch=None, weights=None, n_indep=1):
+    """examples/unet3d_lite.py pattern in miniature: two convs, Pool (1,2,2), two (3,3,3)
+    convs, UpConvMerge (UpConv + Crop + Concat), one conv, 1x1x1 head, Softmax.
+    (z, x, y) -> (z - 4, x - 14, y - 14); x and y must be even after the first two convs."""
+    from elektronn2_amd import neuromancer as nm
+    nm.model_manager.reset()
+    W = (lambda name: {}) if weights is None else (lambda name: dict(w=weights[name + '_w'], b=weights[name + '_b']))
+    inp = nm.Input((batch, 1) + tuple(in_sp), 'b,f,z,x,y', name='raw')
+    c0 = nm.Conv(inp, 8, (1, 3, 3), name='c0', **W('c0'))
+    c1 = nm.Conv(c0, 8, (1, 3, 3), name='c1', **W('c1'))
+    p1 = nm.Pool(c1, (1, 2, 2))
+    c2 = nm.Conv(p1, 16, (3, 3, 3), name='c2', **W('c2'))
+    c3 = nm.Conv(c2, 16, (3, 3, 3), name='c3', **W('c3'))
+    mrg = nm.UpConvMerge(c1, c3, 24)
+    c4 = nm.Conv(mrg, 8, (1, 3, 3), name='c4', **W('c4'))
+    head = nm.Conv(c4, n_out, (1, 1, 1), activation_func='lin', name='head', **W('head'))
+    probs = nm.Softmax(head, n_indep=n_indep)
+    return nm, inp, probs
+
+
+def mirror_forward(model, x, dtype=torch.float64):
+    """probabilities of the model's graph, torch-CPU closed forms (oracle/torch_step.py)"""
+    val = {}
+    P = {k: torch.tensor(p.get_value(), dtype=dtype) for k, p in
+         model.prediction_node.all_params.items()}
+    for node in model.prediction_node.all_parents.values():
+        cls = type(node).__name__
+        if cls == 'Input':
+            val[node] = torch.tensor(x, dtype=dtype)
+        elif cls == 'UpConv':
+            val[node] = TS.upconv_node(val[node.parent], P[node.name + '_w'], P[node.name + '_b'],
+                                       node.pool_shape, node.activation_func)
+        elif cls == 'Conv':
+            val[node] = TS.conv_node(val[node.parent], P[node.name + '_w'], P[node.name + '_b'],
+                                     tuple(node.pool_shape), node.activation_func)
+        elif cls == 'Pool':
+            val[node] = F.max_pool3d(val[node.parent], node.pool_shape)
+        elif cls == 'Crop':
+            v, c = val[node.parent], node.crop
+            val[node] = v[:, :, c[0]:v.shape[2] - c[0], c[1]:v.shape[3] - c[1], c[2]:v.shape[4] - c[2]]
+        elif cls == 'Concat':
+            val[node] = torch.cat([val[q] for q in node.parent], dim=1)
+        elif cls == 'Softmax':
+            return torch.softmax(val[node.parent], dim=1).numpy()
+    raise AssertionError("no Softmax node")
+
+
+@pytest.mark.parametrize("tile_batch", [1, 5, None])
+def test_unet_tiled_dense_prediction(tile_batch):
+    """(1,22,60,62) volume, tiles of (12,36,36) -> (8,22,22): 3 x 3 x 3 tiles (the last
+    ones reach past the volume: zero padding, cut off), 1 / 5 / all-that-fit tiles per
+    launch.  The tile step (8,22,22) is a multiple of the pooling factor (1,2,2), so the
+    tiled prediction must equal ONE pass of the same weights over the whole volume."""
+    nm, inp, probs = small_unet((12, 36, 36))
+    np.random.seed(3)
+    model = nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, prediction_node=probs)
+    assert list(probs.shape.strides) == [1, 1, 1] and probs.shape.offsets == [2, 7, 7]
+    up = [n for n in model.nodes.values() if type(n).__name__ == 'UpConv'][0]
+    assert min(up.shape.fov) < 0            # unknown inside the net, known at the prediction node
+    rng = np.random.RandomState(1)
+    raw = rng.rand(1, 22, 60, 62).astype(np.float32)
+    tiled = model.predict_dense(raw, tile_batch=tile_batch)
+    assert tiled.shape == (2, 18, 46, 48)
+    weights = {k: p.get_value() for k, p in probs.all_params.items()}
+    # one big pass: the same graph built at the volume's size with the same weights
+    nm2, inp2, probs2 = small_unet((22, 60, 62), weights=weights, batch=1)
+    big = nm2.model_manager.getmodel()
+    big.designate_nodes(input_node=inp2, prediction_node=probs2)
+    for k, p in probs2.all_params.items():          # (UpConv is created inside UpConvMerge)
+        p.set_value(weights[k])
+    one = big.predict(raw[None])[0]
+    assert one.shape == tiled.shape
+    assert np.abs(tiled - one).max() < 2e-5
+    ref = mirror_forward(big, raw[None])[0]
+    assert np.abs(one - ref).max() < 2e-5 and np.abs(tiled - ref).max() < 2e-5
+    # per tile against the oracle: the corner tile and the last (zero-padded) one
+    t0 = mirror_forward(model, raw[None, :, :12, :36, :36])[0]
+    assert np.abs(tiled[:, :8, :22, :22] - t0).max() < 2e-5
+    pad = np.zeros((1, 1, 12, 36, 36), np.float32)
+    pad[0, :, :6, :16, :18] = raw[:, 16:, 44:, 44:]
+    t26 = mirror_forward(model, pad)[0]
+    assert np.abs(tiled[:, 16:, 44:, 44:] - t26[:, :2, :2, :4]).max() < 2e-5
+
+
+def test_unet3d_valid_patch_sizes_and_refusal():
+    """examples/unet3d.py net: valid cubes are 92 + 8 n with output extent input - 88; an
+    inner node (unknown fov) refuses predict_dense as the reference does"""
+    from elektronn2_amd import nets, neuromancer as nm
+    nm.model_manager.reset()
+    m = nets.unet3d((None, 1, 92, 100, 108))
+    assert m.prediction_node.shape.spatial_shape == [4, 12, 20]
+    assert m.prediction_node.shape.offsets == [44, 44, 44]
+    inner = [n for n in m.nodes.values() if type(n).__name__ == 'UpConv'][0]
+    with pytest.raises(ValueError, match="UpConvs"):
+        inner.predict_dense(np.zeros((1, 100, 100, 100), np.float32))
+    nm.model_manager.reset()
+    with pytest.raises(ValueError):
+        nets.unet3d((None, 1, 96, 100, 100))
+
+
+@pytest.fixture()
+def process_bf16():
+    import elektronn2_amd
+    elektronn2_amd.set_mfma_dtype('bf16')
+    yield
+    elektronn2_amd.set_mfma_dtype('f32')
+
+
+def test_unet3d_training_step_with_bf16_operands(process_bf16):
+    """nets.unet3d (examples/unet3d.py:61-100) at (92,100,100) -> (4,12,12), bf16 operands
+    in the conv GEMMs, f32 sums: loss within 1e-2 of the float64 evaluation of the f32
+    net (the bound of tests/test_bf16_gpu.py::test_training_step_bf16_close_to_f32_oracle);
+    every gradient tensor points the same way as the float64 one -- cosine > 0.98, i.e. a
+    relative L2 error below 0.2 -- and no element is off by more than 0.3 of the tensor's
+    largest.  (The 7-layer net there holds 0.995 / 0.1; this one is 20 layers deep, its
+    (4,12,12) output gives every gradient only 576 terms per channel, and bf16 rounding
+    moves relu and Pool decisions, which f32 rounding already does for this net -- see
+    tests/test_native_size_gpu.py.  Measured: cosines 0.9868 (conv6) .. 1.0 (head), largest
+    element error 0.23 (upconv2_w); the table is printed.)  Not bit-equal to f32; then Adam
+    steps learn."""
+    from elektronn2_amd import nets, neuromancer as nm
+    from test_native_size_gpu import mirror
+    nm.model_manager.reset()
+    np.random.seed(7)
+    sp = (92, 100, 100)
+    m = nets.unet3d((None, 1) + sp)
+    m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    rng = np.random.RandomState(8)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1, 4, 12, 12)).astype(np.float32)
+    torch.set_num_threads(16)
+    L64, G64 = mirror(m, x, t, torch.float64)
+    loss = float(m.loss(x, t))
+    assert abs(loss - L64) < 1e-2 * abs(L64)
+    assert abs(loss - L64) > 1e-7 * abs(L64)            # not the f32 path
+    g = m.gradients(x, t)
+    names = list(m.loss_node.all_trainable_params.keys())
+    stats = []
+    for gi, nme in zip(g, names):
+        ref = G64[nme]
+        e = float(np.abs(gi - ref).max() / np.abs(ref).max())
+        cos = float((gi * ref).sum() / np.sqrt((gi.astype(np.float64) ** 2).sum() * (ref * ref).sum() + 1e-300))
+        stats.append((nme, e, cos))
+    for nme, e, cos in stats:
+        print("%-12s max-element error %.3f of the tensor's largest, cosine %.5f" % (nme, e, cos))
+    print("unet3d bf16 step: loss rel %.2e, worst gradient tensor %.3f, lowest cosine %.5f"
+          % (abs(loss - L64) / abs(L64), max(s_[1] for s_ in stats), min(s_[2] for s_ in stats)))
+    for nme, e, cos in stats:
+        assert e < 0.3, (nme, e)
+        assert cos > 0.98, (nme, cos)
+    losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+NHOOD = np.array([[-1, 0, 0], [0, -1, 0], [0, 0, -1]], np.int32)
+
+
+def test_malis_nll_on_a_small_unet():
+    """MalisNLL (loss.py:560-690) behind a U-Net (examples/unet3d.py:61-100 pattern: the loss
+    of BASELINE configs[4]): counts == the pinned oracle's on the product's own affinities,
+    loss and every parameter gradient (UpConv's included) within 1e-4 of the float64
+    evaluation with the counts as constants (malisop.py:114-120: zero gradient through
+    them), graph replay == eager."""
+    from elektronn2_amd import malis
+    from elektronn2_amd import neuromancer as nm0
+    sp, osp = (9, 30, 30), (5, 16, 16)
+    np.random.seed(11)
+    nm, inp, probs = small_unet(sp, n_out=6, batch=1, n_indep=3)
+    aff_gt = nm.Input((1, 3) + osp, 'b,f,z,x,y', name='aff_gt', dtype='int16')
+    seg_gt = nm.Input((1, 1) + osp, 'b,f,z,x,y', name='seg_gt', dtype='int16')
+    nll = nm.MalisNLL(probs, aff_gt, seg_gt, NHOOD, unrestrict_neg=True)
+    loss = nm.AggregateLoss(nll)
+    m = nm.model_manager.getmodel()
+    m.designate_nodes(input_node=inp, target_node=aff_gt, loss_node=loss, prediction_node=probs)
+    m.set_opt_meta_params('Adam', dict(lr=2e-3, mom=0.9, beta2=0.999, wd=0.5e-4))
+    assert probs.shape.spatial_shape == list(osp)
+    seg = np.zeros(osp, np.int32)
+    for xx in range(osp[1]):
+        seg[:, xx, :] = 1 + xx // 5
+    seg[0] = 0
+    seg[3, 6:10, 3:8] = 9
+    aff = malis.seg_to_affgraph(seg, NHOOD)[None].astype(np.int16)
+    segb = seg[None, None].astype(np.int16)
+    rng = np.random.RandomState(12)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    pr = m.predict(x)
+    assert np.allclose(pr[0, 0::2] + pr[0, 1::2], 1.0, atol=1e-6)
+    got_loss = float(m.loss(x, aff, segb))
+    pos, neg = MO.malis_weights(pr[0, 1::2], aff[0], segb[0, 0], NHOOD, unrestrict_neg=True)
+    assert np.array_equal(nll.pos_count, pos) and np.array_equal(nll.neg_count, neg)
+    assert pos.sum() > 0 and neg.sum() > 0
+    want_loss, _ = MO.malis_nll(pr[0], pos, neg)
+    assert abs(got_loss - want_loss) <= 1e-4 * abs(want_loss)
+
+    # float64 restatement of the graph with the counts as constants
+    P = {k: torch.tensor(p.get_value(), dtype=torch.float64, requires_grad=True)
+         for k, p in m.loss_node.all_trainable_params.items()}
+    val = {}
+    for node in probs.all_parents.values():
+        cls = type(node).__name__
+        if cls == 'Input':
+            val[node] = torch.tensor(x, dtype=torch.float64)
+        elif cls == 'UpConv':
+            val[node] = TS.upconv_node(val[node.parent], P[node.name + '_w'], P[node.name + '_b'],
+                                       node.pool_shape, node.activation_func)
+        elif cls == 'Conv':
+            val[node] = TS.conv_node(val[node.parent], P[node.name + '_w'], P[node.name + '_b'],
+                                     tuple(node.pool_shape), node.activation_func)
+        elif cls == 'Pool':
+            val[node] = F.max_pool3d(val[node.parent], node.pool_shape)
+        elif cls == 'Crop':
+            v, c = val[node.parent], node.crop
+            val[node] = v[:, :, c[0]:v.shape[2] - c[0], c[1]:v.shape[3] - c[1], c[2]:v.shape[4] - c[2]]
+        elif cls == 'Concat':
+            val[node] = torch.cat([val[q] for q in node.parent], dim=1)
+        elif cls == 'Softmax':
+            lg = val[node.parent][0]
+    p64 = torch.softmax(lg.view(3, 2, *osp), dim=1).view(6, *osp)
+    Pt, Nt = torch.tensor(pos.astype(np.float64)), torch.tensor(neg.astype(np.float64))
+    L = -(Pt * torch.log(p64[1::2] + 1e-5) + Nt * torch.log(p64[0::2] + 1e-5)).sum() / (Pt.sum() + Nt.sum() + 1e-5)
+    L.backward()
+    assert abs(got_loss - float(L.detach())) <= 1e-4 * abs(float(L.detach()))
+    g = m.gradients(x, aff, segb)
+    names = list(m.loss_node.all_trainable_params.keys())
+    assert any('upconv' in n for n in names)
+    for gi, nme in zip(g, names):
+        ref = P[nme].grad.numpy()
+        e = float(np.abs(gi - ref).max() / max(np.abs(ref).max(), 1e-30))
+        assert e < 1e-4, (nme, e)
+    # captured graphs (forward | host Kruskal | backward + update) replay like eager steps
+    l_first = [float(m.trainingstep(x, aff, segb, optimiser='Adam')[0]) for _ in range(12)]
+    assert np.isfinite(l_first).all() and abs(l_first[0] - got_loss) <= 1e-5 * abs(got_loss)
+    assert np.mean(l_first[-3:]) < np.mean(l_first[:3])
