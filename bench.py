@@ -150,6 +150,55 @@ def dense_prediction_bench(args, rank, world):
         print(json.dumps(out))
 
 
+def dense_unet_bench(args, rank, world):
+    """BASELINE configs[4]'s prediction half as stated: tiled dense prediction of a 512^3
+    volume with the examples/unet3d.py net (not the headline metric).  A U-Net predicts at
+    stride 1, so the tiles are plain blocks that overlap by input - output = 88 voxels per
+    axis; the cost per predicted voxel falls with the tile size, and 288 GB of HBM hold
+    the activations of tiles far larger than the (116,132,132) training patch: the net is
+    built at (212,228,228) -> (124,140,140) (valid extents are 92 + 8 n), 4 x 4 x 4 tiles,
+    several per launch.  One "step" = one whole-volume prediction, host volume in, host
+    probabilities out."""
+    from elektronn2_amd import nets
+    patch = tuple(int(v) for v in os.environ.get("E2_DENSE_UNET_PATCH", "212,228,228").split(","))
+    np.random.seed(1)
+    model = nets.unet3d((None, 1) + patch)
+    rng = np.random.RandomState(0)
+    raw = rng.rand(1, 512, 512, 512).astype(np.float32)
+    osp = tuple(model.prediction_node.shape.spatial_shape)
+    model.predict_dense(raw[:, :patch[0], :patch[1], :patch[2] + osp[2]])   # compile (+ tune): 2 tiles
+    steps = max(1, min(args.steps, 2))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pred = model.predict_dense(raw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert pred.shape == (2, 424, 424, 424), pred.shape
+    assert np.isfinite(pred).all() and abs(float(pred.sum(0).mean()) - 1.0) < 1e-4
+    # algorithmic forward FLOPs of one tile (SURVEY.md 8d convention): 2 * MAC per Conv; an
+    # UpConv at its useful cost 2 * Cout * Cin * N_out (its computational_cost counts the
+    # zero-stuffed dense form the CPU reference executes, prod(pool) times that)
+    fwd_gf = sum(2.0 * n.computational_cost / (float(np.prod(n.pool_shape))
+                                               if type(n).__name__ == 'UpConv' else 1.0)
+                 for n in model.nodes.values() if type(n).__name__ in ('Conv', 'UpConv')) / 1e9
+    n_tiles = int(np.prod([-(-424 // o) for o in osp]))
+    peak = PEAK_BF16_MFMA_TFLOPS if args.mfma == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    out = {"metric": "dense_prediction_voxels_per_sec", "value": float(np.prod(pred.shape[1:])) / dt,
+           "unit": "voxels/s", "n_gpus": 1, "steps": steps, "warmup": 1,
+           "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
+           "config": {"workload": "unet3d (examples/unet3d.py) predict_dense (1,512,512,512)->"
+                                  "(2,424,424,424), %d tiles of %s -> %s, host volume in / host "
+                                  "prediction out" % (n_tiles, patch, osp),
+                      "algorithmic_gflop_per_tile": fwd_gf},
+           "roofline": {"bound": "mfma", "achieved": n_tiles * fwd_gf / dt / 1e3,
+                        "peak": peak, "unit": "TFLOP/s",
+                        "frac": n_tiles * fwd_gf / dt / 1e3 / peak, "traffic": None}}
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def warp_bench(args, rank, world):
     """SURVEY 8(f)-1 (not the headline metric): PatchSampler.getbatch at the BASELINE patch
     size -- random warp + perspective, image (23,183,183) trilinear + label target
@@ -296,7 +345,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "warp183", "selftest"])
+    ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "dense512unet", "warp183", "selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--mfma", default=os.environ.get("E2_MFMA_DTYPE", "f32"), choices=["f32", "bf16"],
@@ -341,6 +390,8 @@ def main():
         elektronn2_amd.set_mfma_dtype("bf16")
     if args.workload in ("dense183", "dense183mfp"):
         return dense_prediction_bench(args, rank, world)
+    if args.workload == "dense512unet":
+        return dense_unet_bench(args, rank, world)
     if args.workload == "warp183":
         return warp_bench(args, rank, world)
     builder, sp, gf_table = WORKLOADS[args.workload]
