@@ -40,20 +40,61 @@ WORKLOADS = {
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: fp32 matrix peak (spec; 155 measured)
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak (--mfma bf16 only)
-# HBM-side bytes per step from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-# --pmc WRITE_SIZE runs of this script, profiles/r01_e_pmc_traffic.csv):
-# 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md "HBM") + WRITE_SIZE.
-# It cannot be measured inside the timed run; null for workloads not profiled.
-PMC_TRAFFIC_BYTES = {"lite183": (2 * 650.7 + 400.8) * 1024 * 1024,
-                     "full185": (2 * 552.7 + 551.5) * 1024 * 1024,
-                     "unet132": (2 * 10933.3 + 5241.1) * 1024 * 1024}
-PMC_TRAFFIC_SOURCE = "profiles/r02_v_bench_<workload>_pmc_traffic.csv (unet132: r02_m)"
-# Matrix-pipe utilisation of the whole step from the rocprofv3 PMC pass of this script
-# (tools/gpu_round.sh -> tools/pmc_mfma.py): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel
-# cycles at the clock the chip held), summed over the kernels of a step; None = not profiled.
-PMC_MFMA_UTIL = {"lite183": 0.4797, "full185": 0.3852, "unet132": 0.5797}
-PMC_MFMA_SOURCE = ("profiles/r02_v_bench_<workload>_pmc_mfma.csv (unet132: r02_m; eager launches under rocprofv3; executed "
-                   "MFMA FLOPs / algorithmic: 1.25 lite183, 1.32 full185, 1.14 unet132)")
+# roofline.traffic / roofline.mfma_util cannot be measured inside the timed run (PMC passes
+# serialise the kernels): they are READ, at run time, from the rocprofv3 PMC summaries of this
+# script that profiles/CURRENT.json names for the workload (tools/gpu_round.sh ->
+# tools/adopt_profile.py), and only while the kernel sources and the shipped tilings are
+# still the ones that were profiled (sources_sha16) -- otherwise null + "profile_stale".
+#   traffic   = HBM-side bytes per step: 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md
+#               "HBM") + WRITE_SIZE, separate --pmc passes, <tag>_bench_<workload>_pmc_traffic.csv
+#   mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.4 GHz), summed over the
+#               kernels of a step (<tag>_bench_<workload>_pmc_mfma.csv, tools/pmc_mfma.py): the
+#               share of the chip's matrix-pipe cycles AT THE PEAK CLOCK in which an MFMA
+#               executed.  (Round 2 divided by GRBM_GUI_ACTIVE / 8 instead, which reads 4-7 %
+#               high on dispatches of 0.1-0.2 ms -- the guide says so, tools/clock_check.py
+#               measured it: in-kernel clock 2.35-2.38 GHz, GRBM-derived 2.47-2.55.)
+
+
+def sources_sha16():
+    """identity of what a profile describes: kernel sources + shipped tilings"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "elektronn2_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.hpp"))
+                    + [os.path.join(ROOT, "elektronn2_amd", "tuned.json")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def recorded_profile(workload):
+    """{"traffic", "mfma_util", "profile", "profile_stale"} from profiles/CURRENT.json"""
+    import csv
+    out = {"traffic": None, "mfma_util": None, "profile": None, "profile_stale": None}
+    try:
+        cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json"))).get(workload)
+    except Exception:
+        cur = None
+    if not cur:
+        return out
+    base = os.path.join(ROOT, "profiles", "%s_bench_%s" % (cur["tag"], workload))
+    out["profile"] = "profiles/%s_bench_%s_{pmc_traffic,pmc_mfma,kernel_stats}.csv" % (cur["tag"], workload)
+    out["profile_stale"] = cur.get("sources_sha16") != sources_sha16()
+    if out["profile_stale"]:
+        return out
+    try:
+        tot = {}
+        for r in csv.reader(open(base + "_pmc_traffic.csv")):
+            if len(r) >= 6 and r[1] == "TOTAL":
+                tot[r[0]] = float(r[5])                     # MiB per step
+        out["traffic"] = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 * 1024
+        for r in csv.reader(open(base + "_pmc_mfma.csv")):
+            if r and r[0].startswith("TOTAL"):
+                out["mfma_util"] = float(r[3])
+    except Exception:
+        pass
+    return out
 
 
 def algorithmic_gflop(model):
@@ -348,11 +389,16 @@ def main():
     ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "dense512unet", "warp183", "selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sources-sha", action="store_true",
+                    help="print the identity of the kernel sources + shipped tilings and exit")
     ap.add_argument("--mfma", default=os.environ.get("E2_MFMA_DTYPE", "f32"), choices=["f32", "bf16"],
                     help="arithmetic of the conv GEMMs: f32 (default, the BASELINE metric) or "
                          "bf16 operands with f32 sums (SURVEY.md 8f-3; a separate, looser-"
                          "tolerance path -- never the headline number)")
     args = ap.parse_args()
+    if args.sources_sha:
+        print(sources_sha16())
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: be the launcher (nothing has touched the GPU yet)
@@ -477,6 +523,7 @@ def main():
     value = vox_per_step * args.steps / dt
     achieved = gflop / (dev_ms * 1e-3) / 1e3            # TFLOP/s per GPU
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    prof = recorded_profile(args.workload)
     out = {
         "metric": "training_input_voxels_per_sec",
         "value": value,
@@ -499,11 +546,13 @@ def main():
                    "hipgraph": bool(plan.use_graph), "final_loss": loss},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": None if bf16 else PMC_TRAFFIC_BYTES.get(args.workload),
-                     "traffic_unit": "B/step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC, %s)"
-                                     % PMC_TRAFFIC_SOURCE,
-                     "mfma_util": None if bf16 else PMC_MFMA_UTIL.get(args.workload),
-                     "mfma_util_source": PMC_MFMA_SOURCE,
+                     "traffic": None if bf16 else prof["traffic"],
+                     "traffic_unit": "B/step: 2*FETCH_SIZE + WRITE_SIZE of the recorded rocprofv3 "
+                                     "PMC passes (not measured in this run)",
+                     "mfma_util": None if bf16 else prof["mfma_util"],
+                     "mfma_util_unit": "MFMA-busy cycles / (1024 SIMDs x kernel time x 2.4 GHz), "
+                                       "recorded PMC pass (not measured in this run)",
+                     "profile": prof["profile"], "profile_stale": prof["profile_stale"],
                      "kernel": "training step (hipGraph): conv3d igemm fwd/dgrad/wgrad on "
                                + ("v_mfma_f32_16x16x16_bf16 / 16x16x32_bf16" if bf16 else
                                   "v_mfma_f32_16x16x4_f32") + " + pointwise + Adam",

@@ -87,6 +87,13 @@ def _load():
         "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp,
                                             C.c_void_p, C.c_size_t]),
         "e2_pool_bias_act_fwd": (C.c_int, [vp, P5, fp, i, i, i, i, P5]),
+        "e2_conv3d_fwd_packed_parts": (C.c_int, [vp, P5, vp, i, i, i, i, P5, C.c_int64, i,
+                                                 C.POINTER(C.c_int)]),
+        "e2_conv3d_dgrad_packed_parts": (C.c_int, [vp, P5, vp, i, i, i, i, P5, C.c_int64, i,
+                                                   C.POINTER(C.c_int)]),
+        "e2_pool_bias_act_fwd_parts": (C.c_int, [vp, P5, C.c_int64, i, fp, i, i, i, i, P5]),
+        "e2_pool_bias_act_bwd_parts": (C.c_int, [vp, P5, C.c_int64, i, P5, fp, i, i, i, i, P5, fp]),
+        "e2_bias_act_bwd_out_parts": (C.c_int, [vp, P5, C.c_int64, i, P5, i, P5, fp]),
         "e2_pool_bias_act_bwd": (C.c_int, [vp, P5, P5, fp, i, i, i, i, P5, fp]),
         "e2_maxpool3d_fwd": (C.c_int, [vp, P5, i, i, i, P5]),
         "e2_maxpool3d_bwd": (C.c_int, [vp, P5, P5, i, i, i, P5, i]),
@@ -244,6 +251,45 @@ class Context:
         _chk(_lib.e2_conv3d_dgrad_packed(self.h, C.byref(t5(dy_pad)),
                                          C.c_void_p(wp.data_ptr()), cin, k[0], k[1], k[2],
                                          C.byref(t5(dx))), "e2_conv3d_dgrad_packed")
+
+    # ---- split-K with partial-sum stores (e2hip.h "split-K without atomics") ----------------
+    def conv3d_fwd_packed_parts(self, x, wp, cout, k, y_parts):
+        """y_parts: (P, n, cout, d, h, w) dense slabs; returns the number of parts written
+        (1: y_parts[0] is the complete result)"""
+        n = C.c_int(0)
+        _chk(_lib.e2_conv3d_fwd_packed_parts(self.h, C.byref(t5(x)), C.c_void_p(wp.data_ptr()),
+                                             cout, k[0], k[1], k[2], C.byref(t5(y_parts[0])),
+                                             y_parts.stride(0), y_parts.shape[0], C.byref(n)),
+             "e2_conv3d_fwd_packed_parts")
+        return n.value
+
+    def conv3d_dgrad_packed_parts(self, dy_pad, wp, cin, k, dx_parts):
+        n = C.c_int(0)
+        _chk(_lib.e2_conv3d_dgrad_packed_parts(self.h, C.byref(t5(dy_pad)),
+                                               C.c_void_p(wp.data_ptr()), cin, k[0], k[1], k[2],
+                                               C.byref(t5(dx_parts[0])), dx_parts.stride(0),
+                                               dx_parts.shape[0], C.byref(n)),
+             "e2_conv3d_dgrad_packed_parts")
+        return n.value
+
+    def pool_bias_act_fwd_parts(self, y_parts, nparts, bias, pool, act, out):
+        _chk(_lib.e2_pool_bias_act_fwd_parts(self.h, C.byref(t5(y_parts[0])), y_parts.stride(0),
+                                             nparts, _fp(bias), pool[0], pool[1], pool[2],
+                                             ACT[act], C.byref(t5(out))),
+             "e2_pool_bias_act_fwd_parts")
+
+    def pool_bias_act_bwd_parts(self, dout_parts, nparts, y, bias, pool, act, dy, dbias):
+        _chk(_lib.e2_pool_bias_act_bwd_parts(self.h, C.byref(t5(dout_parts[0])),
+                                             dout_parts.stride(0), nparts, C.byref(t5(y)),
+                                             _fp(bias), pool[0], pool[1], pool[2], ACT[act],
+                                             C.byref(t5(dy)), _fp(dbias)),
+             "e2_pool_bias_act_bwd_parts")
+
+    def bias_act_bwd_out_parts(self, dout_parts, nparts, out, act, dy, dbias):
+        _chk(_lib.e2_bias_act_bwd_out_parts(self.h, C.byref(t5(dout_parts[0])),
+                                            dout_parts.stride(0), nparts, C.byref(t5(out)),
+                                            ACT[act], C.byref(t5(dy)), _fp(dbias)),
+             "e2_bias_act_bwd_out_parts")
 
     def conv3d_fwd_packed_act(self, x, wp, cout, k, bias, act, out):
         """conv + bias + activation in one launch (layers that do not pool)"""

@@ -160,8 +160,9 @@ extern "C" int e2_conv3d_pack(e2_ctx* ctx, const float* w, int cout, int cin, in
                           ciP, coP, 1, 1);
 }
 
-extern "C" int e2_conv3d_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void* wp,
-                                    int cout, int kd, int kh, int kw, const e2_tensor5* y) {
+static int conv_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void* wp, int cout, int kd,
+                           int kh, int kw, const e2_tensor5* y, int64_t part_stride,
+                           int max_parts, int* nparts) {
   E2_REQUIRE(ctx && wp, "conv3d_fwd: null argument");
   if (int rc = view_ok(x, "conv3d_fwd x")) return rc;
   if (int rc = view_ok(y, "conv3d_fwd y")) return rc;
@@ -179,7 +180,19 @@ extern "C" int e2_conv3d_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void
   a.osN = y->sn; a.osC = y->sc; a.osZ = y->sd; a.osY = y->sh;
   e2i_pack_dims(cout, x->c, &a.ciP, &a.coP);
   a.upz = a.upy = a.upx = 1;
+  a.parts_max = max_parts; a.part_stride = part_stride; a.nparts = nparts;
   return e2i_igemm_conv(ctx, a);
+}
+extern "C" int e2_conv3d_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void* wp,
+                                    int cout, int kd, int kh, int kw, const e2_tensor5* y) {
+  return conv_fwd_packed(ctx, x, wp, cout, kd, kh, kw, y, 0, 0, nullptr);
+}
+extern "C" int e2_conv3d_fwd_packed_parts(e2_ctx* ctx, const e2_tensor5* x, const void* wp,
+                                          int cout, int kd, int kh, int kw, const e2_tensor5* y,
+                                          int64_t part_stride, int max_parts, int* nparts) {
+  E2_REQUIRE(nparts && max_parts >= 1 && (max_parts == 1 || part_stride > 0),
+             "conv3d_fwd_parts: bad parts arguments");
+  return conv_fwd_packed(ctx, x, wp, cout, kd, kh, kw, y, part_stride, max_parts, nparts);
 }
 
 extern "C" int e2_conv3d_fwd_packed_act(e2_ctx* ctx, const e2_tensor5* x, const void* wp,
@@ -210,9 +223,9 @@ extern "C" int e2_conv3d_fwd_packed_act(e2_ctx* ctx, const e2_tensor5* x, const 
   return e2i_igemm_conv(ctx, a);
 }
 
-extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, const void* wp,
-                                      int cin, int kd, int kh, int kw,
-                                      const e2_tensor5* dx) {
+static int conv_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, const void* wp, int cin,
+                             int kd, int kh, int kw, const e2_tensor5* dx, int64_t part_stride,
+                             int max_parts, int* nparts) {
   E2_REQUIRE(ctx && wp, "conv3d_dgrad: null argument");
   if (int rc = view_ok(dy_pad, "conv3d_dgrad dy_pad")) return rc;
   if (int rc = view_ok(dx, "conv3d_dgrad dx")) return rc;
@@ -233,7 +246,21 @@ extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, con
   e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
   a.upz = a.upy = a.upx = 1;
   a.zpad = kd - 1;
+  a.parts_max = max_parts; a.part_stride = part_stride; a.nparts = nparts;
   return e2i_igemm_conv(ctx, a);
+}
+extern "C" int e2_conv3d_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, const void* wp,
+                                      int cin, int kd, int kh, int kw,
+                                      const e2_tensor5* dx) {
+  return conv_dgrad_packed(ctx, dy_pad, wp, cin, kd, kh, kw, dx, 0, 0, nullptr);
+}
+extern "C" int e2_conv3d_dgrad_packed_parts(e2_ctx* ctx, const e2_tensor5* dy_pad,
+                                            const void* wp, int cin, int kd, int kh, int kw,
+                                            const e2_tensor5* dx, int64_t part_stride,
+                                            int max_parts, int* nparts) {
+  E2_REQUIRE(nparts && max_parts >= 1 && (max_parts == 1 || part_stride > 0),
+             "conv3d_dgrad_parts: bad parts arguments");
+  return conv_dgrad_packed(ctx, dy_pad, wp, cin, kd, kh, kw, dx, part_stride, max_parts, nparts);
 }
 
 extern "C" int e2_conv3d_dgrad_packed_actbwd(e2_ctx* ctx, const e2_tensor5* dy_pad,

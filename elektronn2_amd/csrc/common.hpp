@@ -100,6 +100,12 @@ struct IgemmArgs {
   // data gradient: `in` is dy zero-padded by kd - 1 planes at both ends of z (the contract
   // of e2_conv3d_dgrad*): the kernels skip the tap planes that read only that border
   int zpad = 0;
+  // split-K with partial-sum stores instead of atomics (e2_conv3d_*_packed_parts): up to
+  // parts_max splits, split s stores to out + s * part_stride; *nparts receives the number
+  // of parts written (1: `out` holds the complete result).  parts_max <= 1: off.
+  int parts_max = 0;
+  int64_t part_stride = 0;
+  int* nparts = nullptr;
 };
 int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
 int e2i_pw_conv(e2_ctx*, const IgemmArgs& a, int MT, int NT);   // 1x1x1 GEMM with LDS-staged weights (conv_pw.hip)

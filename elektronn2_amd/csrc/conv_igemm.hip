@@ -397,10 +397,14 @@ static int igemm4_conv(e2_ctx* ctx, const IgemmArgs& a, const IgemmCfg& c) {
   {   // K splits: every split gets at least one chunk
     const int nChunks = a.kd * p.nChunkC;
     int sk = a.bias ? 1 : std::min(c.SK, nChunks);
+    if (a.parts_max > 1) sk = std::min(sk, a.parts_max);
     const int per = e2_cdiv(nChunks, sk);
     p.splitK = e2_cdiv(nChunks, per);
   }
-  p.atomic = (p.splitK > 1) ? 1 : 0;
+  const bool parts4 = a.parts_max > 1 && p.splitK > 1 && a.upz * a.upy * a.upx == 1;
+  p.parts = parts4 ? 1 : 0; p.partStride = parts4 ? (long)a.part_stride : 0;
+  if (a.nparts) *a.nparts = parts4 ? p.splitK : 1;
+  p.atomic = (p.splitK > 1 && !parts4) ? 1 : 0;
   p.upz = a.upz; p.upy = a.upy; p.upx = a.upx; p.zpad = a.zpad;
   p.bufFloats = c.CC * p.Lpad + 64;
   p.stamps = nullptr; p.bias = a.bias; p.act = a.act; p.bf16 = 0; p.wide = 0;
@@ -438,6 +442,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   E2_REQUIRE(ok, "igemm: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d W=%d)", a.Cin,
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
   if (a.gm_done) *a.gm_done = 0;
+  if (a.nparts) *a.nparts = 1;
   if (c.kind == 4) return igemm4_conv(ctx, a, c);
   if (c.kind == 1) {                                             // "1,MT,NT": conv_pw.hip
     E2_REQUIRE(!ctx->mfma_bf16, "pointwise conv: an f32 kernel, not offered in bf16 mode");
@@ -468,7 +473,12 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), c.MT);
   p.nChunkC = e2_cdiv(a.Cin, c.CC);
   p.splitK = a.bias ? 1 : std::min(c.SK, a.kd * p.nChunkC);     // the fused epilogue cannot split K
-  p.atomic = (p.splitK > 1) ? 1 : 0;
+  const bool parts = a.parts_max > 1 && a.upz * a.upy * a.upx == 1;
+  if (parts) p.splitK = std::min(p.splitK, a.parts_max);
+  p.parts = (parts && p.splitK > 1) ? 1 : 0;
+  p.partStride = p.parts ? (long)a.part_stride : 0;
+  if (a.nparts) *a.nparts = p.parts ? p.splitK : 1;
+  p.atomic = (p.splitK > 1 && !p.parts) ? 1 : 0;
   p.upz = a.upz; p.upy = a.upy; p.upx = a.upx; p.zpad = a.zpad;
   p.bufFloats = (int)buf_floats(a, c.MT, BN, c.CC);
   E2_REQUIRE(p.nMT * 16 * c.MT <= a.coP, "igemm: packed coP too small");
@@ -478,7 +488,7 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   E2_REQUIRE(lds <= 160 * 1024, "igemm: forced tiling needs %zu B of LDS", lds);
   // wide epilogue (fast path): dense output rows, plain stores
   const size_t tile_lds = (size_t)4 * 16 * c.MT * (16 * c.NT + 4) * 4 + (gm ? 4 * 16 * c.MT * 4 : 0);
-  p.wide = (fast && p.splitK == 1 && a.upz * a.upy * a.upx == 1 && (a.osY == a.Wo || a.Wo >= 4) &&
+  p.wide = (fast && (p.splitK == 1 || p.parts) && a.upz * a.upy * a.upx == 1 && (a.osY == a.Wo || a.Wo >= 4) &&
             std::max(lds, tile_lds) <= 160 * 1024 && !e2_dbg_env("E2_IGEMM_NARROW")) ? 1 : 0;
   if (p.wide) lds = std::max(lds, tile_lds);
   p.bias = a.bias; p.act = a.act;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void igemm_generic_kernel(IgemmP p) {
   e2_chunk_range(p, z, c_lo, c_hi);             // (data gradient: border-only tap planes skipped)
   const int per = (c_hi - c_lo + p.splitK - 1) / p.splitK;
   const int cb = c_lo + ks * per, ce = min(cb + per, c_hi);
-  if (cb >= ce) return;
+  if (cb >= ce && !p.parts) return;
   const int aBase = qd * BMpad + l15;
   const int nRows = p.THW * CC;
   const int nPieces = (nRows * BMp4 + 63) >> 6;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void igemm_generic_kernel(IgemmP p) {
         if (co >= p.Cout) continue;
         float* dst;
         if (R == 1) {
-          dst = p.out + (long)n * p.osN + (long)co * p.osC + (long)z * p.osZ +
+          dst = p.out + (long)ks * p.partStride + (long)n * p.osN + (long)co * p.osC + (long)z * p.osZ +
                 (long)r * p.osY + c;
         } else {
           const int cr = co / R, sub = co - cr * R;

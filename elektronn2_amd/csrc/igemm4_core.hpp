@@ -260,7 +260,8 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
 
   for (int t = blockIdx.x; t < x.tilesTotal; t += gridDim.x) {
     G4Tile T; decode(t, T);
-    if (T.cb >= T.ce) continue;                       // empty split of a clipped K range
+    const bool has_items = T.cb < T.ce;
+    if (!has_items && !p.parts) continue;             // empty split of a clipped K range
     const int m0w = T.mt * BM + wm * (4 * MG);        // the wave's first output channel
     const int qw = T.q0 + wn * (64 * NT);             // ... and first position
     unsigned posoffB[NT];
@@ -315,11 +316,13 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
         fty = nty; fc = nfc; fch = nch;                                   \
       }                                                                   \
     }
+    if (has_items) {                         // (partial-sum stores: an empty split stores zeros)
     __syncthreads();                         // the tile's first item (and the one after it) landed
     set_addr();
     g4_reads<MG, NT, KW, U, 0, RALL>(g0, ad);
     E2_WAIT()
     g0.touch();
+    }
     int cs = 0;                              // steps computed in the current chunk
     for (int s = 0; s < total; s += 2) {
       E2_NEXT()
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(1024, 1) void igemm4_kernel(IgemmP p, Igemm4Extra x
       const int r = qq / p.Wo, c = qq - r * p.Wo;
       ooff[nb] = (unsigned)(r * p.upy) * (unsigned)p.osY + (unsigned)(c * p.upx);
     }
-    float* ob = p.out + (long)T.n * p.osN + (long)(T.z * p.upz) * p.osZ;
+    float* ob = p.out + (long)T.ks * p.partStride + (long)T.n * p.osN + (long)(T.z * p.upz) * p.osZ;
 #pragma unroll
     for (int g = 0; g < MG; ++g) {
 #pragma unroll

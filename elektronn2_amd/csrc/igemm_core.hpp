@@ -49,6 +49,12 @@ struct IgemmP {
   // plane z is skipped (exact: it would add 0 * w); the K range of the tile shrinks to
   // dz in [max(0, zpad - z), min(kd - 1, Din - 1 - zpad - z)].
   int zpad = 0;
+  // split-K WITHOUT atomics: split ks stores its partial sums (plain stores, any epilogue)
+  // to out + ks * partStride; the consumer's pointwise kernel adds the parts up
+  // (e2_pool_bias_act_fwd_parts / _bwd_parts).  No zero fill; a split whose K range is
+  // empty (clipped border plane) stores zeros.
+  int parts = 0;
+  long partStride = 0;
 };
 
 // K range (in channel chunks) of output plane z: [lo, hi)
@@ -304,8 +310,9 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   e2_chunk_range(p, z, c_lo, c_hi);
   const int per = (c_hi - c_lo + p.splitK - 1) / p.splitK;
   const int cb = c_lo + ks * per, ce = min(cb + per, c_hi);
-  if (cb >= ce) return;        // (split-K over a clipped range: nothing left for this split;
-                               //  every wave decides alike, the output is accumulated atomically)
+  if (cb >= ce && !p.parts) return;   // (split-K over a clipped range: nothing left for this
+                               //  split; every wave decides alike.  Atomic accumulation: nothing
+                               //  to add; partial-sum stores: the epilogue stores zeros)
   const int nCG = (p.Cin + 3) >> 2;          // channel groups that carry data
   const int CG = CC >> 2;
 
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
     if (!dense) { ro = qw / p.Wo; cq = qw - ro * p.Wo; }
     const long ooff = dense ? (long)qw : (long)ro * p.osY + cq;
     const bool whole = (qw + 3 < p.Q) && (dense || cq + 3 < p.Wo);
-    float* ob = p.out + (long)n * p.osN + (long)z * p.osZ;
+    float* ob = p.out + (long)ks * p.partStride + (long)n * p.osN + (long)z * p.osZ;
     const float* gb = (p.gm && p.gm_src) ? p.gm_src + (long)n * p.gsN + (long)z * p.gsZ + qw : nullptr;
     float* bsum = smem + 4 * (16 * MT * STR);      // [4 waves][16*MT rows], behind the tiles
 #pragma unroll
@@ -600,8 +607,8 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
         if (co >= p.Cout) continue;
         float* dst;
         if (R == 1) {
-          dst = p.out + (long)n * p.osN + (long)co * p.osC + (long)z * p.osZ +
-                (long)r * p.osY + c;
+          dst = p.out + (long)ks * p.partStride + (long)n * p.osN + (long)co * p.osC +
+                (long)z * p.osZ + (long)r * p.osY + c;
         } else {
           const int cr = co / R, sub = co - cr * R;
           const int rz = sub / (p.upy * p.upx);

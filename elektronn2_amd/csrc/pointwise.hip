@@ -244,7 +244,8 @@ __device__ __forceinline__ void pw_storeN(float* p, int nv, const float (&g)[NO]
 template <int PZ, int PY, int PX, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const float* __restrict__ bias,
                                                              int act, View5 out, FastDiv dvw,
-                                                             FastDiv dh, unsigned chunk) {
+                                                             FastDiv dh, unsigned chunk,
+                                                             int nparts, long pstride) {
   static_assert(PX == 1 || PX == 2, "x windows of 1 or 2");
   constexpr int NO = 4 / PX;                                  // pooled outputs per thread
   const unsigned VW = ((unsigned)out.w + NO - 1) / NO;        // pieces per output row
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const floa
   const unsigned s1 = min(s0 + chunk, S);
   const int c = blockIdx.y, n = blockIdx.z;
   const float bv = HAS_BIAS ? bias[c] : 0.f;
-  const float* __restrict__ ybase = y.p + (long)n * y.sn + (long)c * y.sc;
+  float* ybase = y.p + (long)n * y.sn + (long)c * y.sc;
   float* __restrict__ obase = out.p + (long)n * out.sn + (long)c * out.sc;
 #pragma unroll 2
   for (unsigned s = s0 + threadIdx.x; s < s1; s += 256) {
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const floa
     const unsigned zo = fdiv(t, dh);
     const unsigned yo = t - zo * out.h;
     const int nvo = min(NO, out.w - (int)xo);
-    const float* src = ybase + (long)(zo * PZ) * y.sd + (long)(yo * PY) * y.sh + xo * PX;
+    float* src = ybase + (long)(zo * PZ) * y.sd + (long)(yo * PY) * y.sh + xo * PX;
     float m[NO];
 #pragma unroll
     for (int j = 0; j < NO; ++j) m[j] = -INFINITY;
@@ -271,7 +272,17 @@ __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const floa
 #pragma unroll
       for (int b = 0; b < PY; ++b) {
         float w[4];
-        pw_load4(src + a * y.sd + b * y.sh, nvo * PX, 0.f, w);
+        float* row = src + a * y.sd + b * y.sh;
+        pw_load4(row, nvo * PX, 0.f, w);
+        if (nparts > 1) {      // split-K partial sums: add them up, leave the sum in part 0
+          for (int q = 1; q < nparts; ++q) {
+            float u[4];
+            pw_load4(row + q * pstride, nvo * PX, 0.f, u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] += u[e];
+          }
+          pw_store4(row, nvo * PX, w);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) m[e / PX] = fmaxf(m[e / PX], w[e]);
       }
@@ -290,7 +301,8 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
                                                              int act, View5 dy,
                                                              float* __restrict__ dbias,
                                                              int accumulate, FastDiv dvw,
-                                                             FastDiv dh, unsigned chunk) {
+                                                             FastDiv dh, unsigned chunk,
+                                                             int gparts, long gstride) {
   static_assert(PX == 1 || PX == 2, "x windows of 1 or 2");
   constexpr int NO = 4 / PX;
   __shared__ float red[4];
@@ -327,6 +339,12 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
       }
     float g[NO];
     pw_loadN<NO>(gbase + (long)zo * dout.sd + (long)yo * dout.sh + xo, nvo, g);
+    for (int q = 1; q < gparts; ++q) {      // dout arrives as split-K partial sums
+      float u[NO];
+      pw_loadN<NO>(gbase + q * gstride + (long)zo * dout.sd + (long)yo * dout.sh + xo, nvo, u);
+#pragma unroll
+      for (int j = 0; j < NO; ++j) g[j] += u[j];
+    }
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
       if (act == E2_ACT_RELU) {
@@ -366,7 +384,8 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
 __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out, int act,
                                                           View5 dy, float* __restrict__ dbias,
                                                           FastDiv dvw, FastDiv dh,
-                                                          unsigned chunk) {
+                                                          unsigned chunk, int gparts,
+                                                          long gstride) {
   __shared__ float red[4];
   const unsigned VW = (unsigned)(dout.w + 3) >> 2;            // 4-element pieces per row
   const unsigned S = (unsigned)dout.d * dout.h * VW;
@@ -395,6 +414,12 @@ __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out,
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { g[e] = e < nv ? gp[e] : 0.f; o[e] = e < nv ? op[e] : 1.f; }
+    }
+    for (int q = 1; q < gparts; ++q) {      // dout arrives as split-K partial sums
+      float u[4];
+      pw_load4(gp + q * gstride, nv, 0.f, u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] += u[e];
     }
     if (act == E2_ACT_RELU) {
 #pragma unroll
@@ -767,31 +792,32 @@ static dim3 grid_chunked(const View5& v, unsigned chunk) {
 // the grid of the fixed-window kernels counts pieces of 4 input x (4 / PX outputs)
 template <int PZ, int PY, int PX>
 static void launch_pool_fwd_fixed(e2_ctx* ctx, const View5& vy, const float* bias, int act,
-                                  const View5& vo) {
+                                  const View5& vo, int nparts = 1, long pstride = 0) {
   View5 vq = vo; vq.w = (vo.w + 4 / PX - 1) / (4 / PX);
   const unsigned chunk = pw_chunk(vq);
   const dim3 g = grid_chunked(vq, chunk);
   const FastDiv dvw = mk_div(vq.w), dh = mk_div(vo.h);
   if (bias)
     hipLaunchKernelGGL((pool_fwd_fixed_kernel<PZ, PY, PX, true>), g, dim3(256), 0, ctx->stream,
-                       vy, bias, act, vo, dvw, dh, chunk);
+                       vy, bias, act, vo, dvw, dh, chunk, nparts, pstride);
   else
     hipLaunchKernelGGL((pool_fwd_fixed_kernel<PZ, PY, PX, false>), g, dim3(256), 0, ctx->stream,
-                       vy, bias, act, vo, dvw, dh, chunk);
+                       vy, bias, act, vo, dvw, dh, chunk, nparts, pstride);
 }
 template <int PZ, int PY, int PX>
 static void launch_pool_bwd_fixed(e2_ctx* ctx, const View5& vd, const View5& vy, const float* bias,
-                                  int act, const View5& vdy, float* dbias, int accumulate) {
+                                  int act, const View5& vdy, float* dbias, int accumulate,
+                                  int gparts = 1, long gstride = 0) {
   View5 vq = vd; vq.w = (vd.w + 4 / PX - 1) / (4 / PX);
   const unsigned chunk = pw_chunk(vq);
   const dim3 g = grid_chunked(vq, chunk);
   const FastDiv dvw = mk_div(vq.w), dh = mk_div(vd.h);
   if (bias)
     hipLaunchKernelGGL((pool_bwd_fixed_kernel<PZ, PY, PX, true>), g, dim3(256), 0, ctx->stream,
-                       vd, vy, bias, act, vdy, dbias, accumulate, dvw, dh, chunk);
+                       vd, vy, bias, act, vdy, dbias, accumulate, dvw, dh, chunk, gparts, gstride);
   else
     hipLaunchKernelGGL((pool_bwd_fixed_kernel<PZ, PY, PX, false>), g, dim3(256), 0, ctx->stream,
-                       vd, vy, bias, act, vdy, dbias, accumulate, dvw, dh, chunk);
+                       vd, vy, bias, act, vdy, dbias, accumulate, dvw, dh, chunk, gparts, gstride);
 }
 
 int e2i_fill_view(e2_ctx* ctx, const e2_tensor5* t, float value) {
@@ -880,9 +906,21 @@ static int pool_shapes_ok(const e2_tensor5* big, const e2_tensor5* small, int pz
   return 0;
 }
 
+static int pool_fwd_impl(e2_ctx* ctx, const e2_tensor5* y, const float* bias, int pz, int py,
+                         int px, int act, const e2_tensor5* out, int nparts, int64_t pstride);
 extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const float* bias,
                                     int pz, int py, int px, int act,
                                     const e2_tensor5* out) {
+  return pool_fwd_impl(ctx, y, bias, pz, py, px, act, out, 1, 0);
+}
+extern "C" int e2_pool_bias_act_fwd_parts(e2_ctx* ctx, const e2_tensor5* y, int64_t part_stride,
+                                          int nparts, const float* bias, int pz, int py, int px,
+                                          int act, const e2_tensor5* out) {
+  E2_REQUIRE(nparts >= 1 && (nparts == 1 || part_stride > 0), "pool_bias_act_fwd_parts: bad parts");
+  return pool_fwd_impl(ctx, y, bias, pz, py, px, act, out, nparts, part_stride);
+}
+static int pool_fwd_impl(e2_ctx* ctx, const e2_tensor5* y, const float* bias, int pz, int py,
+                         int px, int act, const e2_tensor5* out, int nparts, int64_t pstride) {
   E2_REQUIRE(ctx, "pool_bias_act_fwd: null ctx");
   if (int rc = check_view(y, "pool_bias_act_fwd y")) return rc;
   if (int rc = check_view(out, "pool_bias_act_fwd out")) return rc;
@@ -893,10 +931,13 @@ extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const floa
   const FastDiv dw = mk_div(vo.w), dh = mk_div(vo.h);
   const unsigned chunk = pw_chunk(vo);
   const int pcode = pz * 100 + py * 10 + px;
-  if (pcode == 122) launch_pool_fwd_fixed<1, 2, 2>(ctx, vy, bias, act, vo);
-  else if (pcode == 211) launch_pool_fwd_fixed<2, 1, 1>(ctx, vy, bias, act, vo);
-  else if (pcode == 222) launch_pool_fwd_fixed<2, 2, 2>(ctx, vy, bias, act, vo);
-  else if (pcode == 111) launch_pool_fwd_fixed<1, 1, 1>(ctx, vy, bias, act, vo);
+  E2_REQUIRE(nparts == 1 || pcode == 122 || pcode == 211 || pcode == 222 || pcode == 111,
+             "pool_bias_act_fwd_parts: partial sums are added up by the fixed-window kernels "
+             "((1,1,1), (1,2,2), (2,1,1), (2,2,2)) only");
+  if (pcode == 122) launch_pool_fwd_fixed<1, 2, 2>(ctx, vy, bias, act, vo, nparts, (long)pstride);
+  else if (pcode == 211) launch_pool_fwd_fixed<2, 1, 1>(ctx, vy, bias, act, vo, nparts, (long)pstride);
+  else if (pcode == 222) launch_pool_fwd_fixed<2, 2, 2>(ctx, vy, bias, act, vo, nparts, (long)pstride);
+  else if (pcode == 111) launch_pool_fwd_fixed<1, 1, 1>(ctx, vy, bias, act, vo, nparts, (long)pstride);
   else if (bias)
     hipLaunchKernelGGL((pool_fwd_kernel<true>), grid_chunked(vo, chunk), dim3(256), 0,
                        ctx->stream, vy, bias, pz, py, px, act, vo, dw, dh, chunk);
@@ -909,7 +950,8 @@ extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const floa
 
 static int pool_bwd_common(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* y,
                            const float* bias, int pz, int py, int px, int act,
-                           const e2_tensor5* dy, float* dbias, int accumulate) {
+                           const e2_tensor5* dy, float* dbias, int accumulate,
+                           int gparts = 1, int64_t gstride = 0) {
   if (int rc = check_view(dout, "pool_bwd dout")) return rc;
   if (int rc = check_view(y, "pool_bwd y")) return rc;
   if (int rc = check_view(dy, "pool_bwd dy")) return rc;
@@ -925,14 +967,16 @@ static int pool_bwd_common(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5
   const FastDiv dw = mk_div(vd.w), dh = mk_div(vd.h);
   const unsigned chunk = pw_chunk(vd);
   const int pcode = pz * 100 + py * 10 + px;
+  E2_REQUIRE(gparts == 1 || pcode == 122 || pcode == 211 || pcode == 222 || pcode == 111,
+             "pool_bias_act_bwd_parts: partial sums are added up by the fixed-window kernels only");
   if (pcode == 122)
-    launch_pool_bwd_fixed<1, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
+    launch_pool_bwd_fixed<1, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, gparts, (long)gstride);
   else if (pcode == 211)
-    launch_pool_bwd_fixed<2, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
+    launch_pool_bwd_fixed<2, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, gparts, (long)gstride);
   else if (pcode == 222)
-    launch_pool_bwd_fixed<2, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
+    launch_pool_bwd_fixed<2, 2, 2>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, gparts, (long)gstride);
   else if (pcode == 111)
-    launch_pool_bwd_fixed<1, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate);
+    launch_pool_bwd_fixed<1, 1, 1>(ctx, vd, vy, bias, act, vdy, dbias, accumulate, gparts, (long)gstride);
   else if (bias)
     hipLaunchKernelGGL((pool_bwd_kernel<true>), grid_chunked(vd, chunk), dim3(256), 0,
                        ctx->stream, vd, vy, bias, pz, py, px, act, vdy, dbias, accumulate, dw,
@@ -953,8 +997,34 @@ extern "C" int e2_pool_bias_act_bwd(e2_ctx* ctx, const e2_tensor5* dout,
   return pool_bwd_common(ctx, dout, y, bias, pz, py, px, act, dy, dbias, 0);
 }
 
+extern "C" int e2_pool_bias_act_bwd_parts(e2_ctx* ctx, const e2_tensor5* dout,
+                                          int64_t dout_part_stride, int dout_parts,
+                                          const e2_tensor5* y, const float* bias, int pz, int py,
+                                          int px, int act, const e2_tensor5* dy, float* dbias) {
+  E2_REQUIRE(ctx, "pool_bias_act_bwd_parts: null ctx");
+  E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "pool_bias_act_bwd_parts: bad act %d", act);
+  E2_REQUIRE(dout_parts >= 1 && (dout_parts == 1 || dout_part_stride > 0),
+             "pool_bias_act_bwd_parts: bad parts");
+  return pool_bwd_common(ctx, dout, y, bias, pz, py, px, act, dy, dbias, 0, dout_parts,
+                         dout_part_stride);
+}
+
+static int act_bwd_out_impl(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* out, int act,
+                            const e2_tensor5* dy, float* dbias, int gparts, int64_t gstride);
 extern "C" int e2_bias_act_bwd_out(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* out,
                                    int act, const e2_tensor5* dy, float* dbias) {
+  return act_bwd_out_impl(ctx, dout, out, act, dy, dbias, 1, 0);
+}
+extern "C" int e2_bias_act_bwd_out_parts(e2_ctx* ctx, const e2_tensor5* dout,
+                                         int64_t dout_part_stride, int dout_parts,
+                                         const e2_tensor5* out, int act, const e2_tensor5* dy,
+                                         float* dbias) {
+  E2_REQUIRE(dout_parts >= 1 && (dout_parts == 1 || dout_part_stride > 0),
+             "bias_act_bwd_out_parts: bad parts");
+  return act_bwd_out_impl(ctx, dout, out, act, dy, dbias, dout_parts, dout_part_stride);
+}
+static int act_bwd_out_impl(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* out, int act,
+                            const e2_tensor5* dy, float* dbias, int gparts, int64_t gstride) {
   E2_REQUIRE(ctx, "bias_act_bwd_out: null ctx");
   E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "bias_act_bwd_out: bad act %d", act);
   if (int rc = check_view(dout, "bias_act_bwd_out dout")) return rc;
@@ -969,7 +1039,7 @@ extern "C" int e2_bias_act_bwd_out(e2_ctx* ctx, const e2_tensor5* dout, const e2
   const FastDiv dvw = mk_div(vq.w), dh = mk_div(vd.h);
   const unsigned chunk = pw_chunk(vq);
   hipLaunchKernelGGL(act_bwd_out_kernel, grid_chunked(vq, chunk), dim3(256), 0, ctx->stream, vd,
-                     vo, act, vdy, dbias, dvw, dh, chunk);
+                     vo, act, vdy, dbias, dvw, dh, chunk, gparts, (long)gstride);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -368,6 +368,23 @@ class Conv(NeuralLayer):
         tiles = plan.batch * osp[0] * (-(-(osp[1] * osp[2]) // 128)) * (-(-self.n_f // 112))
         return tiles >= 160
 
+    _PART_WINDOWS = ((1, 1, 1), (1, 2, 2), (2, 1, 1), (2, 2, 2))
+
+    def _parts_ok(self, plan):
+        """this node's pre-activation / output gradient may arrive as split-K partial sums:
+        its bias + activation (+ pooling) kernels add them up (e2hip.h, "split-K without
+        atomics")"""
+        return (type(self) is Conv and not self._bn() and not self._mfp_pool()
+                and tuple(self._p3) in self._PART_WINDOWS and not self._fused_first(plan)
+                and self._fused_head(plan) is None and not plan.fuse_actbwd)
+
+    @staticmethod
+    def _n_parts(shape):
+        """slabs to provide for a tensor of this shape: 8, while they stay small (the layers
+        that need split-K to fill the chip ARE small)"""
+        nbytes = 4 * int(np.prod(shape))
+        return 8 if 8 * nbytes <= (512 << 20) else 1
+
     def _plan_alloc(self, plan):
         N = plan.out_shape(self.parent)[0]     # (the fragments of MFP sit on the batch axis)
         psp = self._sp3(self.parent.shape)
@@ -386,8 +403,17 @@ class Conv(NeuralLayer):
             return
         osp = [psp[i] - k[i] + 1 for i in range(3)]
         if not self._fused_act(plan):
-            plan.scratch[self, 'y'] = plan.empty((N, self.n_f) + tuple(osp))
+            ysh = (N, self.n_f) + tuple(osp)
+            yp = plan.empty(((self._n_parts(ysh) if self._parts_ok(plan) else 1),) + ysh)
+            plan.scratch[self, 'y_parts'] = yp
+            plan.scratch[self, 'y'] = yp[0]
         plan.alloc_out(self)
+        if plan.training and self in plan.grad and self._parts_ok(plan):
+            gsh = tuple(plan.grad[self].shape)
+            if self._n_parts(gsh) > 1:         # the output gradient, as slabs for partial sums
+                gp = plan.empty((self._n_parts(gsh),) + gsh)
+                plan.scratch[self, 'grad_parts'] = gp
+                plan.grad[self] = gp[0]
         if self._bn():
             pooled = any(p != 1 for p in self._p3)
             if pooled:        # batch norm acts on the POOLED conv output (neural.py:678-681)
@@ -453,14 +479,21 @@ class Conv(NeuralLayer):
         y = plan.scratch[self, 'y']
         sig = (0, self.n_f, cin) + tuple(self._k3) + tuple(y.shape[2:]) + \
             (x.stride(3),)
+        yp = plan.scratch[self, 'y_parts']
+        got = [1]                              # parts the (last) launch wrote
+
         def fwd_plain():
             if ctx.bf16_memory_form():
                 ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), y, ws=plan.bf16_ws(self))
+                got[0] = 1
+            elif yp.shape[0] > 1:
+                got[0] = ctx.conv3d_fwd_packed_parts(x, wp, self.n_f, self._k3, yp)
             else:
                 ctx.conv3d_fwd_packed(x, wp, self.n_f, self._k3, y)
         plan.tuned('igemm', sig,
                    autotune.igemm_candidates(self.n_f, cin, self._k3, y.shape[2:]) +
                    plan.bf16_cands(cin), fwd_plain, out=y)
+        y_nparts = got[0]
         if self._bn():
             lin = y
             if any(p != 1 for p in self._p3):
@@ -488,8 +521,12 @@ class Conv(NeuralLayer):
                 ctx.pool_bias_act_fwd(src, plan.param(self.b), self._p3,
                                       self.activation_func, out[i * n_in:(i + 1) * n_in])
             return
-        ctx.pool_bias_act_fwd(y, plan.param(self.b), self._p3, self.activation_func,
-                              plan.out[self])
+        if y_nparts > 1:                        # split-K partial sums: added up on the way
+            ctx.pool_bias_act_fwd_parts(yp, y_nparts, plan.param(self.b), self._p3,
+                                        self.activation_func, plan.out[self])
+        else:
+            ctx.pool_bias_act_fwd(y, plan.param(self.b), self._p3, self.activation_func,
+                                  plan.out[self])
 
     def _plan_bwd(self, plan):
         ctx = plan.ctx
@@ -517,11 +554,24 @@ class Conv(NeuralLayer):
         elif plan.scratch.get((self, 'dy_done')):
             pass        # the consumer's data-gradient launch wrote dy and dbias (below)
         elif self._fused_act(plan):
-            ctx.bias_act_bwd_out(plan.grad[self], plan.out[self], self.activation_func, dy,
-                                 plan.pgrad(self.b))
+            gn = plan.scratch.get((self, 'grad_nparts'), 1)
+            if gn > 1:
+                ctx.bias_act_bwd_out_parts(plan.scratch[self, 'grad_parts'], gn, plan.out[self],
+                                           self.activation_func, dy, plan.pgrad(self.b))
+            else:
+                ctx.bias_act_bwd_out(plan.grad[self], plan.out[self], self.activation_func, dy,
+                                     plan.pgrad(self.b))
         else:
-            ctx.pool_bias_act_bwd(plan.grad[self], plan.scratch[self, 'y'], plan.param(self.b),
-                                  self._p3, self.activation_func, dy, plan.pgrad(self.b))
+            gn = plan.scratch.get((self, 'grad_nparts'), 1)
+            if gn > 1:
+                ctx.pool_bias_act_bwd_parts(plan.scratch[self, 'grad_parts'], gn,
+                                            plan.scratch[self, 'y'], plan.param(self.b),
+                                            self._p3, self.activation_func, dy,
+                                            plan.pgrad(self.b))
+            else:
+                ctx.pool_bias_act_bwd(plan.grad[self], plan.scratch[self, 'y'],
+                                      plan.param(self.b), self._p3, self.activation_func, dy,
+                                      plan.pgrad(self.b))
         cin = self.parent.shape['f']
         dw = self._w5(plan.pgrad(self.w))
         dyp = plan.scratch[self, 'dy_pad']
@@ -571,17 +621,26 @@ class Conv(NeuralLayer):
                 return
             dst, first = plan.grad_slot(self.parent)
             out = dst if first else plan.tmp_like(dst)
+            # first writer of the parent's output gradient: split-K partial sums go to the
+            # parent's slabs, its activation backward adds them up
+            gparts = plan.scratch.get((self.parent, 'grad_parts')) if first else None
+            got = [1]
             sig = (1, cin, self.n_f) + tuple(self._k3) + tuple(out.shape[2:]) + \
                 (dyp.stride(3),)
             def dgrad():
                 if ctx.bf16_memory_form():
                     ctx.conv3d_dgrad_bf16(dyp, self._w5(plan.param(self.w)), out,
                                           ws=plan.bf16_ws(self))
+                    got[0] = 1
+                elif gparts is not None:
+                    got[0] = ctx.conv3d_dgrad_packed_parts(dyp, wp, cin, self._k3, gparts)
                 else:
                     ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out)
             plan.tuned('igemm', sig,
                        autotune.igemm_candidates(cin, self.n_f, self._k3, out.shape[2:]) +
                        plan.bf16_cands(self.n_f), dgrad, out=out)
+            if first:
+                plan.scratch[self.parent, 'grad_nparts'] = got[0]
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
 

@@ -76,8 +76,10 @@ class Optimiser(object):
             self._hyper[:4].copy_(torch.tensor(vals, dtype=torch.float32))
             self._hyper_host = vals
 
-    def __call__(self, *args):
-        """[data (,labels ...)] -> [loss (, additional outputs ...)]"""
+    def __call__(self, *args, **kwargs):
+        """[data (,labels ...)] -> [loss (, additional outputs ...)].  ``sync=False``: the
+        step is only SUBMITTED; the loss returned is the one of the step before it (read
+        back without waiting for the new step; the very first call waits for its own)."""
         if self.step.func is None:
             self.step.compile()
         plan = self.step.func
@@ -87,6 +89,12 @@ class Optimiser(object):
             self._ensure_state(plan)
             self._sync_hyper(plan)
         plan.run()
+        if not kwargs.get('sync', True) and len(self.output) == 1:
+            loss, t = plan.fetch_async()
+            if loss is not None:
+                self.last_exec_time = t
+                self.step.last_exec_time = t
+                return [graphutils.as_floatX(loss)]
         ret = list(plan.fetch())
         ret[0] = graphutils.as_floatX(ret[0])
         self.last_exec_time = plan.last_device_time

@@ -345,8 +345,20 @@ class Plan(object):
         self._capturing = False
         self._calls = 0
         self._grad_written = set()
-        self._ev0, self._ev1 = self.ctx.event(), self.ctx.event()
+        # two pairs of timing events, used alternately: a deferred fetch (fetch_async) reads
+        # the pair of the step BEFORE the one just submitted
+        self._ev_pairs = [(self.ctx.event(), self.ctx.event()), (self.ctx.event(), self.ctx.event())]
+        self._ev_idx = 0
+        self._async = None                   # state of fetch_async: pinned loss slots, events
         self._built = True
+
+    @property
+    def _ev0(self):
+        return self._ev_pairs[self._ev_idx][0]
+
+    @property
+    def _ev1(self):
+        return self._ev_pairs[self._ev_idx][1]
 
     # ---- kernel sequences ----------------------------------------------------------------
     def _emit_forward(self):
@@ -588,6 +600,7 @@ class Plan(object):
 
     def run(self):
         """launch the plan on the already-set inputs; returns nothing (async)."""
+        self._ev_idx ^= 1
         old = self.ctx.stream
         self.ctx.set_stream(self.stream)
         try:
@@ -616,6 +629,34 @@ class Plan(object):
             return [g.detach().cpu().numpy().copy()
                     for g in self.model.device_grads_list()]
         return rets
+
+    def fetch_async(self):
+        """Deferred read-back of a TRAINING plan's loss: queues a copy of this step's loss
+        into pinned host memory behind the step and returns ``(loss, device seconds)`` of
+        the step submitted BEFORE it (None, None on the first call) -- the host never waits
+        for the step it has just submitted, so the next one is queued while this one runs.
+        The reference's trainingstep is synchronous (model.py:548-600: the loss is an output
+        of the compiled function); this is the opt-in form of Model.trainingstep(sync=False)."""
+        if not self.training:
+            raise RuntimeError("fetch_async: a training plan is needed")
+        nll = self.loss_node.parent[0] if isinstance(self.loss_node.parent, (list, tuple)) \
+            else self.loss_node.parent
+        dev_loss = self.scratch[nll, 'loss']
+        if self._async is None:
+            self._async = dict(pin=[torch.empty(1, dtype=torch.float32).pin_memory() for _ in range(2)],
+                               ev=[torch.cuda.Event(), torch.cuda.Event()], n=0)
+        a = self._async
+        slot = a['n'] & 1
+        with torch.cuda.stream(self.stream):
+            a['pin'][slot].copy_(dev_loss.reshape(1), non_blocking=True)
+            a['ev'][slot].record(self.stream)
+        prev = None, None
+        if a['n'] > 0:
+            a['ev'][slot ^ 1].synchronize()          # the step before the one just queued
+            e0, e1 = self._ev_pairs[self._ev_idx ^ 1]
+            prev = np.float32(a['pin'][slot ^ 1].item()), self.ctx.elapsed_ms(e0, e1) * 1e-3
+        a['n'] += 1
+        return prev
 
     def __call__(self, *args):
         self.set_inputs(args)

@@ -190,6 +190,36 @@ int e2_conv1_pool_act_bwd(e2_ctx*, const e2_tensor5* x, const float* w,
                           int kw, int py, int px, int act, float* dw, float* dbias,
                           void* ws, size_t ws_bytes);
 
+/* ---- split-K without atomics: partial sums added up by the consumer ------------------
+ * (No reference counterpart: inside Theano's compiled function the conv, the pooling and the
+ * bias / activation that follows are separate ops, computations.py:364-428, 538-631,
+ * neural.py:705-712; this is how the conv hands its result to the next op here.)
+ * A small layer fills the chip only when its K range is split over several work-groups.
+ * The plain entry points then ACCUMULATE with float atomics into a zero-filled output
+ * (~1.3 TB/s chip-wide, and a fill launch).  The _parts forms store split s with plain
+ * stores to y.ptr + s * part_stride instead (the caller provides max_parts such slabs,
+ * nothing needs to be zero) and report in *nparts how many were written (1: y holds the
+ * complete result -- the tiling did not split K); the pointwise kernel that consumes the
+ * tensor anyway adds the parts up on its way:
+ *   e2_pool_bias_act_fwd_parts   y = sum of the parts (left in part 0), out = act(pool(y) + b)
+ *   e2_pool_bias_act_bwd_parts / e2_bias_act_bwd_out_parts   dout = sum of the parts
+ * Partial sums are added up for the pooling windows (1,1,1), (1,2,2), (2,1,1), (2,2,2). */
+int e2_conv3d_fwd_packed_parts(e2_ctx*, const e2_tensor5* x, const void* wp, int cout, int kd,
+                               int kh, int kw, const e2_tensor5* y, int64_t part_stride,
+                               int max_parts, int* nparts);
+int e2_conv3d_dgrad_packed_parts(e2_ctx*, const e2_tensor5* dy_pad, const void* wp, int cin,
+                                 int kd, int kh, int kw, const e2_tensor5* dx,
+                                 int64_t part_stride, int max_parts, int* nparts);
+int e2_pool_bias_act_fwd_parts(e2_ctx*, const e2_tensor5* y, int64_t part_stride, int nparts,
+                               const float* bias, int pz, int py, int px, int act,
+                               const e2_tensor5* out);
+int e2_pool_bias_act_bwd_parts(e2_ctx*, const e2_tensor5* dout, int64_t dout_part_stride,
+                               int dout_parts, const e2_tensor5* y, const float* bias, int pz,
+                               int py, int px, int act, const e2_tensor5* dy, float* dbias);
+int e2_bias_act_bwd_out_parts(e2_ctx*, const e2_tensor5* dout, int64_t dout_part_stride,
+                              int dout_parts, const e2_tensor5* out, int act,
+                              const e2_tensor5* dy, float* dbias);
+
 /* ---- pool + bias + activation  (computations.py:538-631 pooling();
  *      neural.py:705-712; computations.py:57-134 apply_activation) -------- */
 /* out = act(maxpool(y, pool) + bias[c]) ; pool == stride, floor semantics. */

@@ -208,6 +208,34 @@ def test_graph_replay_equals_eager_at_baseline_size():
         assert rel(a, b) < 1e-4
 
 
+def test_trainingstep_with_deferred_loss():
+    """Model.trainingstep(sync=False): the step is submitted without waiting for it and the
+    loss handed back is the PREVIOUS step's; the same batches from the same initial weights
+    give the losses of the synchronous run shifted by one call, and the same parameters."""
+    from elektronn2_amd import neuromancer as nm
+    spec, sp = O.NEURO3D_LITE, (7, 47, 47)
+    params = O.init_net(spec, 1, seed=1)
+    rng = np.random.RandomState(21)
+    xs = [rng.rand(1, 1, *sp).astype(np.float32) for _ in range(4)]
+    ts = [rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32) for _ in range(4)]
+    runs = []
+    for sync in (True, False):
+        m = build('lite', sp, params)
+        m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        out = [m.trainingstep(xs[i % 4], ts[i % 4], optimiser='Adam', sync=sync) for i in range(9)]
+        assert all(o[2] is None and o[1] > 0 for o in out)
+        torch.cuda.synchronize()
+        runs.append(([float(o[0]) for o in out],
+                     [p.get_value() for p in m.loss_node.all_trainable_params.values()], m.iterations))
+    (ls, ps, n_s), (la, pa, n_a) = runs
+    assert n_s == n_a == 9
+    assert abs(la[0] - ls[0]) < 1e-6 * abs(ls[0])            # the first call waits for its own
+    for i in range(1, 9):                                      # then: one call late
+        assert abs(la[i] - ls[i - 1]) < 1e-5 * abs(ls[i - 1]), (i, la, ls)
+    for a, b in zip(pa, ps):
+        assert rel(a, b) < 1e-4
+
+
 def _dense_model(spec, params, patch_sp):
     from elektronn2_amd import neuromancer as nm
     nm.model_manager.reset()

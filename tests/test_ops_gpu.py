@@ -149,6 +149,81 @@ def test_conv3d_dgrad_skips_border_planes(ctx, force, k, do):
     assert relerr(dx, O.conv3d_dgrad(dy, w, xshape)) < TOL
 
 
+@pytest.mark.parametrize("force", [None, "2,1,8,4", "3,2,8,6", "7,2,16,3", "2,4,16,3", "1,2,4,8",
+                                   "2,2,8,1", "4,5,1,8,4,1,4,1", "4,4,2,8,2,2,2,2"])
+@pytest.mark.parametrize("pool", [(1, 1, 1), (1, 2, 2), (2, 1, 1), (2, 2, 2)])
+def test_split_k_partial_sums_are_added_up_by_the_consumer(ctx, force, pool):
+    """split-K without atomics (e2hip.h): the conv stores one partial sum per K split into
+    slabs that are NOT zeroed (filled with NaN here), the pooling / bias / activation
+    kernel adds them up -- forward (the sum is left in part 0 for the backward) and
+    backward (dout arrives as the partial sums of the consumer's data gradient, incl.
+    border planes whose clipped K range leaves some splits EMPTY: they must store zeros).
+    Every tiling form, split counts 1 .. 8, all four fixed pooling windows."""
+    rng = np.random.RandomState(31)
+    k = (3, 2, 3)
+    ci, co = 22, 24
+    osp = (4 * pool[0], 6 * pool[1], 8 * pool[2])
+    x = rng.rand(1, ci, *[osp[i] + k[i] - 1 for i in range(3)]).astype(np.float32)
+    w = (rng.randn(co, ci, *k) / np.sqrt(ci * np.prod(k))).astype(np.float32)
+    b = (rng.randn(co) / 4).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    out_ref = O.bias_act_fwd(O.maxpool3d_fwd(y_ref, pool), b, 'relu')
+    wd = dev(w)
+    ws = torch.empty(ctx.conv_ws_bytes(co, ci, k) // 4 + 64, device="cuda")
+    ctx.conv3d_pack(wd, 0, ws)
+    yp = torch.full((8,) + y_ref.shape, float("nan"), device="cuda")
+    out = torch.full(out_ref.shape, float("nan"), device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        n = ctx.conv3d_fwd_packed_parts(dev(x), ws, co, k, yp)
+    finally:
+        ctx.set_tiling("igemm", None)
+    want = 1 if force is None else min(int(force.split(",")[4 if force.startswith("4,") else 3]), 8)
+    if force is not None:      # (the 4x4x1 form re-balances the splits: <= the requested count)
+        assert (n == want) if not force.startswith("4,") else (1 <= n <= want), (n, want)
+    assert 1 <= n <= 8
+    assert torch.isnan(yp[n:]).all()                          # untouched slabs
+    ctx.pool_bias_act_fwd_parts(yp, n, dev(b), pool, 'relu', out)
+    assert relerr(out, out_ref) < TOL
+    assert relerr(yp[0], y_ref) < TOL                        # the sum, for the backward
+
+    # the data gradient of THIS conv as partial sums -> the producer's activation backward
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(dy, w, x.shape)                  # = dL/d(out of the producer)
+    ws2 = torch.empty_like(ws)
+    ctx.conv3d_pack(wd, 1, ws2)
+    gp = torch.full((8,) + x.shape, float("nan"), device="cuda")
+    ctx.set_tiling("igemm", force)
+    try:
+        gn = ctx.conv3d_dgrad_packed_parts(_padded_dy(dy, k), ws2, ci, k, gp)
+    finally:
+        ctx.set_tiling("igemm", None)
+    assert 1 <= gn <= 8 and torch.isnan(gp[gn:]).all() and not torch.isnan(gp[:gn]).any()
+    assert relerr(gp[:gn].sum(0), dx_ref) < TOL
+    # producer: a conv layer with this pooling window whose POOLED output is x
+    ysh = (1, ci) + tuple(x.shape[2 + i] * pool[i] for i in range(3))
+    yprod = rng.randn(*ysh).astype(np.float32)
+    yprod[0, 0] = np.round(yprod[0, 0] * 2) / 2              # ties and exact zeros
+    bp = (rng.randn(ci) / 4).astype(np.float32)
+    bp[0] = 0.5
+    pooled = O.maxpool3d_fwd(yprod, pool)
+    dpre, db_ref = O.bias_act_bwd(dx_ref.astype(np.float32), pooled.astype(np.float32), bp, 'relu')
+    dyp_ref = O.maxpool3d_bwd(dpre, yprod, pool)
+    dyprod = torch.full(ysh, float("nan"), device="cuda")
+    db = torch.zeros(ci, device="cuda")
+    ctx.pool_bias_act_bwd_parts(gp, gn, dev(yprod), dev(bp), pool, 'relu', dyprod, db)
+    assert relerr(dyprod, dyp_ref) < TOL
+    assert relerr(db, db_ref) < 1e-4
+    if pool == (1, 1, 1):       # ... or a fused-epilogue producer: slopes from its stored output
+        outp = O.bias_act_fwd(yprod, bp, 'relu')
+        outp_d = dev(outp)
+        outp_d[dev(yprod + bp.reshape(1, -1, 1, 1, 1)) < 0] = -0.0
+        d2 = torch.full(ysh, float("nan"), device="cuda")
+        db2 = torch.zeros(ci, device="cuda")
+        ctx.bias_act_bwd_out_parts(gp, gn, outp_d, 'relu', d2, db2)
+        assert relerr(d2, dyp_ref) < TOL and relerr(db2, db_ref) < 1e-4
+
+
 @pytest.mark.parametrize("act", ["relu", "lin"])
 @pytest.mark.parametrize("k", [(1, 3, 3), (1, 1, 1), (2, 4, 4)])
 def test_conv3d_fused_bias_act(ctx, act, k):

@@ -8,6 +8,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/$T
 mkdir -p $O
+python bench.py --sources-sha > $O/sources_sha16.txt
 timeout -k 10 400 python bench.py --workload $W > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 cat $O/bench.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_prof.json 2> $O/prof.err || { tail -20 $O/prof.err; exit 1; }

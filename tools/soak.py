@@ -1,6 +1,7 @@
 """soak: N training steps of neuro3d_lite@183 on random patches of a synthetic volume
 (device-resident sampler, warp + grey augmentation), checking that the loss stays finite
-and falls and that the captured graphs keep replaying.  usage: soak.py [steps] [--mfma bf16]"""
+and falls and that the captured graphs keep replaying.
+usage: soak.py [steps] [--mfma bf16] [--async]   (--async: trainingstep(sync=False))"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -26,7 +27,7 @@ t0 = time.time()
 losses = []
 for i in range(steps):
     d, t = smp.getbatch(1, 'train', grey_augment_channels=[0], warp=0.5)
-    losses.append(float(model.trainingstep(d, t, optimiser='Adam')[0]))
+    losses.append(float(model.trainingstep(d, t, optimiser='Adam', sync='--async' not in sys.argv)[0]))
     if (i + 1) % 500 == 0:
         print("step %d  loss (mean of last 100) %.4f  %.2f ms/step wall" % (
             i + 1, np.mean(losses[-100:]), (time.time() - t0) / (i + 1) * 1e3), flush=True)
