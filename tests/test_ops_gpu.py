@@ -76,7 +76,7 @@ def test_conv3d_fwd_dgrad_wgrad(ctx, case):
     assert relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < TOL
 
 
-@pytest.mark.parametrize("force", ["1,1,4,1", "2,2,8,2", "3,1,4,4", "13,2,4,1", "10,1,8,2",
+@pytest.mark.parametrize("force", ["1,1,4,1", "2,2,8,2", "3,1,4,4", "13,1,4,1", "10,2,8,2",
                                    "5,2,4,1", "7,1,8,1", "8,2,4,2", "4,1,8,1", "6,2,4,1",
                                    "7,2,24,1", "4,4,16,1", "13,1,24,3", "3,4,12,2"])
 def test_conv3d_fwd_forced_tilings(ctx, force):
