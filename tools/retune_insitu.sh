@@ -17,7 +17,7 @@ json.dump(keep, open(p, "w"), indent=0, sort_keys=True)
 PY
 export E2HIP_TUNE_CACHE=$GRAFT_REPO_ROOT/gpurun_out/$T/tune.json
 for w in $WL; do
-  timeout -k 10 900 python tools/tune_insitu.py $w 5 40 > gpurun_out/$T/insitu_$w.log 2>&1 || { tail -20 gpurun_out/$T/insitu_$w.log; exit 1; }
+  timeout -k 10 900 python tools/tune_insitu.py $w ${E2_INSITU_TOPK:-5} ${E2_INSITU_REPLAYS:-40} > gpurun_out/$T/insitu_$w.log 2>&1 || { tail -20 gpurun_out/$T/insitu_$w.log; exit 1; }
   grep -v amdgpu gpurun_out/$T/insitu_$w.log | tail -25
 done
 for w in $WL; do
