@@ -130,6 +130,13 @@ __global__ void pack_multi_gather_kernel(const PackJobDev* __restrict__ jobs) {
 // ITS contiguous axis (oc).  The plain gather above reads one 4-byte element per cache
 // line -- 16-32x the bytes through L2 -- and took 134 us per step for unet3d_lite.
 constexpr int kPackTileFloats = 8192;
+// input channels per tile: ~32 (ic, tap) pairs x 32 output channels.  (Round 3 tried ~128
+// pairs per tile -- a quarter of the tiles, four times the work between two barriers:
+// neuro3d's repack went from 37 to 41 us, so the tile count is not what bounds it.)
+__host__ __device__ inline int e2_pack_ict(int T) {
+  const int ict = (32 + T - 1) / T;
+  return ict < 1 ? 1 : ict;
+}
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobDev* __restrict__ jobs) {
   __shared__ float tile[kPackTileFloats];
   const PackJobDev j = jobs[blockIdx.y];
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobDev* __res
   const int nCGw = min(nCG, ((j.Cin + 3) >> 2) + 4);
   const int coW = min(j.coP, ((j.Cout + 15) / 16) * 16 + 96);
   const int icW = 4 * nCGw;
-  const int ICT = max(1, (32 + T - 1) / T);          // input channels per tile
+  const int ICT = e2_pack_ict(T);                     // input channels per tile
   const int KT = ICT * T;                             // (ic, tap) pairs per tile
   const int nOT = (coW + 31) >> 5, nIT = (icW + ICT - 1) / ICT;
   const bool oc_major = (j.wsI == T);                 // forward image: w[oc][ic][tap] contiguous in (ic, tap)
@@ -194,7 +201,7 @@ extern "C" int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, i
     e2i_pack_dims(cin, cout, &j->ciP, &j->coP);
   }
   j->total = (long)kd * kh * kw * j->ciP * j->coP;
-  const int ICT = std::max(1, (32 + T - 1) / T);
+  const int ICT = e2_pack_ict(T);
   j->dT = mk_pack_div(T); j->dKT = mk_pack_div(ICT * T); j->d32T = mk_pack_div(32 * T);
   j->dTHW = mk_pack_div(kh * kw);
   return 0;
