@@ -58,6 +58,8 @@ struct FirstM {
   long osN, osC, osD, osH;       // strides of out / dout
   int act;
   int tilesX, tilesY, nTiles;
+  int dbg;                       // timing ablations (debug build, E2_FM_DBG): 1 = no tile loads,
+                                 // 2 = no conv MFMAs, 4 = no output stores / no dW MFMAs
 };
 
 constexpr int kTW = 72;                  // LDS row stride of the input tile (64 + kw - 1 <= 69)
@@ -103,7 +105,7 @@ __device__ __forceinline__ void load_tile(const FirstM& p, int tile, float* xt, 
   for (int e = threadIdx.x; e < G::RT * kTW; e += 256) {
     const int i = e / kTW, j = e - i * kTW;
     const int y = row0 + i, xx = col0 + j;
-    xt[e] = (y < p.H && xx < p.W) ? src[(long)y * p.xsH + xx] : 0.f;
+    xt[e] = (y < p.H && xx < p.W && !(p.dbg & 1)) ? src[(long)y * p.xsH + xx] : 0.f;
   }
 }
 
@@ -157,7 +159,13 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
     load_tile<KH, KW, PY, PX, MG>(p, tile, xt, n, z, row0, col0);
     __syncthreads();
     f32x4 acc[MG][PY];
-    conv_rows<KH, KW, PY, PX, MG>(xt + wave * PY * kTW, lane, aw, acc);
+    if (!(p.dbg & 2)) conv_rows<KH, KW, PY, PX, MG>(xt + wave * PY * kTW, lane, aw, acc);
+    else {
+#pragma unroll
+      for (int g = 0; g < MG; ++g)
+#pragma unroll
+        for (int nb = 0; nb < PY; ++nb) acc[g][nb] = (f32x4){xt[lane], 0.f, 0.f, 0.f};
+    }
     const int prow = row0 / PY + wave;
     const int pcol = (col0 + lane) / PX;
     const bool ok = prow < p.Ho && pcol < p.Wo && (lane % PX) == 0;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
         if (ch < p.Cout) {
           float v = m + bs[g][r];
           if (p.act == E2_ACT_RELU) v = fmaxf(v, 0.f);
-          if (ok) ob[(long)ch * p.osC] = v;
+          if (ok && !((p.dbg & 4) && ch > 0)) ob[(long)ch * p.osC] = v;
         }
       }
   }
@@ -229,7 +237,13 @@ __global__ __launch_bounds__(256) void firstm_bwd_kernel(FirstM p, float* __rest
     __syncthreads();
     const float* xw = xt + wave * PY * kTW;
     f32x4 acc[MG][PY];
-    conv_rows<KH, KW, PY, PX, MG>(xw, lane, aw, acc);
+    if (!(p.dbg & 2)) conv_rows<KH, KW, PY, PX, MG>(xw, lane, aw, acc);
+    else {
+#pragma unroll
+      for (int g = 0; g < MG; ++g)
+#pragma unroll
+        for (int nb = 0; nb < PY; ++nb) acc[g][nb] = (f32x4){xw[lane], 0.f, 0.f, 0.f};
+    }
     // dy of the conv output: the pooled gradient goes to every element equal to the window
     // maximum, through the activation's slope at the pooled pre-activation
 #pragma unroll
@@ -256,6 +270,7 @@ __global__ __launch_bounds__(256) void firstm_bwd_kernel(FirstM p, float* __rest
     // (same wave writes and reads dyw: LDS operations of a wave complete in order)
     // dW[4g..4g+3][tap = lane] += dy[..][position] * x[position + tap]
     const float* xb = xw + tapoff;
+    if (p.dbg & 4) continue;
     if constexpr (Q4) {
       // block (pq, tap quad): A = dy[4g + i][p0 + pq] on lanes (pq, *, i), B = x[p0 + pq + tap]
       fm_for<NP / 4>([&](auto k_) {
@@ -345,6 +360,7 @@ static void fill(FirstM& p, const e2_tensor5* x, const e2_tensor5* o, int cout, 
   p.Ho = o->h; p.Wo = o->w;
   p.xsN = x->sn; p.xsD = x->sd; p.xsH = x->sh;
   p.osN = o->sn; p.osC = o->sc; p.osD = o->sd; p.osH = o->sh;
+  p.dbg = e2_dbg_env_int("E2_FM_DBG");
   p.tilesX = e2_cdiv(o->w * px, 64);
   p.tilesY = e2_cdiv(o->h, 4);
   p.nTiles = p.N * p.D * p.tilesY * p.tilesX;
