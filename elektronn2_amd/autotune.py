@@ -238,17 +238,9 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
                     for q in {ps} | set(_near_divisors(tiles, ps)):
                         cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk, bp, q))
                         if wk in (1, 14) and nnt >= 2 and nmt * q * nnt > 8:
-                            # the same launch in the XCD-grouped block order ...
+                            # the same launch in the XCD-grouped block order (balanced for any
+                            # group count: csrc/conv_wgrad_direct.hip)
                             cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q))
-                            # ... and with the split count moved to where the nmt * q groups
-                            # are a multiple of 8: every XCD then gets the same number of
-                            # groups (50 groups on 8 XCDs = 7 + 6: the long work-groups of the
-                            # 7-group XCDs made the grouped order 8 % slower and the tuner
-                            # kept the order that fetches every gradient row into all 8 L2s)
-                            step = 8 // math.gcd(nmt, 8)
-                            for q8 in {(q // step) * step, -(-q // step) * step}:
-                                if 1 <= q8 <= tiles and q8 != q:
-                                    cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q8))
     return sorted(set(cands))
 
 

@@ -249,19 +249,26 @@ __global__ __launch_bounds__(512, 1) void wgrad_direct_kernel(WdP p) {
   // are dealt round-robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md
   // "Workgroup dispatch"), each with its own L2: with the plain order every XCD fetched
   // every dy line (FETCH_SIZE 5-11x the operand bytes, profiles/r01_e_pmc_traffic.csv).
-  // xcd mode: group g's work-groups are the consecutive blocks of ONE residue class mod 8,
-  // so its dy lines are fetched once into that XCD's L2 (the host rounds the number of
-  // groups up to a multiple of 8; the blocks of the padding groups leave at once).
+  // xcd mode: the (group, n-tile) pairs, group-major, are cut into 8 equal contiguous ranges
+  // and range x is run by the blocks of residue class x mod 8 -- the work-groups of one
+  // group sit on ONE XCD (two, where a range boundary cuts through the group), so its dy
+  // lines are fetched into one or two L2s instead of eight, and every XCD gets the same
+  // number of work-groups whatever the group count is.  (Round 2 dealt whole groups to the
+  // XCDs: 50 groups = 7 + 6 per XCD made the long work-groups of the 7-group XCDs the
+  // kernel's duration, and the tuner kept the plain order for such launches.)
   // Placement only changes speed / traffic, never results.
   int nt, mt, ps;
   if (p.xcd) {
     const int b = blockIdx.x;
+    const int pairs = p.nMT * p.nPS * p.nNT;
+    const int perX = (pairs + 7) >> 3;
     const int j = b >> 3;
-    const int g = (j / p.nNT) * 8 + (b & 7);
-    nt = j % p.nNT;
+    const int pair = (b & 7) * perX + j;
+    if (pair >= pairs) return;              // (j < perX by the grid size)
+    const int g = pair / p.nNT;
+    nt = pair - g * p.nNT;
     mt = g % p.nMT;
     ps = g / p.nMT;
-    if (ps >= p.nPS) return;
   } else {
     int bid = blockIdx.x;
     nt = bid % p.nNT; bid /= p.nNT;
@@ -675,8 +682,8 @@ int e2i_wgrad_direct(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int BP, in
   p.xcd = xcd ? 1 : 0;
   const size_t lds = 2 * (size_t)p.bufFloats * 4;
   E2_REQUIRE(lds <= 160 * 1024, "wgrad(direct): tiling needs %zu B of LDS", lds);
-  const long groups = (long)p.nMT * p.nPS;
-  const long grid = (p.xcd ? (groups + 7) / 8 * 8 : groups) * p.nNT;
+  const long pairs = (long)p.nMT * p.nPS * p.nNT;
+  const long grid = p.xcd ? ((pairs + 7) / 8) * 8 : pairs;
   p.stamps = nullptr;
   static unsigned long long* stamp_buf = nullptr;
   const bool want_stamps = e2_dbg_env("E2_WGRAD_STAMPS") != nullptr && !ctx->capturing && grid <= 65536;
