@@ -285,6 +285,10 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
       f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5]; f.WN = v[6];
       f.G = v[7]; *ok = 1; return f;
     }
+    // a forced tiling this entry point cannot run ("32,MB,NB" belongs to e2_conv3d_*_bf16):
+    // fail, never fall back silently (e2hip.h, e2_set_tiling)
+    *ok = -1;
+    return f;
   }
   const double out_bytes = 4.0 * a.N * a.Cout * a.Do * (double)Q;
   const int cinP = ((a.Cin + 3) / 4) * 4;
@@ -446,6 +450,9 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   E2_REQUIRE(a.isY < (1 << 20), "igemm: input row stride too large");
   int ok = 0;
   IgemmCfg c = choose_cfg(ctx, a, &ok);
+  E2_REQUIRE(ok >= 0, "igemm: the forced tiling '%s' is not one this launch can run (packed conv "
+             "launches take \"MT,NT,CC,SK\", \"4,MG,NT,CC,SK,WM,WN,G\" or \"1,MT,NT\")",
+             ctx->tiling[E2_TILING_IGEMM]);
   E2_REQUIRE(ok, "igemm: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d W=%d)", a.Cin,
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
   if (a.gm_done) *a.gm_done = 0;

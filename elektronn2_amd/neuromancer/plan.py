@@ -163,6 +163,25 @@ class Plan(object):
             return []
         return autotune.bf16_wgrad_candidates(cin, k)
 
+    def _bf16_ws_alloc(self):
+        """both bf16 scratch buffers, sized ONCE for the largest Conv node of the plan before
+        any launch (they used to grow on demand during the first eager step: the old block
+        went back to the caching allocator while a side-stream kernel could still read it)"""
+        need_w = need_c = 0
+        for n in self.nodes:
+            if type(n).__name__ != 'Conv' or not hasattr(n, '_k3') or n.parent is None:
+                continue
+            try:
+                psh = self.out_shape(n.parent)
+                need_w = max(need_w, self.ctx.wgrad_bf16_ws_bytes(psh, n.n_f, n._k3))
+                need_c = max(need_c, self.ctx.conv_bf16_ws_bytes(psh, n.n_f, n._k3))
+            except Exception:
+                continue
+        if need_w:
+            self.scratch['bf16_wgrad_ws'] = torch.empty(need_w, dtype=torch.uint8, device=self.ctx.device)
+        if need_c:
+            self.scratch['bf16_ws'] = torch.empty(need_c, dtype=torch.uint8, device=self.ctx.device)
+
     def bf16_wgrad_ws(self, node):
         """the scratch of csrc/wgrad_bf16.hip (bf16 copies of x and dy, the f32 sums): its own
         buffer, because the weight gradient runs on the side stream next to the data
@@ -172,6 +191,8 @@ class Plan(object):
         if ws is None or ws.numel() < need:
             if self._capturing:
                 raise RuntimeError("bf16 weight-gradient workspace must exist before capture")
+            if ws is not None:
+                ws.record_stream(self.side)       # (a side-stream kernel may still use it)
             ws = torch.empty(need, dtype=torch.uint8, device=self.ctx.device)
             self.scratch['bf16_wgrad_ws'] = ws
         return ws
@@ -333,6 +354,8 @@ class Plan(object):
         with torch.cuda.stream(self.stream):
             for n in self.nodes:
                 n._plan_alloc(self)
+            if getattr(self.ctx, 'mfma_dtype', 'f32') == 'bf16':
+                self._bf16_ws_alloc()
             self._pack_dev = None
             if self.pack_jobs:
                 jobs = [(self._w5(self.param(w)), wp, mode) for (w, wp, mode) in self.pack_jobs]

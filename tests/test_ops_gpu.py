@@ -94,6 +94,24 @@ def test_conv3d_fwd_forced_tilings(ctx, force):
     assert relerr(y, y_ref) < TOL
 
 
+def test_forced_tiling_that_the_launch_cannot_run_is_an_error(ctx):
+    """e2hip.h, e2_set_tiling: "a tiling the problem cannot use makes the launch fail with
+    an error, never silently fall back" -- also for "32,MB,NB" (the bf16-in-memory kernel's
+    form) on a packed f32 launch, which used to fall through to the cost model"""
+    from elektronn2_amd.backend import E2Error
+    x = torch.rand(1, 8, 3, 9, 20, device="cuda")
+    w = torch.rand(16, 8, 1, 3, 3, device="cuda")
+    y = torch.empty(1, 16, 3, 7, 18, device="cuda")
+    ctx.set_tiling("igemm", "32,2,2")
+    try:
+        with pytest.raises(E2Error, match="forced tiling"):
+            ctx.conv3d_fwd(x, w, y)
+    finally:
+        ctx.set_tiling("igemm", None)
+    ctx.conv3d_fwd(x, w, y)                   # the cost model's choice again
+    assert relerr(y, O.conv3d_fwd(x.cpu().numpy(), w.cpu().numpy())) < TOL
+
+
 def _padded_dy(dy, k):
     pad = [kk - 1 for kk in k]
     dyp = torch.zeros(dy.shape[0], dy.shape[1], *[dy.shape[2 + i] + 2 * pad[i] for i in range(3)],

@@ -1,6 +1,8 @@
 #!/bin/bash
 # like tools/ab.sh but with a debug-environment build of the library (make DEBUG_ENV=1 on the box)
-cd $GRAFT_REPO_ROOT/elektronn2_amd/csrc && touch common.hpp && make -j16 DEBUG_ENV=1 > /dev/null 2>&1 || { echo build failed; exit 1; }
+# the debug-switch build lives in a directory of its own (the product library is never overwritten)
+cd $GRAFT_REPO_ROOT/elektronn2_amd/csrc && make -j16 BUILD=build/dbg OUT=build/dbg/libe2hip.so DEBUG_ENV=1 > /dev/null 2>&1 || { echo build failed; exit 1; }
+export E2HIP_LIB=$GRAFT_REPO_ROOT/elektronn2_amd/csrc/build/dbg/libe2hip.so
 cd $GRAFT_REPO_ROOT
 W=$1; shift
 R=2

@@ -1,6 +1,8 @@
 #!/bin/bash
 # in-kernel timeline of the 16x16 igemm kernel for the main layers of neuro3d_lite@183 (debug-env build)
-cd $GRAFT_REPO_ROOT/elektronn2_amd/csrc && touch common.hpp && make -j16 DEBUG_ENV=1 > /dev/null 2>&1 || { echo build failed; exit 1; }
+# the debug-switch build lives in a directory of its own (the product library is never overwritten)
+cd $GRAFT_REPO_ROOT/elektronn2_amd/csrc && make -j16 BUILD=build/dbg OUT=build/dbg/libe2hip.so DEBUG_ENV=1 > /dev/null 2>&1 || { echo build failed; exit 1; }
+export E2HIP_LIB=$GRAFT_REPO_ROOT/elektronn2_amd/csrc/build/dbg/libe2hip.so
 cd $GRAFT_REPO_ROOT
 run() { # op cin cout kd kh kw D H W force
   E2_IGEMM_STAMPS=1 E2_VERBOSE=1 E2_IGEMM_FORCE="${10}" python tools/one_layer.py $1 $2 $3 $4 $5 $6 $7 $8 $9 5 2>&1 | grep -E "stamps|TF" | tail -2
