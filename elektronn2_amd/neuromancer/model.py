@@ -225,23 +225,30 @@ class Model(GraphManager):
         return [self.device_grad(p) for p in self.trainable_params]
 
     # ------------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, group=None, weight_by_labelled=True):
+    def enable_data_parallel(self, group=None, weight_by_labelled=True, exchange_at_world_1=False):
         """replicas + gradient exchange.  ``weight_by_labelled``: combine the
         ranks' gradients as the reference's whole-batch normalisation does when the ranks
         see different numbers of labelled voxels (parallel.BucketedMean); one extra
-        one-element all-reduce per step, the plain mean when the counts are equal."""
+        one-element all-reduce per step, the plain mean when the counts are equal.
+        ``exchange_at_world_1``: run the segmented step and its collectives even in a
+        one-rank group (the mean over one rank is the identity) -- the only way to take the
+        RCCL path through its paces on a one-GPU box (tests/test_dp_gpu.py)."""
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self._dp_group = group if group is not None else dist.group.WORLD
         self._dp_weighted = bool(weight_by_labelled)
+        self._dp_force = bool(exchange_at_world_1)
         self.broadcast_params()
 
     def dp_world(self):
+        """ranks that exchange gradients (1: no exchange).  A one-rank group counts as 2
+        when the exchange was forced (enable_data_parallel(exchange_at_world_1=True))."""
         if self._dp_group is None:
             return 1
         import torch.distributed as dist
-        return dist.get_world_size(self._dp_group)
+        w = dist.get_world_size(self._dp_group)
+        return 2 if (w == 1 and getattr(self, '_dp_force', False)) else w
 
     def broadcast_params(self):
         """rank 0's parameters -> everyone (replicas start identical)."""
@@ -267,7 +274,7 @@ class Model(GraphManager):
         from ..parallel import BucketedMean
         return BucketedMean(self.G, self._dp_group,
                             count=count if getattr(self, '_dp_weighted', False) else None,
-                            spare=True)
+                            spare=True, force=getattr(self, '_dp_force', False))
 
     # ------------------------------------------------------------------ functions
     def save(self, file_name):

@@ -54,7 +54,7 @@ class BucketedMean:
     current stream (RCCL runs it on its own stream); finish() makes the current stream
     wait for every slice."""
 
-    def __init__(self, flat, group=None, count=None, spare=False):
+    def __init__(self, flat, group=None, count=None, spare=False, force=False):
         """``count``: one-element tensor with this rank's number of LABELLED target voxels.
         The reference normalises the NLL by the labelled count of the WHOLE batch
         (loss.py:342-344); a rank's gradient is normalised by its own count, so with
@@ -69,6 +69,8 @@ class BucketedMean:
         sizes is pure latency; without a spare slot it takes a one-element all-reduce."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force: run the collectives in a one-rank group too (the sums are identities)
+        self._skip = self.world == 1 and not (force and dist.is_initialized())
         self._work, self._covered = [], 0
         self._count, self._total = count, None
         self._ext = None
@@ -77,7 +79,7 @@ class BucketedMean:
             self._ext = flat.as_strided((n + 1,), (1,), flat.storage_offset())
 
     def start(self, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if self._skip or hi <= lo:
             return
         buf = self.flat
         if self._count is not None:
@@ -94,7 +96,7 @@ class BucketedMean:
         self._covered += min(hi, self.flat.numel()) - lo
 
     def finish(self):
-        if self.world == 1:
+        if self._skip:
             return self.flat
         for w in self._work:
             w.wait()

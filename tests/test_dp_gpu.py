@@ -95,3 +95,56 @@ def test_two_rank_step_overlapped_exchange():
             err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
             assert err < 5e-4, (i, ref.shape, err)
             off += (ref.size + 3) // 4 * 4
+
+
+def _rccl_worker(port, q):
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      LOCAL_RANK="0")
+    from elektronn2_amd import nets, neuromancer as nm
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    x, t = _data(0)
+    t.flat[::7] = -1                              # some unlabelled voxels: the count rides along
+    out = {}
+    for mode in ("plain", "rccl-overlap", "rccl-single"):
+        os.environ["E2_DP_OVERLAP"] = "0" if mode == "rccl-single" else "1"
+        nm.model_manager.reset()
+        m = nets.neuro3d_lite((None, 1) + SP, params=O.init_net(O.NEURO3D_LITE, 1, seed=5))
+        m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        m.loss(x, t)
+        if mode != "plain":
+            m.enable_data_parallel(exchange_at_world_1=True)
+        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(6)]
+        plan = m.optimisers['Adam'].step.func
+        out[mode] = dict(P=m.P.cpu().numpy().copy(), losses=losses,
+                         n_graphs=len(plan._graphs or []), backend=torch.distributed.get_backend())
+    q.put(out)
+    torch.distributed.destroy_process_group()
+
+
+def test_exchange_over_rccl_with_a_one_rank_communicator():
+    """RCCL itself, on the one GPU a test box has: a ONE-rank "nccl" group, the exchange forced
+    (``enable_data_parallel(exchange_at_world_1=True)``).  The mean over one rank is the
+    identity, so the segmented step -- graph A (forward + late backward) | async all-reduce
+    of the arena's tail on RCCL's stream | graph B | all-reduce of the head + the labelled
+    count | wait, scale | graph C (optimiser) -- must reproduce the plain step: same losses,
+    same parameters, for the overlapped and the single-exchange form, eager call and graph
+    replays.  What this covers that gloo cannot: RCCL initialisation, its stream ordering
+    against the plan's stream between hipGraph launches, ``Work.wait()`` on device tensors,
+    arena slices as collective buffers.  (What it cannot: more than one rank.)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=500)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res["rccl-overlap"]["backend"] == "nccl"
+    assert res["plain"]["n_graphs"] == 1
+    assert res["rccl-overlap"]["n_graphs"] == 3 and res["rccl-single"]["n_graphs"] == 2
+    for mode in ("rccl-overlap", "rccl-single"):
+        for a, b in zip(res[mode]["losses"], res["plain"]["losses"]):
+            assert abs(a - b) <= 2e-5 * abs(b), (mode, res[mode]["losses"], res["plain"]["losses"])
+        d = np.abs(res[mode]["P"] - res["plain"]["P"]).max()
+        assert d <= 2e-5 * np.abs(res["plain"]["P"]).max(), (mode, d)
