@@ -389,6 +389,10 @@ def main():
     ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "dense512unet", "warp183", "selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--exchange-at-1", action="store_true",
+                    help="N = 1 only, not the headline: run the data-parallel form of the step "
+                         "(segmented graphs + the RCCL all-reduces) over a ONE-rank nccl group -- "
+                         "what the exchange machinery itself costs per step")
     ap.add_argument("--sources-sha", action="store_true",
                     help="print the identity of the kernel sources + shipped tilings and exit")
     ap.add_argument("--mfma", default=os.environ.get("E2_MFMA_DTYPE", "f32"), choices=["f32", "bf16"],
@@ -429,6 +433,11 @@ def main():
         # RCCL ("nccl") on the GPU node; E2_DIST_BACKEND=gloo only to rehearse the
         # multi-rank flow where the ranks have to share one GPU
         parallel.init_from_env(os.environ.get("E2_DIST_BACKEND", "nccl"))
+    elif args.exchange_at_1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
 
     bf16 = args.mfma == "bf16"
     if bf16:
@@ -466,6 +475,8 @@ def main():
     plan.set_inputs([xs[0], ts[0]])          # builds plan + arena
     if world > 1:
         model.enable_data_parallel()
+    elif args.exchange_at_1:
+        model.enable_data_parallel(exchange_at_world_1=True)
     x_buf, t_buf = plan.input_buffer(plan.inputs[0]), plan.input_buffer(plan.inputs[1])
 
     def one_step(i):
@@ -541,7 +552,9 @@ def main():
                                % ((builder,) + tuple(sp) + tuple(osp) +
                                   ((", conv GEMM operands rounded to bf16, f32 sums, f32 tensors",)
                                    if bf16 else ("",))),
-                   "parallelism": "dp%d" % world, "ranks": ranks,
+                   "parallelism": "dp%d" % world + (" (exchange forced over a one-rank RCCL group)"
+                                                    if args.exchange_at_1 and world == 1 else ""),
+                   "ranks": ranks,
                    "output_voxels_per_sec": float(np.prod(osp)) * world * args.steps / dt,
                    "hipgraph": bool(plan.use_graph), "final_loss": loss},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
