@@ -352,6 +352,19 @@ class Plan(object):
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
         with torch.cuda.stream(self.stream):
+            # the static input buffers of all Input nodes are slices of ONE allocation (each
+            # 16-byte aligned): a producer that stages a batch in the same layout fills them
+            # with a single copy (input_arena; bench.py does)
+            offs, tot = [], 0
+            for n in self.inputs:
+                offs.append(tot)
+                tot += (int(np.prod(self.out_shape(n))) + 3) // 4 * 4
+            self.input_arena = self.empty_flat(max(tot, 4))
+            self.input_slices = {}
+            for n, o in zip(self.inputs, offs):
+                sh = self.out_shape(n)
+                self.out[n] = self.input_arena[o:o + int(np.prod(sh))].view(sh)
+                self.input_slices[n] = (o, int(np.prod(sh)))
             for n in self.nodes:
                 n._plan_alloc(self)
             if getattr(self.ctx, 'mfma_dtype', 'f32') == 'bf16':
@@ -697,7 +710,8 @@ class Plan(object):
 
 
 def _input_alloc(self, plan):
-    plan.out[self] = plan.empty(plan.out_shape(self))
+    if self not in plan.out:                  # (inputs of the plan are slices of its input arena)
+        plan.out[self] = plan.empty(plan.out_shape(self))
 
 
 from .node_basic import Input as _Input   # noqa: E402
