@@ -39,7 +39,7 @@ for c in cands:
         continue
     res.append((t * 1e3, c))
 ctx.set_tiling("igemm", None)
-for kind, sel in (("16x16x4", [r for r in res if r[1].count(",") == 3]),
+for kind, sel in (("16x16x4", [r for r in res if r[1].count(",") in (3, 4)]),
                   ("4x4x1", [r for r in res if r[1].count(",") >= 5])):
     sel.sort()
     print("%s %s %s: %.2f GF, ideal %.1f us" % (op, sys.argv[2:10], kind, gf, gf / 157.3 * 1e3))
