@@ -117,6 +117,9 @@ def _load():
         "e2_conv3d_dgrad_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz]),
         "e2_conv3d_wgrad_bf16_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
         "e2_conv3d_wgrad_bf16": (C.c_int, [vp, P5, P5, fp, i, i, i, i, vp, sz]),
+        "e2_conv3d_bf16_xkeep_bytes": (sz, [i, i, i, i, i, i, i]),
+        "e2_conv3d_fwd_bf16_keep": (C.c_int, [vp, P5, fp, i, i, i, i, fp, i, P5, vp, sz, vp, sz]),
+        "e2_conv3d_wgrad_bf16_xcl": (C.c_int, [vp, P5, vp, i, P5, fp, i, i, i, i, vp, sz]),
         "e2_dense_fwd": (C.c_int, [vp, fp, fp, fp, i, i, i]),
         "e2_dense_dgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
         "e2_dense_wgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
@@ -508,10 +511,26 @@ class Context:
         n, cin, d, h, w = (int(v) for v in x_shape)
         return int(_lib.e2_conv3d_bf16_workspace_bytes(n, cin, d, h, w, int(cout), k[0], k[1], k[2]))
 
-    def conv3d_fwd_bf16(self, x, w, y, bias=None, act='lin', ws=None):
+    @staticmethod
+    def conv_bf16_xkeep_bytes(x_shape, k):
+        """bytes of the forward's kept bf16 copy of x (zero-fill it once)"""
+        n, cin, d, h, w = (int(v) for v in x_shape)
+        return int(_lib.e2_conv3d_bf16_xkeep_bytes(n, cin, d, h, w, k[1], k[2]))
+
+    def conv3d_fwd_bf16(self, x, w, y, bias=None, act='lin', ws=None, xkeep=None):
+        """xkeep: a zero-initialised uint8 buffer of conv_bf16_xkeep_bytes that receives the
+        channels-last bf16 copy of x (read again by conv3d_wgrad_bf16(xcl=...))"""
         cout, cin, kd, kh, kw = w.shape
         if ws is None:
             ws = self.workspace("conv_bf16", self.conv_bf16_ws_bytes(x.shape, cout, (kd, kh, kw)))
+        if xkeep is not None:
+            _chk(_lib.e2_conv3d_fwd_bf16_keep(self.h, C.byref(t5(x)), _fp(w), cout, kd, kh, kw,
+                                              _fp(bias), ACT[act], C.byref(t5(y)),
+                                              C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size(),
+                                              C.c_void_p(xkeep.data_ptr()),
+                                              xkeep.numel() * xkeep.element_size()),
+                 "e2_conv3d_fwd_bf16_keep")
+            return
         _chk(_lib.e2_conv3d_fwd_bf16(self.h, C.byref(t5(x)), _fp(w), cout, kd, kh, kw,
                                      _fp(bias), ACT[act], C.byref(t5(y)),
                                      C.c_void_p(ws.data_ptr()), ws.numel() * ws.element_size()),
@@ -530,11 +549,19 @@ class Context:
         n, cin, d, h, w = (int(v) for v in x_shape)
         return int(_lib.e2_conv3d_wgrad_bf16_workspace_bytes(n, cin, d, h, w, int(cout), k[0], k[1], k[2]))
 
-    def conv3d_wgrad_bf16(self, x, dy, dw, accumulate=False, ws=None):
-        """dw (n_f, n_in, kd, kh, kw) from x and the UNPADDED gradient view dy"""
+    def conv3d_wgrad_bf16(self, x, dy, dw, accumulate=False, ws=None, xcl=None):
+        """dw (n_f, n_in, kd, kh, kw) from x and the UNPADDED gradient view dy; xcl: the
+        forward's kept bf16 copy of x (conv3d_fwd_bf16(xkeep=...)) -- x is not converted again"""
         cout, cin, kd, kh, kw = dw.shape
         if ws is None:
             ws = self.workspace("wgrad_bf16", self.wgrad_bf16_ws_bytes(x.shape, cout, (kd, kh, kw)))
+        if xcl is not None:
+            _chk(_lib.e2_conv3d_wgrad_bf16_xcl(self.h, C.byref(t5(x)), C.c_void_p(xcl.data_ptr()),
+                                               (cin + 15) // 16 * 2, C.byref(t5(dy)), _fp(dw),
+                                               kd, kh, kw, int(accumulate), C.c_void_p(ws.data_ptr()),
+                                               ws.numel() * ws.element_size()),
+                 "e2_conv3d_wgrad_bf16_xcl")
+            return
         _chk(_lib.e2_conv3d_wgrad_bf16(self.h, C.byref(t5(x)), C.byref(t5(dy)), _fp(dw), kd, kh, kw,
                                        int(accumulate), C.c_void_p(ws.data_ptr()),
                                        ws.numel() * ws.element_size()), "e2_conv3d_wgrad_bf16")

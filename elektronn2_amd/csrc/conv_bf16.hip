@@ -373,7 +373,8 @@ static int span_pixels(int BN, int Wo, int Win, int kh, int kw) {
 // the GEMM (forward: n_f; data gradient: n_in), kk = its reduction channels
 static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, int nin, int kd,
                      int kh, int kw, int mode, const float* bias, int act, const e2_tensor5* out,
-                     void* ws, size_t ws_bytes, int MB, int NB) {
+                     void* ws, size_t ws_bytes, int MB, int NB, void* xkeep = nullptr,
+                     size_t xkeep_bytes = 0) {
   const int rows = mode ? nin : nf, kk = mode ? nf : nin;
   E2_REQUIRE(in->c == kk && out->c == rows, "conv_bf16: channel mismatch");
   E2_REQUIRE(out->n == in->n && out->d == in->d - kd + 1 && out->h == in->h - kh + 1 &&
@@ -402,7 +403,11 @@ static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, 
   E2_REQUIRE(ws && ws_bytes >= need, "conv_bf16: workspace of %zu bytes needed, %zu given", need, ws_bytes);
   E2_REQUIRE(((uintptr_t)ws & 15) == 0, "conv_bf16: workspace must be 16-byte aligned");
   E2_REQUIRE((long)ocP * 32 < (1L << 31), "conv_bf16: too many channels");
-  __bf16* xb = reinterpret_cast<__bf16*>(ws);
+  E2_REQUIRE(!xkeep || (xkeep_bytes >= xb_bytes && ((uintptr_t)xkeep & 15) == 0),
+             "conv_bf16: the kept input copy needs %zu bytes, 16-byte aligned (%zu given)", xb_bytes, xkeep_bytes);
+  // (xkeep: the channels-last bf16 copy of the input goes to the caller's buffer instead of
+  // the workspace -- the layer's weight gradient reads it again, e2_conv3d_wgrad_bf16_xcl)
+  __bf16* xb = xkeep ? reinterpret_cast<__bf16*>(xkeep) : reinterpret_cast<__bf16*>(ws);
   __bf16* wb = reinterpret_cast<__bf16*>((char*)ws + ((xb_bytes + 255) / 256) * 256);
   CvP c{in->ptr, in->sn, in->sc, in->sd, in->sh, in->n, in->c, in->d, in->h, in->w, KG, xb};
   const long ctot = (long)in->n * in->d * in->h * KG * in->w;
@@ -471,6 +476,28 @@ extern "C" int e2_conv3d_fwd_bf16(e2_ctx* ctx, const e2_tensor5* x, const float*
   int MB, NB;
   tile_from_ctx(ctx, &MB, &NB);
   return conv_bf16(ctx, x, w, cout, x->c, kd, kh, kw, 0, bias, act, out, ws, ws_bytes, MB, NB);
+}
+
+extern "C" size_t e2_conv3d_bf16_xkeep_bytes(int n, int cin, int d, int h, int w, int kh, int kw) {
+  // the forward's copy [n][z][kg][pixel][8] (kg = channel groups of 8, an even count) + the
+  // zero pixels behind the last plane that the weight gradient's windows run into
+  const size_t pieces = (size_t)n * d * (pad16(cin) / 8) * h * w;
+  const size_t slack = (size_t)(((h - kh + 1) * w + 63) / 64 * 64) + (size_t)(kh - 1) * w + kw + 128;
+  return ((pieces + slack) * 16 + 255) / 256 * 256;
+}
+
+extern "C" int e2_conv3d_fwd_bf16_keep(e2_ctx* ctx, const e2_tensor5* x, const float* w, int cout,
+                                       int kd, int kh, int kw, const float* bias, int act,
+                                       const e2_tensor5* out, void* ws, size_t ws_bytes,
+                                       void* xkeep, size_t xkeep_bytes) {
+  E2_REQUIRE(ctx && w && xkeep, "conv3d_fwd_bf16_keep: null argument");
+  if (int rc = view_ok(x, "conv3d_fwd_bf16_keep x")) return rc;
+  if (int rc = view_ok(out, "conv3d_fwd_bf16_keep out")) return rc;
+  E2_REQUIRE(!bias || act == E2_ACT_LIN || act == E2_ACT_RELU, "conv3d_fwd_bf16_keep: bad act %d", act);
+  int MB, NB;
+  tile_from_ctx(ctx, &MB, &NB);
+  return conv_bf16(ctx, x, w, cout, x->c, kd, kh, kw, 0, bias, act, out, ws, ws_bytes, MB, NB,
+                   xkeep, xkeep_bytes);
 }
 
 extern "C" int e2_conv3d_dgrad_bf16(e2_ctx* ctx, const e2_tensor5* dy_pad, const float* w, int cin,

@@ -108,6 +108,7 @@ struct WbP {
   const __bf16* dyc;
   float* dwt;                         // [Cout][T][CinP] f32 sums (atomics), zeroed by the conversion pass
   int N, Cin, Cout, Din, Do, KG, CinP;
+  int KGs;                            // channel groups per plane IN MEMORY (>= KG: the forward's copy pads to an even count)
   int kd, kh, kw, T;
   int Win, planeD;
   long planePix;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
 #pragma unroll
     for (int c = 0; c < MB; ++c)
       __builtin_amdgcn_global_load_lds((gbl_vp)(ap + aoff[c]), (lds_vp)(lb + adst[c]), 16, 0, 0);
-    const __bf16* xp = p.xcl + ((((long)n * p.Din + z + sz) * p.KG + kg0) * p.planePix +
+    const __bf16* xp = p.xcl + ((((long)n * p.Din + z + sz) * p.KGs + kg0) * p.planePix +
                                 (long)squ * kKU + shiftLo) * 8;
 #pragma unroll
     for (int t = 0; t < kTBmax; ++t)
@@ -397,11 +398,18 @@ extern "C" size_t e2_conv3d_wgrad_bf16_workspace_bytes(int n, int cin, int d, in
   return g.xbytes + g.dbytes + g.tbytes + 256;
 }
 
-extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy, float* dw,
-                                    int kd, int kh, int kw, int accumulate, void* ws,
-                                    size_t ws_bytes) {
+// xcl_ext != nullptr: the channels-last bf16 copy of x already exists (written by the layer's
+// forward pass, e2_conv3d_fwd_bf16_keep: the same layout with kgs_ext channel groups per
+// plane and zero pixels behind the last plane) -- x is used for its shape only
+static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int kgs_ext,
+                      const e2_tensor5* dy, float* dw, int kd, int kh, int kw, int accumulate,
+                      void* ws, size_t ws_bytes) {
   E2_REQUIRE(ctx && dw, "conv3d_wgrad_bf16: null argument");
-  if (int rc = view_ok(x, "conv3d_wgrad_bf16 x")) return rc;
+  if (xcl_ext) {
+    E2_REQUIRE(x && x->n > 0 && x->c > 0 && x->d > 0 && x->h > 0 && x->w > 0, "conv3d_wgrad_bf16_xcl: bad x shape");
+    E2_REQUIRE(kgs_ext >= (x->c + 7) / 8 && ((uintptr_t)xcl_ext & 15) == 0,
+               "conv3d_wgrad_bf16_xcl: %d channel groups per plane for %d channels", kgs_ext, x->c);
+  } else if (int rc = view_ok(x, "conv3d_wgrad_bf16 x")) return rc;
   if (int rc = view_ok(dy, "conv3d_wgrad_bf16 dy")) return rc;
   E2_REQUIRE(dy->n == x->n && dy->d == x->d - kd + 1 && dy->h == x->h - kh + 1 &&
                  dy->w == x->w - kw + 1,
@@ -421,7 +429,8 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   }
   if (NB <= 0) NB = kw >= 4 ? 4 : (kw == 3 ? 3 : kw);        // taps of a kernel row per wave
   E2_REQUIRE((MB == 1 || MB == 2) && NB >= 1 && NB <= 4, "conv3d_wgrad_bf16: MB 1..2, NB 1..4");
-  __bf16* xcl = reinterpret_cast<__bf16*>(ws);
+  __bf16* xcl = xcl_ext ? const_cast<__bf16*>(reinterpret_cast<const __bf16*>(xcl_ext))
+                        : reinterpret_cast<__bf16*>(ws);
   __bf16* dyc = reinterpret_cast<__bf16*>((char*)ws + g.xbytes);
   float* dwt = reinterpret_cast<float*>((char*)ws + g.xbytes + g.dbytes);
   WcP c;
@@ -433,8 +442,8 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   c.xcl = xcl; c.dyc = dyc; c.dwt = dwt; c.nT4 = (long)(g.tbytes / 16);
   c.cx = (int)((g.planePix + 255) / 256);
   c.cd = (g.planeD + 2047) / 2048;
-  const long nbx = (long)x->n * x->d * g.KG * c.cx, nbd = (long)x->n * Cout * dy->d * c.cd;
-  const long nbs = (g.xSlack + 255) / 256, nbt = (c.nT4 + 255) / 256;
+  const long nbx = xcl_ext ? 0 : (long)x->n * x->d * g.KG * c.cx, nbd = (long)x->n * Cout * dy->d * c.cd;
+  const long nbs = xcl_ext ? 0 : (g.xSlack + 255) / 256, nbt = (c.nT4 + 255) / 256;
   E2_REQUIRE(g.planePix < (1L << 30) && nbx + nbd + nbs + nbt < (1L << 31), "conv3d_wgrad_bf16: volume too large");
   c.nbx = (int)nbx; c.nbd = (int)nbd; c.nbs = (int)nbs;
   hipLaunchKernelGGL(wgrad_bf16_cvt_kernel, dim3((unsigned)(nbx + nbd + nbs + nbt)), dim3(256), 0, ctx->stream, c);
@@ -442,6 +451,7 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
   WbP p;
   p.xcl = xcl; p.dyc = dyc; p.dwt = dwt; p.CinP = g.CinP;
   p.N = x->n; p.Cin = Cin; p.Cout = Cout; p.Din = x->d; p.Do = dy->d; p.KG = g.KG;
+  p.KGs = xcl_ext ? kgs_ext : g.KG;
   p.kd = kd; p.kh = kh; p.kw = kw; p.T = T;
   p.Win = x->w; p.planeD = g.planeD; p.planePix = g.planePix;
   p.unitsPerPlane = g.planeD / kKU;
@@ -479,4 +489,17 @@ extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_t
                      (size_t)T * 33 * 4, ctx->stream, dwt, dw, Cin, g.CinP, T, accumulate);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int e2_conv3d_wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const e2_tensor5* dy, float* dw,
+                                    int kd, int kh, int kw, int accumulate, void* ws,
+                                    size_t ws_bytes) {
+  return wgrad_bf16(ctx, x, nullptr, 0, dy, dw, kd, kh, kw, accumulate, ws, ws_bytes);
+}
+
+extern "C" int e2_conv3d_wgrad_bf16_xcl(e2_ctx* ctx, const e2_tensor5* x_shape, const void* xcl,
+                                        int kg_per_plane, const e2_tensor5* dy, float* dw, int kd,
+                                        int kh, int kw, int accumulate, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(xcl, "conv3d_wgrad_bf16_xcl: null copy");
+  return wgrad_bf16(ctx, x_shape, xcl, kg_per_plane, dy, dw, kd, kh, kw, accumulate, ws, ws_bytes);
 }

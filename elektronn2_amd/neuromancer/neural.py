@@ -467,8 +467,10 @@ class Conv(NeuralLayer):
                 if ctx.bf16_memory_form():
                     ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), out,
                                         bias=plan.param(self.b), act=self.activation_func,
-                                        ws=plan.bf16_ws(self))
+                                        ws=plan.bf16_ws(self), xkeep=plan.bf16_xkeep(self))
+                    plan.bf16_xkeep_valid(self, True)
                 else:
+                    plan.bf16_xkeep_valid(self, False)
                     ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self._k3, plan.param(self.b),
                                               self.activation_func, out)
             plan.tuned('igemm', sig,
@@ -483,8 +485,10 @@ class Conv(NeuralLayer):
         got = [1]                              # parts the (last) launch wrote
 
         def fwd_plain():
+            plan.bf16_xkeep_valid(self, ctx.bf16_memory_form())
             if ctx.bf16_memory_form():
-                ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), y, ws=plan.bf16_ws(self))
+                ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), y, ws=plan.bf16_ws(self),
+                                    xkeep=plan.bf16_xkeep(self))
                 got[0] = 1
             elif yp.shape[0] > 1:
                 got[0] = ctx.conv3d_fwd_packed_parts(x, wp, self.n_f, self._k3, yp)
@@ -582,7 +586,10 @@ class Conv(NeuralLayer):
 
         def wgrad(accumulate):
             if ctx.bf16_memory_wgrad():     # "32,MB,NB,0,S": bf16 operands in memory
-                ctx.conv3d_wgrad_bf16(x, dy, dw, accumulate=accumulate, ws=wws)
+                # (the forward's channels-last bf16 copy of x, when this step's forward of
+                # the layer was the memory form: one conversion pass less)
+                ctx.conv3d_wgrad_bf16(x, dy, dw, accumulate=accumulate, ws=wws,
+                                      xcl=plan.bf16_xkeep(self, only_valid=True))
             else:
                 ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=accumulate)
         # the weight gradient is independent of the data-gradient chain below: side stream

@@ -182,6 +182,28 @@ class Plan(object):
         if need_c:
             self.scratch['bf16_ws'] = torch.empty(need_c, dtype=torch.uint8, device=self.ctx.device)
 
+    def bf16_xkeep(self, node, only_valid=False):
+        """the per-layer buffer that keeps the forward's channels-last bf16 copy of the layer's
+        input for its weight gradient (zero-filled once: the pixels behind the last plane are
+        never written); ``only_valid``: None unless this step's forward filled it"""
+        if os.environ.get("E2_BF16_XKEEP", "1") != "1":
+            return None
+        if only_valid and not self._xkeep_valid.get(node, False):
+            return None
+        buf = self.scratch.get((node, 'xb_keep'))
+        if buf is None:
+            if only_valid:
+                return None
+            if self._capturing:
+                raise RuntimeError("bf16 kept-copy buffer must exist before capture")
+            need = self.ctx.conv_bf16_xkeep_bytes(self.out_shape(node.parent), node._k3)
+            buf = torch.zeros(need, dtype=torch.uint8, device=self.ctx.device)
+            self.scratch[node, 'xb_keep'] = buf
+        return buf
+
+    def bf16_xkeep_valid(self, node, ok):
+        self._xkeep_valid[node] = bool(ok)
+
     def bf16_wgrad_ws(self, node):
         """the scratch of csrc/wgrad_bf16.hip (bf16 copies of x and dy, the f32 sums): its own
         buffer, because the weight gradient runs on the side stream next to the data
@@ -349,6 +371,7 @@ class Plan(object):
         # bias-gradient atomics of split-K grids cost more (neuro3d@185 +0.7 ms) -- off
         self.fuse_actbwd = int(os.environ.get("E2_FUSE_ACTBWD", "0"))
         self.out, self.grad, self.scratch = {}, {}, {}
+        self._xkeep_valid = {}       # Conv node -> its kept bf16 input copy is this step's
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
         with torch.cuda.stream(self.stream):

@@ -424,6 +424,19 @@ size_t e2_conv3d_wgrad_bf16_workspace_bytes(int n, int cin, int d, int h, int w,
                                             int kd, int kh, int kw);
 int e2_conv3d_wgrad_bf16(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy, float* dw, int kd,
                          int kh, int kw, int accumulate, void* ws, size_t ws_bytes);
+/* One conversion less per layer and step: e2_conv3d_fwd_bf16_keep writes the bf16
+ * channels-last copy of its input into a buffer of the caller's (e2_conv3d_bf16_xkeep_bytes,
+ * zero-filled ONCE by the caller: the pixels behind the last plane stay zero) instead of the
+ * shared workspace, and e2_conv3d_wgrad_bf16_xcl reads that copy (kg_per_plane = channel
+ * groups of 8 per plane in it = ceil(cin / 16) * 2; x_shape: the input's extents, its
+ * pointer and strides are not used) instead of converting x again. */
+size_t e2_conv3d_bf16_xkeep_bytes(int n, int cin, int d, int h, int w, int kh, int kw);
+int e2_conv3d_fwd_bf16_keep(e2_ctx*, const e2_tensor5* x, const float* w, int cout, int kd,
+                            int kh, int kw, const float* bias, int act, const e2_tensor5* out,
+                            void* ws, size_t ws_bytes, void* xkeep, size_t xkeep_bytes);
+int e2_conv3d_wgrad_bf16_xcl(e2_ctx*, const e2_tensor5* x_shape, const void* xcl,
+                             int kg_per_plane, const e2_tensor5* dy, float* dw, int kd, int kh,
+                             int kw, int accumulate, void* ws, size_t ws_bytes);
 
 /* ---- BASELINE config 1 (examples/mnist.py:29-56): Perceptron and batch normalisation ----
  * Correctness-first kernels for the reference's CPU-runnable plumbing case.

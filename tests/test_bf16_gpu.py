@@ -252,5 +252,17 @@ def test_wgrad_with_bf16_operands_in_memory(ctx, case, tile):
         assert 1e-5 < e < 2e-2, e
         ctx.conv3d_wgrad_bf16(dev(x), dyv, dw, accumulate=True)
         assert relerr(dw, 2 * ref) < TOL
+        # the forward's kept channels-last copy of x instead of a second conversion
+        # (e2_conv3d_fwd_bf16_keep -> e2_conv3d_wgrad_bf16_xcl); the x handed to the weight
+        # gradient is poisoned: only its shape may be used
+        w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k))).astype(np.float32)
+        keep = torch.zeros(ctx.conv_bf16_xkeep_bytes(x.shape, k), dtype=torch.uint8, device="cuda")
+        y = torch.empty((N, Co) + osp, device="cuda")
+        ctx.conv3d_fwd_bf16(dev(x), dev(w), y, xkeep=keep)
+        assert relerr(y, O.conv3d_fwd(bf16_round(x), bf16_round(w))) < TOL
+        poison = torch.full(x.shape, float("nan"), device="cuda")
+        dw.fill_(float("nan"))
+        ctx.conv3d_wgrad_bf16(poison, dyv, dw, xcl=keep)
+        assert relerr(dw, ref) < TOL
     finally:
         ctx.set_tiling("wgrad", None)
