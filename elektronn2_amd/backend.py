@@ -100,6 +100,9 @@ def _load():
         "e2_upconv3d_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
         "e2_upconv3d_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, P5, vp, sz]),
         "e2_upconv3d_bwd": (C.c_int, [vp, P5, fp, P5, P5, i, i, i, i, P5, fp, fp, vp, sz]),
+        "e2_upconv3d_image_bytes": (sz, [i, i, i, i, i]),
+        "e2_upconv3d_fwd_packed": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, P5]),
+        "e2_upconv3d_bwd_packed": (C.c_int, [vp, P5, fp, P5, P5, i, i, i, i, P5, fp, fp, vp, sz, i]),
         "e2_transpose_ncdhw_to_ndhwc": (C.c_int, [vp, P5, fp]),
         "e2_transpose_ndhwc_to_ncdhw": (C.c_int, [vp, fp, P5]),
         "e2_copy5": (C.c_int, [vp, P5, P5, i]),
@@ -460,6 +463,27 @@ class Context:
                                   C.byref(t5(dx)) if dx is not None else None,
                                   _fp(dw), _fp(dbias), C.c_void_p(ws.data_ptr()),
                                   ws.numel() * 4), "e2_upconv3d_bwd")
+
+    @staticmethod
+    def upconv_image_bytes(cout, cin, pool):
+        return int(_lib.e2_upconv3d_image_bytes(int(cout), int(cin), pool[0], pool[1], pool[2]))
+
+    def upconv3d_fwd_packed(self, x, wp_fwd, bias, cout, pool, act, y):
+        """the forward with the image a mode-2 pack job keeps current (make_pack_jobs)"""
+        _chk(_lib.e2_upconv3d_fwd_packed(self.h, C.byref(t5(x)), _fp(wp_fwd), _fp(bias), int(cout),
+                                         pool[0], pool[1], pool[2], ACT[act], C.byref(t5(y))),
+             "e2_upconv3d_fwd_packed")
+
+    def upconv3d_bwd_packed(self, x, wp_dgrad, y, dout, pool, act, dx, dw, dbias, ws,
+                            accumulate=False):
+        """the backward with the data gradient's image of a mode-3 pack job; accumulate: dw
+        and dbias are added to (the caller zeroed them)"""
+        _chk(_lib.e2_upconv3d_bwd_packed(self.h, C.byref(t5(x)), _fp(wp_dgrad), C.byref(t5(y)),
+                                         C.byref(t5(dout)), pool[0], pool[1], pool[2], ACT[act],
+                                         C.byref(t5(dx)) if dx is not None else None,
+                                         _fp(dw), _fp(dbias), C.c_void_p(ws.data_ptr()),
+                                         ws.numel() * 4, int(bool(accumulate))),
+             "e2_upconv3d_bwd_packed")
 
     # ---- layout ------------------------------------------------------------------
     def to_ndhwc(self, src, dst):

@@ -416,10 +416,12 @@ extern "C" size_t e2_upconv3d_workspace_bytes(int cout, int cin, int pz, int py,
                           (size_t)n * cout * R * d * h * w) + 512;
 }
 
-extern "C" int e2_upconv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
-                               const float* bias, int cout, int pz, int py, int px, int act,
-                               const e2_tensor5* y, void* ws, size_t ws_bytes) {
-  E2_REQUIRE(ctx && w && ws, "upconv3d_fwd: null argument");
+// wp != nullptr: the packed image exists (a pack job of mode 2, e2_pack_job_fill); else the
+// canonical weights w are packed into the workspace first
+static int upconv_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w, const float* wp,
+                      const float* bias, int cout, int pz, int py, int px, int act,
+                      const e2_tensor5* y, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(ctx && (wp || (w && ws)), "upconv3d_fwd: null argument");
   if (int rc = view_ok(x, "upconv3d_fwd x")) return rc;
   if (int rc = view_ok(y, "upconv3d_fwd y")) return rc;
   E2_REQUIRE(pz >= 1 && py >= 1 && px >= 1, "upconv3d_fwd: bad factors");
@@ -427,14 +429,17 @@ extern "C" int e2_upconv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
                  y->w == x->w * px, "upconv3d_fwd: y shape mismatch");
   E2_REQUIRE(bias || act == E2_ACT_LIN, "upconv3d_fwd: act needs bias");
   const int R = pz * py * px;
-  E2_REQUIRE(ws_bytes >= sizeof(float) * up_pack_floats(cout, x->c, R),
-             "upconv3d_fwd: workspace too small");
   IgemmArgs a;
   e2i_pack_dims(cout * R, x->c, &a.ciP, &a.coP);
-  if (int rc = e2i_pack_weights(ctx, w, (float*)ws, cout * R, x->c, 1, 1, 1,
-                                (int64_t)x->c * R, R, 0, a.ciP, a.coP, R, 1))
-    return rc;
-  a.in = x->ptr; a.wp = (const float*)ws; a.out = y->ptr;
+  if (!wp) {
+    E2_REQUIRE(ws_bytes >= sizeof(float) * up_pack_floats(cout, x->c, R),
+               "upconv3d_fwd: workspace too small");
+    if (int rc = e2i_pack_weights(ctx, w, (float*)ws, cout * R, x->c, 1, 1, 1,
+                                  (int64_t)x->c * R, R, 0, a.ciP, a.coP, R, 1))
+      return rc;
+    wp = (const float*)ws;
+  }
+  a.in = x->ptr; a.wp = wp; a.out = y->ptr;
   a.N = x->n; a.Cin = x->c; a.Cout = cout * R;
   a.kd = a.kh = a.kw = 1;
   a.Do = x->d; a.Ho = x->h; a.Wo = x->w;
@@ -446,11 +451,33 @@ extern "C" int e2_upconv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
   return 0;
 }
 
-extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
-                               const e2_tensor5* y, const e2_tensor5* dout, int pz, int py,
-                               int px, int act, const e2_tensor5* dx, float* dw,
-                               float* dbias, void* ws, size_t ws_bytes) {
-  E2_REQUIRE(ctx && w && ws, "upconv3d_bwd: null argument");
+extern "C" int e2_upconv3d_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
+                               const float* bias, int cout, int pz, int py, int px, int act,
+                               const e2_tensor5* y, void* ws, size_t ws_bytes) {
+  E2_REQUIRE(w && ws, "upconv3d_fwd: null argument");
+  return upconv_fwd(ctx, x, w, nullptr, bias, cout, pz, py, px, act, y, ws, ws_bytes);
+}
+
+extern "C" size_t e2_upconv3d_image_bytes(int cout, int cin, int pz, int py, int px) {
+  return sizeof(float) * up_pack_floats(cout, cin, pz * py * px) + 256;
+}
+
+extern "C" int e2_upconv3d_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const float* wp_fwd,
+                                      const float* bias, int cout, int pz, int py, int px,
+                                      int act, const e2_tensor5* y) {
+  E2_REQUIRE(wp_fwd, "upconv3d_fwd_packed: null image");
+  return upconv_fwd(ctx, x, nullptr, wp_fwd, bias, cout, pz, py, px, act, y, nullptr, 0);
+}
+
+// accumulate: dw and dbias are ADDED to (the caller zeroed them: the plan clears the whole
+// gradient arena with one launch at the start of the backward pass) -- two fills less
+// wp_d != nullptr: the data gradient's packed image exists (pack job of mode 3)
+static int upconv_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
+                      const e2_tensor5* y, const e2_tensor5* dout, int pz, int py,
+                      int px, int act, const e2_tensor5* dx, float* dw,
+                      float* dbias, void* ws, size_t ws_bytes, int accumulate,
+                      const float* wp_d = nullptr) {
+  E2_REQUIRE(ctx && (w || wp_d) && ws, "upconv3d_bwd: null argument");
   if (int rc = view_ok(x, "upconv3d_bwd x")) return rc;
   if (int rc = view_ok(y, "upconv3d_bwd y")) return rc;
   if (int rc = view_ok(dout, "upconv3d_bwd dout")) return rc;
@@ -464,7 +491,7 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
   float* wp = (float*)ws;
   size_t off = (up_pack_floats(cout, cin, R) + 63) & ~(size_t)63;
   float* s2d = wp + off;
-  if (dbias)
+  if (dbias && !accumulate)
     if (int rc = e2i_fill_flat(ctx, dbias, (size_t)cout, 0.f)) return rc;
   if (int rc = e2i_upconv_dpre_s2d(ctx, dout, y, pz, py, px, act, s2d, dbias)) return rc;
   const long S = (long)x->d * x->h * x->w;
@@ -475,10 +502,11 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
     IgemmArgs a;
     e2i_pack_dims(cin, cout * R, &a.ciP, &a.coP);
     // Wp[ic' = co*R + r][oc = ci] = w[co][ci][r]
-    if (int rc = e2i_pack_weights(ctx, w, wp, cin, cout * R, 1, 1, 1, R, (int64_t)cin * R,
-                                  0, a.ciP, a.coP, 1, R))
-      return rc;
-    a.in = s2d; a.wp = wp; a.out = dx->ptr;
+    if (!wp_d)
+      if (int rc = e2i_pack_weights(ctx, w, wp, cin, cout * R, 1, 1, 1, R, (int64_t)cin * R,
+                                    0, a.ciP, a.coP, 1, R))
+        return rc;
+    a.in = s2d; a.wp = wp_d ? wp_d : wp; a.out = dx->ptr;
     a.N = x->n; a.Cin = cout * R; a.Cout = cin;
     a.kd = a.kh = a.kw = 1;
     a.Do = x->d; a.Ho = x->h; a.Wo = x->w;
@@ -500,10 +528,26 @@ extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
     g.dsN = (long)cout * R * S; g.dsC = S; g.dsZ = (long)x->h * x->w; g.dsY = x->w;
     g.flip = 0;
     g.upR = R;
-    g.accumulate = 0;
+    g.accumulate = accumulate;
     if (int rc = e2i_wgrad_conv(ctx, g)) return rc;
   }
   return 0;
+}
+
+extern "C" int e2_upconv3d_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
+                               const e2_tensor5* y, const e2_tensor5* dout, int pz, int py,
+                               int px, int act, const e2_tensor5* dx, float* dw,
+                               float* dbias, void* ws, size_t ws_bytes) {
+  return upconv_bwd(ctx, x, w, y, dout, pz, py, px, act, dx, dw, dbias, ws, ws_bytes, 0);
+}
+
+extern "C" int e2_upconv3d_bwd_packed(e2_ctx* ctx, const e2_tensor5* x, const float* wp_dgrad,
+                                      const e2_tensor5* y, const e2_tensor5* dout, int pz,
+                                      int py, int px, int act, const e2_tensor5* dx, float* dw,
+                                      float* dbias, void* ws, size_t ws_bytes, int accumulate) {
+  E2_REQUIRE(wp_dgrad || !dx, "upconv3d_bwd_packed: null image");
+  return upconv_bwd(ctx, x, nullptr, y, dout, pz, py, px, act, dx, dw, dbias, ws, ws_bytes,
+                    accumulate ? 1 : 0, wp_dgrad);
 }
 
 // ---------------------------------------------------------------------------

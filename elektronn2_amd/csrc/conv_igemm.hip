@@ -92,6 +92,8 @@ struct PackJobDev {
   int flip, ciP, coP;
   long total;
   PackDiv dT, dKT, d32T, dTHW;       // divisors of the tiled repack (T, ICT*T, 32*T, THW)
+  int up, Rout, Rin;                 // up: an UpConv image (e2_pack_job_fill modes 2 / 3) -- the
+                                     // sub-position r of w[co][ci][r] folded into the row / k index
 };
 __global__ void pack_multi_gather_kernel(const PackJobDev* __restrict__ jobs) {
   // Only the part of an image that the kernels actually fetch is rewritten: the channel
@@ -140,6 +142,18 @@ __host__ __device__ inline int e2_pack_ict(int T) {
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobDev* __restrict__ jobs) {
   __shared__ float tile[kPackTileFloats];
   const PackJobDev j = jobs[blockIdx.y];
+  if (j.up) {
+    // UpConv (one tap, Wp[cg][qd][oc']): the whole image, as pack_weights_kernel writes it
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < j.total; i += (long)gridDim.x * 256) {
+      const int oc = (int)(i % j.coP);
+      const int ic = (int)(i / j.coP);
+      float v = 0.f;
+      if (oc < j.Cout && ic < j.Cin)
+        v = j.w[(long)(oc / j.Rout) * j.wsO + (long)(ic / j.Rin) * j.wsI + (oc % j.Rout) + (ic % j.Rin)];
+      j.wp[i] = v;
+    }
+    return;
+  }
   const int T = j.kd * j.THW;
   const int nCG = j.ciP >> 2;
   const int nCGw = min(nCG, ((j.Cin + 3) >> 2) + 4);
@@ -192,6 +206,24 @@ extern "C" int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, i
              "(use e2_conv3d_pack)", kd * kh * kw);
   PackJobDev* j = (PackJobDev*)rec;
   const int T = kd * kh * kw;
+  j->up = 0; j->Rout = j->Rin = 1;
+  if (mode == 2 || mode == 3) {
+    // UpConv weights w[cout][cin][R = kd*kh*kw sub-positions]; mode 2: the forward GEMM's image
+    // (rows oc' = co*R + r, k = ci), mode 3: the data gradient's (rows ci, k = co*R + r) --
+    // what e2_upconv3d_fwd / _bwd pack per call (api.hip)
+    const int R = T;
+    j->w = w; j->wp = (float*)wp; j->kd = 1; j->THW = 1; j->flip = 0; j->up = 1;
+    if (mode == 2) {
+      j->Cout = cout * R; j->Cin = cin; j->wsO = (long)cin * R; j->wsI = R; j->Rout = R;
+      e2i_pack_dims(cout * R, cin, &j->ciP, &j->coP);
+    } else {
+      j->Cout = cin; j->Cin = cout * R; j->wsO = R; j->wsI = (long)cin * R; j->Rin = R;
+      e2i_pack_dims(cin, cout * R, &j->ciP, &j->coP);
+    }
+    j->total = (long)j->ciP * j->coP;
+    j->dT = j->dKT = j->d32T = j->dTHW = mk_pack_div(1);
+    return 0;
+  }
   j->w = w; j->wp = (float*)wp; j->kd = kd; j->THW = kh * kw;
   if (mode == 0) {
     j->Cout = cout; j->Cin = cin; j->wsO = (long)cin * T; j->wsI = T; j->flip = 1;

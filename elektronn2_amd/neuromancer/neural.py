@@ -861,8 +861,21 @@ class UpConv(Conv):
     def _plan_alloc(self, plan):
         plan.alloc_out(self)
         xs = plan.out_shape(self.parent)
-        nb = plan.ctx.upconv_ws_bytes(self.n_f, self.parent.shape['f'], self.pool_shape, xs)
+        cin = self.parent.shape['f']
+        nb = plan.ctx.upconv_ws_bytes(self.n_f, cin, self.pool_shape, xs)
         plan.scratch[self, 'ws'] = plan.empty_flat(nb // 4 + 64)
+        # the two packed images, refreshed by the plan's one repack launch per step (they
+        # used to be repacked inside every forward and backward call: two launches per node)
+        w5 = plan._w5(plan.param(self.w))
+        import os
+        if w5.dim() == 5 and tuple(w5.shape[2:]) == tuple(self.pool_shape) \
+                and os.environ.get("E2_UPCONV_PACKED", "1") == "1":
+            ib = plan.ctx.upconv_image_bytes(self.n_f, cin, self.pool_shape)
+            plan.scratch[self, 'wp_f'] = plan.zeros_flat(ib // 4 + 64)
+            plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 2))
+            if plan.training and plan.needs_grad(self.parent):
+                plan.scratch[self, 'wp_d'] = plan.zeros_flat(ib // 4 + 64)
+                plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_d'], 3))
 
     def _tune_sigs(self, plan):
         """the GEMMs inside e2_upconv3d_fwd / _bwd: forward M = Cout*R, K = Cin over the INPUT
@@ -879,11 +892,21 @@ class UpConv(Conv):
 
     def _plan_fwd(self, plan):
         sig, cands = self._tune_sigs(plan)['fwd']
-        plan.tuned('igemm', sig, cands,
-                   lambda: plan.ctx.upconv3d_fwd(plan.out[self.parent], plan.param(self.w),
-                                                 plan.param(self.b), self.pool_shape,
-                                                 self.activation_func, plan.out[self],
-                                                 plan.scratch[self, 'ws']))
+        wp = plan.scratch.get((self, 'wp_f'))
+        if wp is not None:
+            plan.join_side()                  # (the repack may run on the side stream)
+
+        def run():
+            if wp is not None:
+                plan.ctx.upconv3d_fwd_packed(plan.out[self.parent], wp, plan.param(self.b),
+                                             self.n_f, self.pool_shape, self.activation_func,
+                                             plan.out[self])
+            else:
+                plan.ctx.upconv3d_fwd(plan.out[self.parent], plan.param(self.w),
+                                      plan.param(self.b), self.pool_shape,
+                                      self.activation_func, plan.out[self],
+                                      plan.scratch[self, 'ws'])
+        plan.tuned('igemm', sig, cands, run)
 
     def _plan_bwd(self, plan):
         ctx = plan.ctx
@@ -892,15 +915,24 @@ class UpConv(Conv):
         if plan.needs_grad(self.parent):
             dst, first = plan.grad_slot(self.parent)
             dx = dst if first else plan.tmp_like(dst)
-        # one call = space-to-depth + data-gradient GEMM + weight-gradient GEMM, all of them
-        # overwriting their outputs (idempotent): each GEMM's tiling is tuned with the
-        # other at its best known one
+        # one call = space-to-depth + data-gradient GEMM + weight-gradient GEMM.  The eager
+        # form overwrites every output (idempotent: the tuner may run it many times, each
+        # GEMM's tiling tuned with the other at its best known one); the captured form adds
+        # dw and dbias to the gradient arena the plan has zeroed (two fill launches less)
         sigs = self._tune_sigs(plan)
+        wp_d = plan.scratch.get((self, 'wp_d'))
+        packed = (self, 'wp_f') in plan.scratch and (dx is None or wp_d is not None)
 
         def run():
-            ctx.upconv3d_bwd(plan.out[self.parent], plan.param(self.w), plan.out[self],
-                             plan.grad[self], self.pool_shape, self.activation_func, dx,
-                             plan.pgrad(self.w), plan.pgrad(self.b), plan.scratch[self, 'ws'])
+            if packed:
+                ctx.upconv3d_bwd_packed(plan.out[self.parent], wp_d, plan.out[self],
+                                        plan.grad[self], self.pool_shape, self.activation_func,
+                                        dx, plan.pgrad(self.w), plan.pgrad(self.b),
+                                        plan.scratch[self, 'ws'], accumulate=plan._capturing)
+            else:
+                ctx.upconv3d_bwd(plan.out[self.parent], plan.param(self.w), plan.out[self],
+                                 plan.grad[self], self.pool_shape, self.activation_func, dx,
+                                 plan.pgrad(self.w), plan.pgrad(self.b), plan.scratch[self, 'ws'])
         plan.tuned('igemm', sigs['dgrad'][0], sigs['dgrad'][1] if dx is not None else [],
                    lambda: plan.tuned('wgrad', sigs['wgrad'][0], sigs['wgrad'][1], run))
         if dx is not None and not first:

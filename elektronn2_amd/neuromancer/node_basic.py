@@ -582,22 +582,58 @@ class Concat(Node):
     def _calc_comp_cost(self):
         self.computational_cost = 0
 
+    def _plan_alloc(self, plan):
+        """A parent that feeds ONLY this concat does not need buffers of its own: an UpConv
+        (its GEMM and bias / activation kernels write any strided view) gets its channel slice
+        of the concat buffer as output and the slice of the concat gradient as gradient; a
+        Crop (a view of ITS parent's output, which others read too) keeps the forward copy
+        but takes the gradient slice.  Per U-Net merge that removes one copy launch from the
+        forward and two from the backward pass (E2_CONCAT_ALIAS=0: every parent is copied)."""
+        import os
+        plan.alloc_out(self)
+        alias = plan.scratch[self, 'alias'] = {}
+        if self.axis != 1 or os.environ.get("E2_CONCAT_ALIAS", "1") != "1":
+            return
+        out, g = plan.out[self], plan.grad.get(self)
+        c0 = 0
+        for p in self.parent:
+            c = p.shape['f']
+            sole = (len(p.children) == 1 and not any(p is o for o in plan.outputs)
+                    and sum(1 for q in self.parent if q is p) == 1)
+            kind = type(p).__name__
+            if sole and kind == 'UpConv' and p in plan.out:
+                plan.out[p] = out[:, c0:c0 + c]
+                alias[p] = 'out'
+                if g is not None and p in plan.grad:
+                    plan.grad[p] = g[:, c0:c0 + c]
+                    alias[p] = 'out+grad'
+            elif sole and kind == 'Crop' and g is not None and p in plan.grad:
+                plan.grad[p] = g[:, c0:c0 + c]
+                alias[p] = 'grad'
+            c0 += c
+
     def _plan_fwd(self, plan):
         if self.axis != 1:
             raise NotImplementedError("HIP Concat only along the feature axis")
         out = plan.out[self]
+        alias = plan.scratch[self, 'alias']
         c0 = 0
         for p in self.parent:
             c = p.shape['f']
-            plan.ctx.copy5(plan.out[p], out[:, c0:c0 + c])
+            if 'out' not in alias.get(p, ''):         # (an aliased parent wrote its slice itself)
+                plan.ctx.copy5(plan.out[p], out[:, c0:c0 + c])
             c0 += c
 
     def _plan_bwd(self, plan):
         g = plan.grad[self]
+        alias = plan.scratch[self, 'alias']
         c0 = 0
         for p in self.parent:
             c = p.shape['f']
-            plan.add_grad(p, g[:, c0:c0 + c])
+            if 'grad' in alias.get(p, ''):
+                plan._grad_written.add(id(p))         # its gradient buffer IS this slice
+            else:
+                plan.add_grad(p, g[:, c0:c0 + c])
             c0 += c
 
 

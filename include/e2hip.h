@@ -166,7 +166,9 @@ int e2_conv3d_wgrad_pad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy_pad,
  * record per (tensor, mode) with e2_pack_job_fill on the host, copy the records
  * (e2_pack_job_bytes() each) to the device, then call e2_conv3d_pack_multi.  It
  * rewrites the weight-carrying part of every image only: the images must have been
- * zero-filled (or packed by e2_conv3d_pack) once before the first call. */
+ * zero-filled (or packed by e2_conv3d_pack) once before the first call.  mode 0 / 1: a
+ * conv's forward / data-gradient image; mode 2 / 3: an UpConv's (w [cout][cin][kd][kh][kw]
+ * with the factors in place of the kernel extents; see e2_upconv3d_fwd_packed). */
 size_t e2_pack_job_bytes(void);
 int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin,
                      int kd, int kh, int kw, int mode);
@@ -260,6 +262,20 @@ int e2_upconv3d_bwd(e2_ctx*, const e2_tensor5* x, const float* w,
                     int pz, int py, int px, int act,
                     const e2_tensor5* dx, float* dw, float* dbias,
                     void* ws, size_t ws_bytes);
+/* The same with the two packed weight images kept by the caller and refreshed once per step
+ * by e2_conv3d_pack_multi (e2_pack_job_fill modes 2 = forward image, 3 = data-gradient image;
+ * e2_upconv3d_image_bytes each) instead of a repack launch inside every call; ws of the
+ * backward (e2_upconv3d_workspace_bytes) still holds the space-to-depth image.  accumulate
+ * != 0: dw and dbias are ADDED to -- the caller cleared them (the training plan zeroes the
+ * whole gradient arena with one launch), two fill launches less; dx is overwritten. */
+size_t e2_upconv3d_image_bytes(int cout, int cin, int pz, int py, int px);
+int e2_upconv3d_fwd_packed(e2_ctx*, const e2_tensor5* x, const float* wp_fwd,
+                           const float* bias, int cout, int pz, int py, int px, int act,
+                           const e2_tensor5* y);
+int e2_upconv3d_bwd_packed(e2_ctx*, const e2_tensor5* x, const float* wp_dgrad,
+                           const e2_tensor5* y, const e2_tensor5* dout, int pz, int py, int px,
+                           int act, const e2_tensor5* dx, float* dw, float* dbias, void* ws,
+                           size_t ws_bytes, int accumulate);
 
 /* ---- layout / copies (computations.py:398-401,414-428 dimshuffles;
  *      neural.py:1152-1168 Crop; node_basic.py:1433-1440 Concat) ---------- */

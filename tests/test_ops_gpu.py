@@ -651,6 +651,38 @@ def test_upconv3d(ctx, case):
     assert relerr(dx, O.upconv3d_dgrad(dpre, w, pool)) < TOL
     assert relerr(dw, O.upconv3d_wgrad(dpre, x, pool)) < TOL
     assert relerr(db, db_ref) < TOL
+    # the form the training plan uses: both images kept current by ONE repack launch for all
+    # layers (pack jobs of mode 2 / 3 next to a conv's), the output a channel slice of a
+    # wider buffer (the concat it feeds), dw / dbias ADDED to a zeroed gradient arena
+    nb = ctx.upconv_image_bytes(Co, Ci, pool) // 4 + 64
+    wp_f = torch.zeros(nb, device="cuda")
+    wp_d = torch.zeros(nb, device="cuda")
+    wc = (rng.randn(7, 5, 1, 3, 3)).astype(np.float32)            # a conv job in the same launch
+    wpc = torch.zeros(ctx.conv_ws_bytes(7, 5, (1, 3, 3)) // 4 + 64, device="cuda")
+    wd, wcd = dev(w), dev(wc)
+    jobs = ctx.make_pack_jobs([(wd, wp_f, 2), (wcd, wpc, 0), (wd, wp_d, 3)])
+    ctx.conv3d_pack_multi(*jobs)
+    ref_img = torch.zeros_like(wpc)
+    ctx.conv3d_pack(wcd, 0, ref_img)
+    assert torch.equal(wpc, ref_img)                    # the conv job is untouched by its neighbours
+    wide = torch.full((N, Co + 3) + tuple(y_ref.shape[2:]), float("nan"), device="cuda")
+    yv = wide[:, 2:2 + Co]
+    ctx.upconv3d_fwd_packed(dev(x), wp_f, dev(b), Co, pool, act, yv)
+    assert torch.equal(yv, y)                           # same GEMM, same image: bit for bit
+    gw = torch.full((N, Co + 3) + tuple(y_ref.shape[2:]), float("nan"), device="cuda")
+    gv = gw[:, 2:2 + Co]
+    gv.copy_(dev(dout))
+    ws = torch.empty(ctx.upconv_ws_bytes(Co, Ci, pool, x.shape) // 4 + 64, device="cuda")
+    dx2 = torch.full(x.shape, float("nan"), device="cuda")
+    dw2 = torch.full(w.shape, 1.0, device="cuda")
+    db2 = torch.full((Co,), 2.0, device="cuda")
+    ctx.upconv3d_bwd_packed(dev(x), wp_d, yv, gv, pool, act, dx2, dw2, db2, ws, accumulate=True)
+    assert relerr(dx2, O.upconv3d_dgrad(dpre, w, pool)) < TOL
+    assert relerr(dw2, O.upconv3d_wgrad(dpre, x, pool) + 1.0) < TOL
+    assert relerr(db2, db_ref + 2.0) < TOL
+    ctx.upconv3d_bwd_packed(dev(x), wp_d, yv, gv, pool, act, dx2, dw2, db2, ws)   # overwrite form
+    assert relerr(dw2, O.upconv3d_wgrad(dpre, x, pool)) < TOL
+    assert relerr(db2, db_ref) < TOL
 
 
 def test_transposes_and_copy(ctx):
