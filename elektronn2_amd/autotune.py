@@ -129,20 +129,30 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
             for cc in ccs:
                 for sk in sks:
                     cands.append("%d,%d,%d,%d" % (mt, nt, cc, sk))
-    return cands + igemm4_candidates(cout, cin, k, out_sp, split_k) + pointwise_candidates(cout, k)
+    return cands + igemm4_candidates(cout, cin, k, out_sp, split_k) + pointwise_candidates(cout, k, cin)
 
 
 PW_MTS = (4, 5, 6, 7, 8, 10, 13, 16)
 
 
-def pointwise_candidates(cout, k):
+def pointwise_candidates(cout, k, cin=1 << 30):
     """"1,MT,NT": the 1x1x1 GEMM with LDS-staged weights (csrc/conv_pw.hip): all 16*MT
     channels of an M tile x 64*NT positions per work-group"""
     if tuple(k) != (1, 1, 1) or cout < 48:
         return []
     mblocks = -(-cout // 16)
-    return ["1,%d,%d" % (mt, nt) for mt in _best_mts(mblocks, PW_MTS, keep=3) for nt in (1, 2)
-            if not (mt == 16 and nt == 2)]
+    out = []
+    for mt in _best_mts(mblocks, PW_MTS, keep=3):
+        for nt in (1, 2):
+            if mt == 16 and nt == 2:
+                continue
+            out.append("1,%d,%d" % (mt, nt))
+            # longer pipeline chunks ("1,MT,NT,KC,0"): what fits LDS twice and the registers
+            for kc in (64, 128):
+                bms = 16 * mt if (16 * mt) % 32 == 16 else 16 * mt + 16
+                if 2 * kc * bms * 4 <= 160 * 1024 and nt * (kc // 4) * 2 <= 64 and cin > 32:
+                    out.append("1,%d,%d,%d,0" % (mt, nt, kc))
+    return out
 
 
 IGEMM4_INSTANCES = [(4, 2), (5, 1), (5, 2), (7, 1), (7, 2), (8, 1), (10, 1), (13, 1), (16, 1)]

@@ -446,8 +446,10 @@ static int upconv_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w, const fl
   a.isN = x->sn; a.isC = x->sc; a.isZ = x->sd; a.isY = x->sh;
   a.osN = y->sn; a.osC = y->sc; a.osZ = y->sd; a.osY = y->sh;
   a.upz = pz; a.upy = py; a.upx = px;
+  int fused = 0;                 // (the pointwise GEMM applies bias + act in its epilogue)
+  a.up_bias = bias; a.up_act = act; a.up_bias_done = &fused;
   if (int rc = e2i_igemm_conv(ctx, a)) return rc;
-  if (bias) return e2_pool_bias_act_fwd(ctx, y, bias, 1, 1, 1, act, y);
+  if (bias && !fused) return e2_pool_bias_act_fwd(ctx, y, bias, 1, 1, 1, act, y);
   return 0;
 }
 

@@ -82,6 +82,12 @@ struct IgemmArgs {
   // zero, so that the backward can tell relu'(0) = 0.5 from 0 without the pre-activation
   const float* bias = nullptr;
   int act = 0;
+  // UpConv (upz * upy * upx > 1): bias[oc' / R] + activation in the epilogue IF the chosen
+  // kernel can (the pointwise GEMM, conv_pw.hip); *up_bias_done reports it, else the caller
+  // runs its bias / activation pass on the output
+  const float* up_bias = nullptr;
+  int up_act = 0;
+  int* up_bias_done = nullptr;
   // gradient-mask epilogue (data gradient fused with the activation backward of the layer
   // that produced this conv's input): out = conv * act'(gm_src), gm_dbias += column sums.
   // gm_src: that layer's activated output with dense rows (nullptr = linear activation).
@@ -108,7 +114,7 @@ struct IgemmArgs {
   int* nparts = nullptr;
 };
 int e2i_igemm_conv(e2_ctx*, const IgemmArgs& a);
-int e2i_pw_conv(e2_ctx*, const IgemmArgs& a, int MT, int NT);   // 1x1x1 GEMM with LDS-staged weights (conv_pw.hip)
+int e2i_pw_conv(e2_ctx*, const IgemmArgs& a, int MT, int NT, int KC);   // 1x1x1 GEMM with LDS-staged weights (conv_pw.hip)
 
 // Wp[dz][t][ic(ciP)][oc(coP)] = w[(oc/Rout)*wsO + (ic/Rin)*wsI + tap + oc%Rout + ic%Rin],
 // tap = (dz*kh*kw+t), reversed when flip.  Zero in the padding.  Cout/Cin are

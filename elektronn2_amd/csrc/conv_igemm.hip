@@ -257,7 +257,7 @@ extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs
 // kind 0: 16x16x4 kernel, tile 16*MT channels x 64*NT positions ("MT,NT,CC,SK");
 // kind 4: 4x4x1 kernel (igemm4_core.hpp), MT = channel groups of 4 per wave, WM x WN compute
 // waves along the channels / positions, G work-groups per CU ("4,MG,NT,CC,SK,WM,WN,G")
-struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1, WN = 4, G = 1; };
+struct IgemmCfg { int MT, NT, CC, SK, kind = 0, WM = 1, WN = 4, G = 1, KC = 32; };
 
 static const int kMTs[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 13};
 
@@ -313,6 +313,7 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
     const int nf = sscanf(force, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
     if (nf == 4) { f.MT = v[0]; f.NT = v[1]; f.CC = v[2]; f.SK = v[3]; *ok = 1; return f; }
     if (nf == 3 && v[0] == 1) { f.kind = 1; f.MT = v[1]; f.NT = v[2]; *ok = 1; return f; }
+    if (nf == 5 && v[0] == 1) { f.kind = 1; f.MT = v[1]; f.NT = v[2]; f.KC = v[3]; *ok = 1; return f; }
     if (nf == 8 && v[0] == 4) {
       f.kind = 4; f.MT = v[1]; f.NT = v[2]; f.CC = v[3]; f.SK = v[4]; f.WM = v[5]; f.WN = v[6];
       f.G = v[7]; *ok = 1; return f;
@@ -483,16 +484,17 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   int ok = 0;
   IgemmCfg c = choose_cfg(ctx, a, &ok);
   E2_REQUIRE(ok >= 0, "igemm: the forced tiling '%s' is not one this launch can run (packed conv "
-             "launches take \"MT,NT,CC,SK\", \"4,MG,NT,CC,SK,WM,WN,G\" or \"1,MT,NT\")",
+             "launches take \"MT,NT,CC,SK\", \"4,MG,NT,CC,SK,WM,WN,G\", \"1,MT,NT\" or \"1,MT,NT,KC,0\")",
              ctx->tiling[E2_TILING_IGEMM]);
   E2_REQUIRE(ok, "igemm: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d W=%d)", a.Cin,
              a.Cout, a.kd, a.kh, a.kw, a.Wo);
   if (a.gm_done) *a.gm_done = 0;
+  if (a.up_bias_done) *a.up_bias_done = 0;
   if (a.nparts) *a.nparts = 1;
   if (c.kind == 4) return igemm4_conv(ctx, a, c);
   if (c.kind == 1) {                                             // "1,MT,NT": conv_pw.hip
     E2_REQUIRE(!ctx->mfma_bf16, "pointwise conv: an f32 kernel, not offered in bf16 mode");
-    return e2i_pw_conv(ctx, a, c.MT, c.NT);
+    return e2i_pw_conv(ctx, a, c.MT, c.NT, c.KC);
   }
   const bool fast = has_fast_kw(a.kw);
   // the gradient-mask epilogue lives in the specialised-width 16x16x4 kernel

@@ -17,7 +17,16 @@
 //   channels of an M tile; grid = N * Do * ceil(Q / (64 NT)) * ceil(Cout / (16 MT)).
 // MFMA maps (16x16x4 f32): A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
 // D: col = l & 15 (position), row = 4 * (l >> 4) + reg (channel).
-// Tiling "1,MT,NT" through e2_set_tiling(E2_TILING_IGEMM, ...); never chosen untuned.
+// Tiling "1,MT,NT" (chunks of 32 k-rows) or "1,MT,NT,KC,0" (KC = 32 / 64 / 128 k-rows per
+// chunk) through e2_set_tiling(E2_TILING_IGEMM, ...); never chosen untuned.  A chunk is the
+// unit of the software pipeline -- the next chunk's weights (DMA) and activations (registers)
+// are in flight while this one's MFMAs run -- so its MFMA time has to cover the memory
+// latency: with 4 x 1 blocks a 32-row chunk is 0.4 us of MFMAs, and the small GEMMs that
+// cannot fill the chip with work-groups (UpConv, K = 1-2 k) stalled at every chunk.
+// UpConv (round 3): the same GEMM with M = Cout * R rows and the depth-to-space scatter in the
+// epilogue -- row m = co * R + r goes to out[co][pz z + rz][py y + ry][px x + rx] -- and the
+// bias of channel m / R (+ activation) fused, which the implicit-GEMM forms leave to one more
+// launch.
 #include "common.hpp"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -26,21 +35,21 @@ typedef const __attribute__((address_space(1))) void* gbl_vp;
 
 namespace {
 
-constexpr int kKC = 32;                 // k-rows (input channels) per staged chunk
-constexpr int kSteps = kKC / 4;
 
 struct PwP {
   const float* in; const float* wp; float* out;
   const float* bias; int act;
   int N, Cin, Cout, Do, Wo, Q;
   long isN, isC, isZ, isY, osN, osC, osZ, osY;
-  int coP, nPT, nMT, nChunks;
+  int coP, ciP, nPT, nMT, nChunks;
+  int upz, upy, upx, R;                  // UpConv scatter (R = upz * upy * upx; 1 = plain conv)
 };
 
 constexpr int bms_of(int MT) { return ((16 * MT) & 31) == 16 ? 16 * MT : 16 * MT + 16; }
 
-template <int MT, int NT>
+template <int MT, int NT, int KC>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
+  constexpr int kKC = KC, kSteps = KC / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int BMS = bms_of(MT);               // LDS row stride (floats), 16 mod 32: the four
                                                 // k-rows of a fragment read sit 16 banks apart
@@ -67,16 +76,18 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
     const int qc = min(q, p.Q - 1);
     const int y = qc / p.Wo, x = qc - y * p.Wo;
     xoff[nb] = (long)n * p.isN + (long)z * p.isZ + (long)y * p.isY + x;
-    ooff[nb] = (long)n * p.osN + (long)z * p.osZ + (long)y * p.osY + x;
+    ooff[nb] = (long)n * p.osN + (long)(z * p.upz) * p.osZ + (long)(y * p.upy) * p.osY + x * p.upx;
   }
   // weight pieces this thread stages: piece pi = it * 256 + tid covers floats 4 pi .. 4 pi + 3
   // of the chunk [k][BMS]; the pad columns of a row (BMS > 16 MT) re-read its last piece
   long woff[NI];
+  int wrow[NI];                                  // the piece's k-row inside its chunk
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int pi = min(it * 256 + tid, PIECES - 1);
     const int k = (pi * 4) / BMS, m = min(pi * 4 - k * BMS, 16 * MT - 4);
     woff[it] = (long)k * p.coP + m0 + m;
+    wrow[it] = k;
   }
   const unsigned abase = (unsigned)(uintptr_t)(lds_vp)(lds + (kq * BMS + l15) * 4);
 
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
     const float* wc = p.wp + (long)c * kKC * p.coP;
     unsigned char* lb = lds + buf * BUFB + (wave * 64) * 16;
 #pragma unroll
-    for (int it = 0; it < NI; ++it)
-      if (it * 256 + tid < PIECES)
+    for (int it = 0; it < NI; ++it)       // (rows past the packed image: never read -- steps_of)
+      if (it * 256 + tid < PIECES && c * kKC + wrow[it] < p.ciP)
         __builtin_amdgcn_global_load_lds((gbl_vp)(wc + woff[it]), (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
   };
   // activations of chunk c: B[k = 4 s + kq][position]; channels past the last one re-read it
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
   float* bl = reinterpret_cast<float*>(lds);
   if (p.bias) {
     __builtin_amdgcn_s_barrier();               // every wave is done with the weight buffers
-    if (tid < 16 * MT) bl[tid] = p.bias[min(m0 + tid, p.Cout - 1)];
+    if (tid < 16 * MT) bl[tid] = p.bias[min(m0 + tid, p.Cout - 1) / p.R];
     __syncthreads();
   }
 #pragma unroll
@@ -191,6 +202,13 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
     for (int r = 0; r < 4; ++r) {
       const int co = m0 + 16 * mb + 4 * kq + r;
       if (co >= p.Cout) continue;
+      long roff = (long)co * p.osC;
+      if (p.R > 1) {                              // UpConv: row = (channel, sub-position)
+        const int cc = co / p.R, rr = co - cc * p.R;
+        const int rz = rr / (p.upy * p.upx), r2 = rr - rz * (p.upy * p.upx);
+        const int ry = r2 / p.upx, rx = r2 - ry * p.upx;
+        roff = (long)cc * p.osC + (long)rz * p.osZ + (long)ry * p.osY + rx;
+      }
 #pragma unroll
       for (int nb = 0; nb < NT; ++nb) {
         if (!qok[nb]) continue;
@@ -201,48 +219,69 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(PwP p) {
           // the backward pass tells relu'(0) = 0.5 from 0 by it (igemm_core.hpp, wide epilogue)
           if (p.act == E2_ACT_RELU) t = (t > 0.f) ? t : ((t == 0.f) ? 0.f : -0.f);
         }
-        p.out[(long)co * p.osC + ooff[nb]] = t;
+        p.out[roff + ooff[nb]] = t;
       }
     }
   }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int KC>
 int launch(e2_ctx* ctx, const PwP& p, long grid) {
-  const size_t ldsb = 2 * (size_t)kKC * bms_of(MT) * 4;
-  static bool attr_done = false;
-  if (!attr_done && ldsb > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<MT, NT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
-    attr_done = true;
+  constexpr size_t ldsb = 2 * (size_t)KC * bms_of(MT) * 4;
+  if constexpr (ldsb > 160 * 1024 || NT * (KC / 4) * 2 > 64) {      // (two register sets of a chunk's activations: beyond 64 they spill)
+    e2_set_error("pointwise conv: %d x %d blocks with %d-row chunks do not fit (LDS %zu B)", MT, NT, KC, ldsb);
+    return 2;
+  } else {
+    static bool attr_done = false;
+    if (!attr_done && ldsb > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<MT, NT, KC>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+      if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((pw_gemm_kernel<MT, NT, KC>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
+    E2_CHECK_HIP(hipGetLastError());
+    return 0;
   }
-  hipLaunchKernelGGL((pw_gemm_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
-  E2_CHECK_HIP(hipGetLastError());
-  return 0;
+}
+
+template <int MT, int NT>
+int launch_kc(e2_ctx* ctx, const PwP& p, long grid, int KC) {
+  if (KC == 32) return launch<MT, NT, 32>(ctx, p, grid);
+  if (KC == 64) return launch<MT, NT, 64>(ctx, p, grid);
+  if (KC == 128) return launch<MT, NT, 128>(ctx, p, grid);
+  e2_set_error("pointwise conv: chunks of %d k-rows (32, 64 or 128)", KC);
+  return 2;
 }
 
 }  // namespace
 
-int e2i_pw_conv(e2_ctx* ctx, const IgemmArgs& a, int MT, int NT) {
+int e2i_pw_conv(e2_ctx* ctx, const IgemmArgs& a, int MT, int NT, int KC) {
   E2_REQUIRE(a.kd == 1 && a.kh == 1 && a.kw == 1, "pointwise conv: kernel %dx%dx%d is not 1x1x1", a.kd, a.kh, a.kw);
-  E2_REQUIRE(a.upz * a.upy * a.upx == 1, "pointwise conv: no UpConv scatter epilogue");
   E2_REQUIRE(NT == 1 || NT == 2, "pointwise conv: NT must be 1 or 2");
+  E2_REQUIRE(a.parts_max <= 1, "pointwise conv: no partial-sum form");
   PwP p;
   p.in = a.in; p.wp = a.wp; p.out = a.out; p.bias = a.bias; p.act = a.act;
+  p.upz = a.upz; p.upy = a.upy; p.upx = a.upx; p.R = a.upz * a.upy * a.upx;
+  E2_REQUIRE(p.R >= 1 && a.Cout % p.R == 0, "pointwise conv: %d rows for %d sub-positions", a.Cout, p.R);
+  if (p.R > 1 && a.up_bias) {              // UpConv: bias[m / R] (+ act) in the epilogue
+    p.bias = a.up_bias; p.act = a.up_act;
+    if (a.up_bias_done) *a.up_bias_done = 1;
+  }
+  p.ciP = a.ciP;
   p.N = a.N; p.Cin = a.Cin; p.Cout = a.Cout; p.Do = a.Do; p.Wo = a.Wo; p.Q = a.Ho * a.Wo;
   p.isN = a.isN; p.isC = a.isC; p.isZ = a.isZ; p.isY = a.isY;
   p.osN = a.osN; p.osC = a.osC; p.osZ = a.osZ; p.osY = a.osY;
   p.coP = a.coP;
   p.nPT = e2_cdiv(p.Q, 64 * NT);
   p.nMT = e2_cdiv(e2_cdiv(a.Cout, 16), MT);
-  p.nChunks = e2_cdiv(a.Cin, kKC);
+  p.nChunks = e2_cdiv(a.Cin, KC);
   E2_REQUIRE(p.nMT * 16 * MT <= a.coP, "pointwise conv: packed coP too small");
-  E2_REQUIRE(p.nChunks * kKC <= a.ciP, "pointwise conv: packed ciP too small");
+  E2_REQUIRE(a.Cin <= a.ciP, "pointwise conv: packed ciP too small");
   const long grid = (long)a.N * p.Do * p.nPT * p.nMT;
   E2_REQUIRE(grid < (1L << 31), "pointwise conv: grid too large");
   ctx->last_fill_ptr = nullptr; ctx->last_fill_n = 0;
-#define E2_L(M, N_) if (MT == M && NT == N_) return launch<M, N_>(ctx, p, grid);
+#define E2_L(M, N_) if (MT == M && NT == N_) return launch_kc<M, N_>(ctx, p, grid, KC);
   E2_L(4, 1) E2_L(4, 2) E2_L(5, 1) E2_L(5, 2) E2_L(6, 1) E2_L(6, 2) E2_L(7, 1) E2_L(7, 2)
   E2_L(8, 1) E2_L(8, 2) E2_L(10, 1) E2_L(10, 2) E2_L(13, 1) E2_L(13, 2) E2_L(16, 1)
 #undef E2_L

@@ -73,7 +73,11 @@ int  e2_get_mfma_dtype(const e2_ctx* ctx);
  * CC input channels per LDS chunk, SK-way split of K), or cfg = "4,MG,NT,CC,SK,WM,WN,G"
  * (4x4x1 MFMA kernel, persistent: 4*MG channels x 64*NT positions per WAVE, WM x WN <= 12
  * compute waves per work-group along the channels / positions, G work-groups per CU
- * walking the tiles); kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
+ * walking the tiles), or, for 1x1x1 kernels and UpConv, cfg = "1,MT,NT" / "1,MT,NT,KC,0" (the
+ * GEMM with LDS-staged weights of conv_pw.hip: 16*MT channels x 64*NT positions per
+ * work-group, KC = 32 / 64 / 128 reduction channels per pipeline chunk, 32 in the short form;
+ * for UpConv its epilogue scatters depth-to-space and applies bias + activation);
+ * kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
  * e2_conv3d_wgrad / e2_conv3d_wgrad_pad (WK 1 / 14 direct kernel, 0 / 4 LDS-staged;
  * BP positions per tile, PS position splits).  The setting holds for every following
  * launch of that kind on this context until changed; cfg NULL or "" returns the choice

@@ -229,7 +229,9 @@ def test_tiling_candidate_lists():
     from elektronn2_amd import autotune
     # 1x1x1 GEMM with LDS-staged weights: "1,MT,NT", only for 1x1x1 kernels with enough channels
     pw = autotune.pointwise_candidates(200, (1, 1, 1))
-    assert pw and all(re.fullmatch(r"1,(4|5|6|7|8|10|13|16),(1|2)", c) for c in pw)
+    assert pw and all(re.fullmatch(r"1,(4|5|6|7|8|10|13|16),(1|2)(,(64|128),0)?", c) for c in pw)
+    assert "1,13,1,64,0" in pw and not any(c.startswith("1,13,2,128") for c in pw)
+    assert all("," not in c[6:] for c in autotune.pointwise_candidates(200, (1, 1, 1), cin=20))
     assert "1,13,1" in pw and "1,7,2" in pw
     assert autotune.pointwise_candidates(200, (1, 3, 3)) == []
     assert autotune.pointwise_candidates(2, (1, 1, 1)) == []

@@ -341,13 +341,16 @@ def test_conv3d_4x4_mfma_tap_widths_dgrad_and_fused_act(ctx, kw, force):
 
 
 @pytest.mark.parametrize("force", ["1,4,1", "1,4,2", "1,5,1", "1,5,2", "1,6,1", "1,6,2", "1,7,1", "1,7,2",
-                                   "1,8,1", "1,8,2", "1,10,1", "1,10,2", "1,13,1", "1,13,2", "1,16,1"])
+                                   "1,8,1", "1,8,2", "1,10,1", "1,10,2", "1,13,1", "1,13,2", "1,16,1",
+                                   "1,4,1,64,0", "1,4,2,64,0", "1,7,1,128,0", "1,8,1,128,0", "1,13,2,64,0",
+                                   "1,16,1,64,0", "1,5,1,128,0", "1,10,2,64,0"])
 @pytest.mark.parametrize("Ci,Co,sp", [(70, 100, (4, 12, 21)), (200, 200, (2, 9, 37)), (33, 250, (1, 5, 70))])
 def test_conv3d_pointwise_gemm(ctx, force, Ci, Co, sp):
-    """csrc/conv_pw.hip ("1,MT,NT"): the 1x1x1 conv as a GEMM with LDS-staged weights --
-    forward (batch of 2, input a strided interior view), the fused bias + relu epilogue with
-    its signed zeros, the data gradient; channel counts that are not multiples of the 32-row
-    chunks / 16-row blocks, position counts that are not multiples of the tile"""
+    """csrc/conv_pw.hip ("1,MT,NT" / "1,MT,NT,KC,0"): the 1x1x1 conv as a GEMM with LDS-staged
+    weights -- forward (batch of 2, input a strided interior view), the fused bias + relu
+    epilogue with its signed zeros, the data gradient; channel counts that are not multiples
+    of the 32 / 64 / 128-row chunks (a last chunk that runs past the packed image) or the
+    16-row blocks, position counts that are not multiples of the tile"""
     rng = np.random.RandomState(Ci + Co)
     k = (1, 1, 1)
     N = 2
@@ -622,6 +625,19 @@ UPCONV_CASES = [(1, 8, 6, (2, 2, 2), (3, 4, 5), 'relu'), (1, 32, 16, (1, 2, 2), 
 def test_upconv3d_4x4_mfma_scatter_epilogue(ctx, force):
     """UpConv forward through the 4x4x1 kernel: 1x1x1 GEMM to Cout * prod(pool) rows with the
     depth-to-space scatter in the epilogue (the backward's data gradient takes the same kernel)"""
+    for case in UPCONV_CASES:
+        ctx.set_tiling("igemm", force)
+        try:
+            test_upconv3d(ctx, case)
+        finally:
+            ctx.set_tiling("igemm", None)
+
+
+@pytest.mark.parametrize("force", ["1,4,1", "1,4,2", "1,8,1,64,0", "1,7,2,64,0", "1,5,1,128,0", "1,6,2"])
+def test_upconv3d_pointwise_gemm_scatter_epilogue(ctx, force):
+    """UpConv forward through csrc/conv_pw.hip: M = Cout * prod(pool) rows, the depth-to-space
+    scatter and bias[row / R] + activation in the GEMM's epilogue (no separate bias launch);
+    the backward's data gradient takes the same kernel in its plain form"""
     for case in UPCONV_CASES:
         ctx.set_tiling("igemm", force)
         try:
