@@ -245,7 +245,7 @@ def test_tiling_candidate_lists():
     assert max(int(x.split(",")[2]) for x in autotune.bf16_wgrad_candidates(64, (2, 4, 4))) == 4
     # every shipped choice is a well-formed string of one of the known forms
     shipped = json.load(open(os.path.join(os.path.dirname(autotune.__file__), "tuned.json")))
-    forms = {"igemm": r"\d+,\d+,\d+,\d+|4(,\d+){7}|1,\d+,[12]|32,\d+,\d+",
+    forms = {"igemm": r"\d+,\d+,\d+,\d+|4(,\d+){7}|1,\d+,[12](,(32|64|128),0)?|32,\d+,\d+",
              "wgrad": r"\d+,\d+,\d+,\d+,\d+"}
     for key, val in shipped.items():
         kind = key.split("|")[0].replace("_bf16", "")
