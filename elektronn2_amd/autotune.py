@@ -251,7 +251,31 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
                             # the same launch in the XCD-grouped block order (balanced for any
                             # group count: csrc/conv_wgrad_direct.hip)
                             cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q))
-    return sorted(set(cands))
+    return sorted(set(cands) | set(pointwise_wgrad_candidates(cout, cin, k, out_sp, n_cu)))
+
+
+PW_WGRAD_TILES = [(2, 2), (4, 2), (2, 4), (4, 4), (4, 3), (3, 4), (7, 2), (2, 7), (7, 4), (4, 7)]
+
+
+def pointwise_wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
+    """"MT,NT,7,0,S": the 1x1x1 (and UpConv) weight gradient as a GEMM with K-contiguous
+    operands (csrc/conv_pw_wgrad.hip): 2 x 2 waves of MT x NT blocks of 16 x 16 per
+    work-group, S splits of the positions"""
+    if tuple(k) != (1, 1, 1) or cout < 32 or cin < 32:
+        return []
+    steps = -(-(out_sp[0] * out_sp[1] * out_sp[2]) // 16)
+    scored = []
+    for mt, nt in PW_WGRAD_TILES:
+        nm, nn = -(-cout // (32 * mt)), -(-cin // (32 * nt))
+        eff = (cout * cin) / float(nm * 32 * mt * nn * 32 * nt)
+        scored.append((-eff, mt * nt, mt, nt, nm * nn))
+    scored.sort()
+    out = []
+    for _, _, mt, nt, tiles in scored[:5]:
+        for fill in (0.5, 1, 2, 4):
+            s = max(1, min(steps, int(n_cu * fill) // tiles))
+            out.append("%d,%d,7,0,%d" % (mt, nt, s))
+    return sorted(set(out))
 
 
 _forced = {}

@@ -1,0 +1,189 @@
+// conv_pw_wgrad.hip -- the weight gradient of a 1x1x1 conv (and of UpConv, whose GEMMs are
+// 1x1x1: api.hip upconv_bwd) as a plain GEMM of its own:
+//
+//   dw[m][n] (+)= sum over samples and positions k of  dy[m][k] * x[n][k]
+//
+// (T.grad's ConvGradW for the reference's "tensordot" branch, computations.py:330-335,
+// 377-384; model.py:182-186.)  Both operands are K-CONTIGUOUS -- a channel's positions lie
+// next to each other in memory -- which is the one shape the direct weight-gradient kernel
+// (conv_wgrad_direct.hip) is not built for: it stages input SPANS per (channel, tap) in LDS and
+// gathers from them, machinery a single tap does not need, and with NT = 1 it re-reads every
+// dy row once per 16 input channels (DESIGN.md known loss 5: 31 us for 7 us of MFMA on
+// neuro3d_lite's 200 -> 200 layer, 56-61 us for the U-Nets' 1.4-2.4 GF UpConv gradients).
+//
+// Here: 16x16x4 f32 MFMA with operands straight from memory.  For 16 consecutive positions
+// lane (i = l & 15, q = l >> 4) loads ONE float4 -- positions 4q .. 4q+3 of channel row i --
+// per 16-row block; the four MFMAs of the step take component j as their k index, i.e. k-step
+// j covers positions {4q + j}: A and B use the same permutation of the 16 positions, so the
+// sum is unchanged and no lane ever shuffles.  A wave owns MT x NT blocks, a work-group 2 x 2
+// waves (a tile of 32 MT x 32 NT outputs; the two waves of a row share their dy rows through
+// L1), S work-groups split the positions of a tile and add their partial tiles to dw with
+// f32 atomics (dw zeroed first unless accumulate).  The operand sets of 2-5 steps are in flight
+// (a ring of 3-6 register sets, deeper for the smaller tiles).
+// Tiling "MT,NT,7,0,S" through e2_set_tiling(E2_TILING_WGRAD, ...); never chosen untuned.
+// Requires dense channel planes (row stride = W, plane stride = H * W) for x and dy.
+#include "common.hpp"
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct PgP {
+  const float* a; const float* b; float* c;        // dy, x, dw
+  long asN, asC, bsN, bsC;
+  int N, M, Ncol, K;                               // K = positions of one sample
+  int R;                                           // UpConv: row m = co * R + r
+  int nMT, nNT, S;
+  int stepsPerSample, steps, per;                  // 16-position steps: per sample, total, per split
+};
+
+// lane's float4 of a 16-position step: positions k0 + 4q .. + 3 of one channel row; past the end
+// of the sample's K the values are zero (the row pointer itself is always valid)
+__device__ __forceinline__ f32x4 pg_load(const float* row, int k, int K) {
+  if (k + 3 < K) {
+    f32x4 v;
+    __builtin_memcpy(&v, row + k, 16);             // (4-byte aligned only: rows need not be 16-byte aligned)
+    return v;
+  }
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (k + j < K) v[j] = row[k + j];
+  return v;
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(PgP p) {
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int b = blockIdx.x;
+  const int nt = b % p.nNT; b /= p.nNT;
+  const int mt = b % p.nMT;
+  const int sp = b / p.nMT;
+  const int m0 = (mt * 2 + wm) * 16 * MT;
+  const int n0 = (nt * 2 + wn) * 16 * NT;
+  const int s0 = sp * p.per, s1 = min(s0 + p.per, p.steps);
+
+  // row offsets (clamped: rows past the end are computed and never flushed)
+  long aoff[MT], boff[NT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) aoff[mb] = (long)min(m0 + 16 * mb + l15, p.M - 1) * p.asC;
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) boff[nb] = (long)min(n0 + 16 * nb + l15, p.Ncol - 1) * p.bsC;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto load = [&](int s, f32x4 (&A)[MT], f32x4 (&B)[NT]) {
+    const int sc = min(s, s1 - 1);                   // (a load past the range repeats the last step: unused)
+    const int n = sc / p.stepsPerSample;
+    const int k = (sc - n * p.stepsPerSample) * 16 + 4 * q;
+    const float* ap = p.a + (long)n * p.asN;
+    const float* bp = p.b + (long)n * p.bsN;
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) A[mb] = pg_load(ap + aoff[mb], k, p.K);
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) B[nb] = pg_load(bp + boff[nb], k, p.K);
+  };
+  auto fma = [&](const f32x4 (&A)[MT], const f32x4 (&B)[NT]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mb][j], B[nb][j], acc[mb][nb], 0, 0, 0);
+  };
+
+  // a ring of D operand sets: D - 1 steps are in flight while one is multiplied (a step of a
+  // 2 x 2 tile is 16 MFMAs = 0.2 us, a round trip to L2 / HBM five to ten times that)
+  constexpr int D = (MT + NT) <= 4 ? 6 : ((MT + NT) <= 6 ? 4 : 3);
+  if (s0 < s1) {
+    f32x4 A[D][MT], B[D][NT];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load(s0 + d, A[d], B[d]);
+    int s = s0;
+    for (; s + D <= s1; s += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        load(s + d + D - 1, A[(d + D - 1) % D], B[(d + D - 1) % D]);   // into the set the last fma freed
+        fma(A[d], B[d]);
+      }
+    }
+    // fewer than D steps left: sets 0 .. D-2 hold steps s .. s + D - 2
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+      if (s + d < s1) fma(A[d], B[d]);
+  }
+
+  // ---- flush: D row = 4 q + r, col = l15 -----------------------------------------------------
+  const bool single = p.S == 1;
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * mb + 4 * q + r;
+      if (m >= p.M) continue;
+      long rbase;
+      int cstride;
+      if (p.R > 1) { const int co = m / p.R; rbase = (long)co * p.Ncol * p.R + (m - co * p.R); cstride = p.R; }
+      else { rbase = (long)m * p.Ncol; cstride = 1; }
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) {
+        const int n = n0 + 16 * nb + l15;
+        if (n >= p.Ncol) continue;
+        float* dst = p.c + rbase + (long)n * cstride;
+        if (single) *dst += acc[mb][nb][r];          // (dw was zeroed or holds what to add to)
+        else unsafeAtomicAdd(dst, acc[mb][nb][r]);
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+int launch(e2_ctx* ctx, const PgP& p, long grid) {
+  hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int e2i_pw_wgrad(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
+  E2_REQUIRE(a.kd == 1 && a.kh == 1 && a.kw == 1, "pointwise wgrad: kernel %dx%dx%d is not 1x1x1", a.kd, a.kh, a.kw);
+  E2_REQUIRE(a.xsY == a.Wo && a.xsZ == (int64_t)a.Ho * a.Wo && a.dsY == a.Wo && a.dsZ == (int64_t)a.Ho * a.Wo,
+             "pointwise wgrad: x and dy need dense channel planes (row stride = W, plane stride = H * W)");
+  E2_REQUIRE(!ctx->mfma_bf16, "pointwise wgrad: an f32 kernel, not offered in bf16 mode");
+  PgP p;
+  p.a = a.dy; p.b = a.x; p.c = a.dw;
+  p.asN = a.dsN; p.asC = a.dsC; p.bsN = a.xsN; p.bsC = a.xsC;
+  p.N = a.N; p.M = a.Cout; p.Ncol = a.Cin;
+  const long K = (long)a.Do * a.Ho * a.Wo;
+  E2_REQUIRE(K < (1L << 30), "pointwise wgrad: sample too large");
+  p.K = (int)K;
+  p.R = a.upR > 1 ? a.upR : 1;
+  E2_REQUIRE(a.Cout % p.R == 0, "pointwise wgrad: %d rows for %d sub-positions", a.Cout, p.R);
+  p.nMT = e2_cdiv(a.Cout, 32 * MT);
+  p.nNT = e2_cdiv(a.Cin, 32 * NT);
+  p.stepsPerSample = (int)((K + 15) / 16);
+  const long steps = (long)a.N * p.stepsPerSample;
+  E2_REQUIRE(steps < (1L << 30), "pointwise wgrad: too many positions");
+  p.steps = (int)steps;
+  S = (int)std::max<long>(1, std::min<long>(S, steps));
+  p.per = (int)((steps + S - 1) / S);
+  p.S = (int)((steps + p.per - 1) / p.per);
+  const long grid = (long)p.nMT * p.nNT * p.S;
+  E2_REQUIRE(grid < (1L << 31), "pointwise wgrad: grid too large");
+  if (!a.accumulate)
+    if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * a.Cin, 0.f)) return rc;
+#define E2_L(M, N_) if (MT == M && NT == N_) return launch<M, N_>(ctx, p, grid);
+  E2_L(2, 2) E2_L(4, 2) E2_L(2, 4) E2_L(4, 4) E2_L(4, 3) E2_L(3, 4) E2_L(7, 2) E2_L(2, 7) E2_L(7, 4) E2_L(4, 7)
+#undef E2_L
+  e2_set_error("pointwise wgrad: no instance MT=%d NT=%d", MT, NT);
+  return 2;
+}

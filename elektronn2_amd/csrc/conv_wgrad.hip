@@ -550,6 +550,8 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   // kernel; 14 = direct kernel, waves split the quads of a tile (NT 2/4);
   // 0 = LDS-staged kernel forced; 4 = LDS-staged kernel, waves split K
   // WK 101 / 114: the direct kernel with the XCD-grouped block order (nMT * PS % 8 == 0)
+  // WK 7 ("MT,NT,7,0,S"): 1x1x1 kernels -- the GEMM with K-contiguous operands (conv_pw_wgrad.hip)
+  if (c.WK == 7) return e2i_pw_wgrad(ctx, a, c.MT, c.NT, c.PS);
   if (a.dy_padded && (c.WK == 1 || c.WK == 14 || c.WK == 101 || c.WK == 114) && (c.BP == 128 || c.BP == 256))
     return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS, (c.WK % 100) == 14 ? 4 : 1, c.WK >= 100);
   E2_REQUIRE(c.WK != 14 && c.WK < 100, "wgrad: WK=14/101/114 need the padded-gradient entry point and BP 128/256");

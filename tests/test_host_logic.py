@@ -236,6 +236,16 @@ def test_tiling_candidate_lists():
     assert autotune.pointwise_candidates(200, (1, 3, 3)) == []
     assert autotune.pointwise_candidates(2, (1, 1, 1)) == []
     assert set(pw) <= set(autotune.igemm_candidates(200, 200, (1, 1, 1), (10, 37, 37)))
+    # 1x1x1 / UpConv weight gradient as a GEMM with K-contiguous operands: "MT,NT,7,0,S"; the
+    # tile list is the kernel's instance list (csrc/conv_pw_wgrad.hip)
+    src = open(os.path.join(os.path.dirname(autotune.__file__), "csrc", "conv_pw_wgrad.hip")).read()
+    inst = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", src))
+    assert inst == set(autotune.PW_WGRAD_TILES)
+    pg = autotune.pointwise_wgrad_candidates(2048, 256, (1, 1, 1), (18, 10, 10))
+    assert pg and all(re.fullmatch(r"\d+,\d+,7,0,\d+", c) for c in pg)
+    assert all((int(c.split(",")[0]), int(c.split(",")[1])) in inst for c in pg)
+    assert autotune.pointwise_wgrad_candidates(200, 200, (1, 3, 3), (10, 37, 37)) == []
+    assert set(pg) <= set(autotune.wgrad_candidates(2048, 256, (1, 1, 1), (18, 10, 10)))
     # bf16 weight gradient: "32,MB,NB,R,S"; the row form (R = 1) for few input channels only,
     # the column form (R = 0) when at least 48
     for cin, forms in ((20, {"1"}), (40, {"1"}), (100, {"0", "1"}), (200, {"0"}), (8, set())):

@@ -530,6 +530,57 @@ def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
         ctx.set_tiling("wgrad", None)
 
 
+@pytest.mark.parametrize("force", ["2,2,7,0,1", "2,2,7,0,5", "4,2,7,0,3", "2,4,7,0,64", "4,4,7,0,2", "4,3,7,0,7",
+                                   "3,4,7,0,1", "7,2,7,0,4", "2,7,7,0,9", "7,4,7,0,3", "4,7,7,0,100000"])
+@pytest.mark.parametrize("Ci,Co,N,sp", [(70, 100, 2, (3, 7, 13)), (200, 200, 1, (2, 9, 37)), (33, 250, 1, (1, 5, 70)),
+                                        (40, 37, 3, (1, 1, 5))])
+def test_conv3d_pointwise_wgrad_gemm(ctx, force, Ci, Co, N, sp):
+    """csrc/conv_pw_wgrad.hip ("MT,NT,7,0,S"): the 1x1x1 weight gradient as a GEMM whose two
+    operands are K-contiguous (positions): channel counts that are not multiples of the
+    tiles, position counts that are not multiples of 16 (a masked last step per sample) or
+    4, batches, one split (plain stores) to more splits than steps, overwrite and accumulate;
+    channel rows that are NOT 16-byte aligned (odd plane sizes)."""
+    rng = np.random.RandomState(Ci + Co)
+    k = (1, 1, 1)
+    x = rng.rand(N, Ci, *sp).astype(np.float32)
+    dy = rng.randn(N, Co, *sp).astype(np.float32)
+    ref = O.conv3d_wgrad(dy, x, (Co, Ci) + k)
+    flat = torch.zeros(dy.size + 32, device="cuda")        # (the padded form of a 1x1x1 gradient
+    dyp = flat[:dy.size].view(dy.shape)                   # is the gradient itself + its slack)
+    dyp.copy_(dev(dy))
+    dw = torch.full((Co, Ci) + k, float("nan"), device="cuda")
+    ctx.set_tiling("wgrad", force)
+    try:
+        ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
+        assert relerr(dw, ref) < TOL
+        ctx.conv3d_wgrad_pad(dev(x), dyp, dw, accumulate=True)
+        assert relerr(dw, 2 * ref) < TOL
+        # x as a channel slice of a wider buffer (a concat input): planes stay dense
+        wide = torch.full((N, Ci + 5) + tuple(sp), float("nan"), device="cuda")
+        wide[:, 3:3 + Ci] = dev(x)
+        ctx.conv3d_wgrad_pad(wide[:, 3:3 + Ci], dyp, dw)
+        assert relerr(dw, ref) < TOL
+        # rows that are not dense are refused, never mis-read
+        crop = torch.zeros((N, Ci, sp[0], sp[1], sp[2] + 2), device="cuda")
+        from elektronn2_amd.backend import E2Error
+        with pytest.raises(E2Error, match="dense channel planes"):
+            ctx.conv3d_wgrad_pad(crop[..., 1:-1], dyp, dw)
+    finally:
+        ctx.set_tiling("wgrad", None)
+
+
+@pytest.mark.parametrize("force", ["2,2,7,0,3", "4,4,7,0,1", "7,2,7,0,6"])
+def test_upconv3d_pointwise_wgrad_gemm(ctx, force):
+    """UpConv's weight gradient through the same GEMM: rows m = co * R + r land in
+    dw[co][ci][r]"""
+    for case in UPCONV_CASES:
+        ctx.set_tiling("wgrad", force)
+        try:
+            test_upconv3d(ctx, case)
+        finally:
+            ctx.set_tiling("wgrad", None)
+
+
 @pytest.mark.parametrize("force", ["1,1,1,64,3", "2,2,1,128,5", "3,4,1,64,2", "4,1,4,128,7",
                                    "5,2,1,64,1", "7,2,1,128,3", "1,1,4,64,2", "7,1,1,64,4"])
 def test_conv3d_wgrad_forced_tilings(ctx, force):
