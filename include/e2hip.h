@@ -78,7 +78,9 @@ int  e2_get_mfma_dtype(const e2_ctx* ctx);
  * work-group, KC = 32 / 64 / 128 reduction channels per pipeline chunk, 32 in the short form;
  * for UpConv its epilogue scatters depth-to-space and applies bias + activation);
  * kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
- * e2_conv3d_wgrad / e2_conv3d_wgrad_pad (WK 1 / 14 direct kernel, 0 / 4 LDS-staged;
+ * e2_conv3d_wgrad / e2_conv3d_wgrad_pad (WK 1 / 14 direct kernel, 0 / 4 LDS-staged, 7 =
+ * "MT,NT,7,0,S": 1x1x1 kernels and UpConv, the GEMM with K-contiguous operands of
+ * conv_pw_wgrad.hip, 2 x 2 waves of MT x NT blocks, S position splits;
  * BP positions per tile, PS position splits).  The setting holds for every following
  * launch of that kind on this context until changed; cfg NULL or "" returns the choice
  * to the library's cost model.  A tiling the problem cannot use (LDS, instance list)
