@@ -310,15 +310,20 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def launch_ranks(n, argv, extra_env=None, timeout=None):
+def launch_ranks(n, argv, extra_env=None, timeout=3000):
     """`python bench.py --gpus N` without a launcher around it: start N fresh processes of
     this script (one per GPU: RANK = LOCAL_RANK = 0..N-1, WORLD_SIZE = N, rendezvous on
     127.0.0.1) and hand back (exit code, rank 0's stdout).  The parent never touches the
     GPU -- a process that has initialised HIP must not be replaced or forked -- and never
     retries: if any rank fails, the others are terminated and the code is non-zero."""
     import subprocess
+    import tempfile
     port = _free_port()
     procs = []
+    # rank 0's stdout goes to a FILE, read at the end: a pipe that nobody drains blocks rank 0
+    # in write() once a library has printed ~64 KiB of banners there (NCCL_DEBUG), the other
+    # ranks then hang in the collective and this loop would poll forever (ADVICE r3)
+    out_file = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n),
@@ -326,7 +331,7 @@ def launch_ranks(n, argv, extra_env=None, timeout=None):
                     "MASTER_PORT": str(port)})
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
-                                      env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      env=env, stdout=out_file if r == 0 else subprocess.DEVNULL,
                                       text=True))
     out0, rc = "", 0
     t_end = None if timeout is None else time.time() + timeout
@@ -344,11 +349,12 @@ def launch_ranks(n, argv, extra_env=None, timeout=None):
                 rc = rc or 124
                 break
             if pending:
-                # rank 0 prints one line at its very end: reading it here cannot block the others
                 time.sleep(0.05)
         if rc == 0:
-            out0 = procs[0].stdout.read()
+            out_file.seek(0)
+            out0 = out_file.read()
     finally:
+        out_file.close()
         for pr in procs:
             if pr.poll() is None:
                 pr.terminate()
@@ -375,10 +381,94 @@ def selftest_bench(args, rank, world):
         dist.all_gather_object(ranks, me)
     if os.environ.get("E2_SELFTEST_FAIL_RANK") == str(rank):
         sys.exit(3)
+    if rank == 0 and os.environ.get("E2_SELFTEST_NOISE"):
+        # a library that fills rank 0's stdout (NCCL_DEBUG banners) must not block the launch
+        sys.stdout.write("x" * int(os.environ["E2_SELFTEST_NOISE"]) + "\n")
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "selftest", "value": float(v.item()), "unit": "rank",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "config": {"workload": "selftest (no GPU)", "ranks": ranks}}))
+
+
+def time_training(workload, args, rank, world, dev, steps, warmup):
+    """Build the workload's net, capture its training step and time `steps` steps of it after
+    `warmup` untimed ones (barrier + synchronize on both sides; HIP events on the plan's
+    stream for the device time).  Inputs wait in HBM before the timed region starts."""
+    from elektronn2_amd import parallel, nets
+    from elektronn2_amd import neuromancer as nm
+    builder, sp, gf_table = WORKLOADS[workload]
+    nm.model_manager.reset()
+    np.random.seed(1)                         # identical initial weights on every rank
+    model = getattr(nets, builder)((None, 1) + sp)
+    osp = tuple(model.prediction_node.shape.spatial_shape)
+    if builder in ("unet3d_lite", "unet3d"):
+        gflop = gf_table                      # UpConv / merge net: SURVEY.md §8d's figure
+    else:
+        gflop = algorithmic_gflop(model)
+    params0 = conv_params(model)              # initial weights, for the CPU baseline leg
+    model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    opt = model.optimisers['Adam']
+    opt.step.compile()
+    plan = opt.step.func
+    plan.use_graph = not args.no_graph
+    rng = np.random.RandomState(parallel.rank_seed(0, rank))
+    n_batches = 4
+    xs = [torch.tensor(rng.rand(1, 1, *sp).astype(np.float32), device=dev)
+          for _ in range(n_batches)]
+    ts = [torch.tensor(rng.randint(0, 2, (1, 1) + osp).astype(np.float32), device=dev)
+          for _ in range(n_batches)]
+    plan.set_inputs([xs[0], ts[0]])          # builds plan + arena
+    if world > 1:
+        model.enable_data_parallel()
+    elif args.exchange_at_1:
+        model.enable_data_parallel(exchange_at_world_1=True)
+    # the batches wait in HBM in the layout of the plan's input arena (image | target, each
+    # slice 16-byte aligned): handing one over is ONE device copy into the static buffers
+    arena = plan.input_arena
+    staged = []
+    for xb, tb in zip(xs, ts):
+        flat = torch.zeros_like(arena)
+        for node, src in zip(plan.inputs[:2], (xb, tb)):
+            o, n_el = plan.input_slices[node]
+            flat[o:o + n_el] = src.reshape(-1)
+        staged.append(flat)
+
+    def one_step(i):
+        with torch.cuda.stream(plan.stream):
+            arena.copy_(staged[i % n_batches], non_blocking=True)
+            opt._ensure_state(plan)
+            opt._sync_hyper(plan)
+        plan.run()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ctx = plan.ctx
+    e0, e1 = ctx.event(), ctx.event()
+    old = ctx.stream
+    t0 = time.perf_counter()
+    ctx.set_stream(plan.stream); ctx.record(e0); ctx.set_stream(old)
+    for i in range(steps):
+        one_step(warmup + i)
+    ctx.set_stream(plan.stream); ctx.record(e1); ctx.set_stream(old)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev_ms = ctx.elapsed_ms(e0, e1) / steps
+    loss = float(plan.scratch[model.loss_node.parent[0], 'loss'].item())
+    assert np.isfinite(loss), "non-finite loss"
+    return dict(builder=builder, sp=sp, osp=osp, gflop=gflop, params0=params0, model=model,
+                plan=plan, xs=xs, ts=ts, dt=dt, dev_ms=dev_ms, loss=loss)
 
 
 def main():
@@ -389,6 +479,8 @@ def main():
     ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "dense512unet", "warp183", "selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="lite183 at N = 1 also times neuro3d@185 (roofline.also.full185); skip it")
     ap.add_argument("--exchange-at-1", action="store_true",
                     help="N = 1 only, not the headline: run the data-parallel form of the step "
                          "(segmented graphs + the RCCL all-reduces) over a ONE-rank nccl group -- "
@@ -449,76 +541,11 @@ def main():
         return dense_unet_bench(args, rank, world)
     if args.workload == "warp183":
         return warp_bench(args, rank, world)
-    builder, sp, gf_table = WORKLOADS[args.workload]
-    np.random.seed(1)                         # identical initial weights on every rank
-    model = getattr(nets, builder)((None, 1) + sp)
-    osp = tuple(model.prediction_node.shape.spatial_shape)
-    if builder in ("unet3d_lite", "unet3d"):
-        gflop = gf_table                      # UpConv / merge net: SURVEY.md §8d's figure
-        args.no_cpu_baseline = True           # the CPU leg is the sequential-net port
-    else:
-        gflop = algorithmic_gflop(model)
-    params0 = conv_params(model)              # initial weights, for the CPU baseline leg
-    model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
-    opt = model.optimisers['Adam']
-    opt.step.compile()
-    plan = opt.step.func
-    plan.use_graph = not args.no_graph
-    dev = torch.device("cuda", min(int(os.environ.get("LOCAL_RANK", "0")),
-                                   max(torch.cuda.device_count() - 1, 0)))
-    rng = np.random.RandomState(parallel.rank_seed(0, rank))
-    n_batches = 4
-    xs = [torch.tensor(rng.rand(1, 1, *sp).astype(np.float32), device=dev)
-          for _ in range(n_batches)]
-    ts = [torch.tensor(rng.randint(0, 2, (1, 1) + osp).astype(np.float32), device=dev)
-          for _ in range(n_batches)]
-    plan.set_inputs([xs[0], ts[0]])          # builds plan + arena
-    if world > 1:
-        model.enable_data_parallel()
-    elif args.exchange_at_1:
-        model.enable_data_parallel(exchange_at_world_1=True)
-    # the batches wait in HBM in the layout of the plan's input arena (image | target, each
-    # slice 16-byte aligned): handing one over is ONE device copy into the static buffers
-    arena = plan.input_arena
-    staged = []
-    for xb, tb in zip(xs, ts):
-        flat = torch.zeros_like(arena)
-        for node, src in zip(plan.inputs[:2], (xb, tb)):
-            o, n_el = plan.input_slices[node]
-            flat[o:o + n_el] = src.reshape(-1)
-        staged.append(flat)
-
-    def one_step(i):
-        with torch.cuda.stream(plan.stream):
-            arena.copy_(staged[i % n_batches], non_blocking=True)
-            opt._ensure_state(plan)
-            opt._sync_hyper(plan)
-        plan.run()
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for i in range(args.warmup):
-        one_step(i)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ctx = plan.ctx
-    e0, e1 = ctx.event(), ctx.event()
-    old = ctx.stream
-    t0 = time.perf_counter()
-    ctx.set_stream(plan.stream); ctx.record(e0); ctx.set_stream(old)
-    for i in range(args.steps):
-        one_step(args.warmup + i)
-    ctx.set_stream(plan.stream); ctx.record(e1); ctx.set_stream(old)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dev_ms = ctx.elapsed_ms(e0, e1) / args.steps
-    loss = float(plan.scratch[model.loss_node.parent[0], 'loss'].item())
-    assert np.isfinite(loss), "non-finite loss"
+    backend_name = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
+    dev = torch.device("cuda", parallel.local_device(backend_name))
+    r = time_training(args.workload, args, rank, world, dev, args.steps, args.warmup)
+    builder, sp, osp, gflop = r["builder"], r["sp"], r["osp"], r["gflop"]
+    plan, dt, dev_ms, loss = r["plan"], r["dt"], r["dev_ms"], r["loss"]
 
     ranks = None
     if world > 1:
@@ -527,14 +554,17 @@ def main():
         dt = float(tt.item())
         # who took part: one line per rank (device, PCI bus id, backend) gathered on rank 0,
         # so that a scaling run shows N distinct GPUs behind the N ranks
+        import socket
         props = torch.cuda.get_device_properties(dev)
         me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
-              "device": dev.index, "name": props.name,
+              "device": dev.index, "name": props.name, "host": socket.gethostname(),
               "pci": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
               "backend": torch.distributed.get_backend(), "ms_per_step": dev_ms}
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, me)
         ranks = gathered
+        # two ranks on one GPU under RCCL = a mis-bound launch: no line, non-zero exit
+        parallel.check_distinct_devices(ranks, torch.distributed.get_backend())
 
     if rank != 0:
         return
@@ -580,7 +610,29 @@ def main():
                      "algorithmic_gflop_per_step": gflop,
                      "device_ms_per_step": dev_ms},
     }
+    if (world == 1 and args.workload == "lite183" and not args.no_also and not bf16
+            and not args.exchange_at_1):
+        # The net the target NAMES (north_star: ">= 50 % MFMA roofline on the neuro3d 3D-conv
+        # fwd+bwd", examples/neuro3d.py:51-63) rides in the same driver-run line: same process,
+        # same protocol, its own captured step; the headline fields above stay BASELINE
+        # configs[1].
+        r2 = time_training("full185", args, rank, world, dev, args.steps, args.warmup)
+        prof2 = recorded_profile("full185")
+        ach2 = r2["gflop"] / (r2["dev_ms"] * 1e-3) / 1e3
+        out["roofline"]["also"] = {"full185": {
+            "workload": "%s (1,1,%d,%d,%d)->(1,2,%d,%d,%d) fwd+bwd+Adam, 1 sample/GPU"
+                        % ((r2["builder"],) + tuple(r2["sp"]) + tuple(r2["osp"])),
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r2["dt"] / args.steps * 1e3, "device_ms_per_step": r2["dev_ms"],
+            "value": float(np.prod((1, 1) + r2["sp"])) * args.steps / r2["dt"], "unit": "voxels/s",
+            "algorithmic_gflop_per_step": r2["gflop"], "achieved": ach2, "peak": peak,
+            "frac": ach2 / peak, "mfma_util": prof2["mfma_util"], "traffic": prof2["traffic"],
+            "profile": prof2["profile"], "profile_stale": prof2["profile_stale"],
+            "final_loss": r2["loss"]}}
+    if builder in ("unet3d_lite", "unet3d"):
+        args.no_cpu_baseline = True           # the CPU leg is the sequential-net port
     if world == 1 and not args.no_cpu_baseline:
+        xs, ts, params0 = r["xs"], r["ts"], r["params0"]
         # the ONLY use of oracle/ in this script: the CPU port, timed as the baseline
         from oracle import e2_oracle as O
         from oracle import torch_step as TS

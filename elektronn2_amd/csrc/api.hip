@@ -479,7 +479,9 @@ static int upconv_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
                       int px, int act, const e2_tensor5* dx, float* dw,
                       float* dbias, void* ws, size_t ws_bytes, int accumulate,
                       const float* wp_d = nullptr) {
-  E2_REQUIRE(ctx && (w || wp_d) && ws, "upconv3d_bwd: null argument");
+  // the weights are read by the data gradient only: an UpConv whose parent needs no gradient
+  // (dx == nullptr, e.g. directly on an Input) passes neither w nor an image
+  E2_REQUIRE(ctx && ws && (w || wp_d || !dx), "upconv3d_bwd: null argument");
   if (int rc = view_ok(x, "upconv3d_bwd x")) return rc;
   if (int rc = view_ok(y, "upconv3d_bwd y")) return rc;
   if (int rc = view_ok(dout, "upconv3d_bwd dout")) return rc;

@@ -62,6 +62,15 @@ struct FirstM {
                                  // 2 = no conv MFMAs, 4 = no output stores / no dW MFMAs
 };
 
+// The ablation switches exist in a `make DEBUG_ENV=1` build only.  As run-time branches on a
+// kernel argument they cost the RELEASE backward 25 registers (103 -> 128: occupancy 3 -> 2
+// with 3 persistent work-groups launched per CU) and +16 us per step.
+#ifdef E2_DEBUG_ENV
+#define FM_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define FM_DBG(p, bit) false
+#endif
+
 constexpr int kTW = 72;                  // LDS row stride of the input tile (64 + kw - 1 <= 69)
 
 template <int KH, int KW, int PY, int PX, int MG>
@@ -105,7 +114,7 @@ __device__ __forceinline__ void load_tile(const FirstM& p, int tile, float* xt, 
   for (int e = threadIdx.x; e < G::RT * kTW; e += 256) {
     const int i = e / kTW, j = e - i * kTW;
     const int y = row0 + i, xx = col0 + j;
-    xt[e] = (y < p.H && xx < p.W && !(p.dbg & 1)) ? src[(long)y * p.xsH + xx] : 0.f;
+    xt[e] = (y < p.H && xx < p.W && !FM_DBG(p, 1)) ? src[(long)y * p.xsH + xx] : 0.f;
   }
 }
 
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
     load_tile<KH, KW, PY, PX, MG>(p, tile, xt, n, z, row0, col0);
     __syncthreads();
     f32x4 acc[MG][PY];
-    if (!(p.dbg & 2)) conv_rows<KH, KW, PY, PX, MG>(xt + wave * PY * kTW, lane, aw, acc);
+    if (!FM_DBG(p, 2)) conv_rows<KH, KW, PY, PX, MG>(xt + wave * PY * kTW, lane, aw, acc);
     else {
 #pragma unroll
       for (int g = 0; g < MG; ++g)
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
         if (ch < p.Cout) {
           float v = m + bs[g][r];
           if (p.act == E2_ACT_RELU) v = fmaxf(v, 0.f);
-          if (ok && !((p.dbg & 4) && ch > 0)) ob[(long)ch * p.osC] = v;
+          if (ok && !(FM_DBG(p, 4) && ch > 0)) ob[(long)ch * p.osC] = v;
         }
       }
   }
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void firstm_bwd_kernel(FirstM p, float* __rest
     __syncthreads();
     const float* xw = xt + wave * PY * kTW;
     f32x4 acc[MG][PY];
-    if (!(p.dbg & 2)) conv_rows<KH, KW, PY, PX, MG>(xw, lane, aw, acc);
+    if (!FM_DBG(p, 2)) conv_rows<KH, KW, PY, PX, MG>(xw, lane, aw, acc);
     else {
 #pragma unroll
       for (int g = 0; g < MG; ++g)
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256) void firstm_bwd_kernel(FirstM p, float* __rest
     // (same wave writes and reads dyw: LDS operations of a wave complete in order)
     // dW[4g..4g+3][tap = lane] += dy[..][position] * x[position + tap]
     const float* xb = xw + tapoff;
-    if (p.dbg & 4) continue;
+    if (FM_DBG(p, 4)) continue;
     if constexpr (Q4) {
       // block (pq, tap quad): A = dy[4g + i][p0 + pq] on lanes (pq, *, i), B = x[p0 + pq + tap]
       fm_for<NP / 4>([&](auto k_) {

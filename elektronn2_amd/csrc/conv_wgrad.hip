@@ -455,7 +455,17 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
   const char* force = ctx->tiling[E2_TILING_WGRAD];
   if (force[0]) {
     WCfg f{0, 0, 0, 0, 0};
-    if (sscanf(force, "%d,%d,%d,%d,%d", &f.MT, &f.NT, &f.WK, &f.BP, &f.PS) == 5) { *ok = 1; return f; }
+    if (sscanf(force, "%d,%d,%d,%d,%d", &f.MT, &f.NT, &f.WK, &f.BP, &f.PS) == 5) {
+      // "MT,NT,7,0,S" names the K-contiguous 1x1x1 GEMM (conv_pw_wgrad.hip), which takes dense
+      // channel planes and f32 mode only.  The tuning keys hold the row pitch, not the plane
+      // pitch: a view that keeps the rows but not the planes (a crop along the second spatial
+      // axis of the parent) matches a shipped entry it cannot run -- such a call takes the
+      // cost model's choice instead of failing.
+      const bool pw_ok = a.kd == 1 && a.kh == 1 && a.kw == 1 && a.xsY == a.Wo &&
+                         a.xsZ == (int64_t)a.Ho * a.Wo && a.dsY == a.Wo &&
+                         a.dsZ == (int64_t)a.Ho * a.Wo && !ctx->mfma_bf16;
+      if (f.WK != 7 || pw_ok) { *ok = 1; return f; }
+    }
   }
   if (a.dy_padded && nblocks > 2) {
     // direct kernel (conv_wgrad_direct.hip): no dy staging; tiles of 128/256 span positions

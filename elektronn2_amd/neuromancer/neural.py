@@ -89,11 +89,8 @@ class NeuralLayer(Node):
         """neural.py:146-256 (BN / dropout / gradnet branches are out of scope)."""
         from .. import config
         self.w = None
-        if config.use_ortho_init:
-            raise NotImplementedError("config.use_ortho_init: orthogonal initialisation is not "
-                                      "built (no BASELINE config sets it)")
-        w_init = dict(scale='glorot', mode='normal', pool=pool_shape,
-                      spatial_axes=self.spatial_axes)
+        w_init = dict(scale='glorot', mode='ortho' if config.use_ortho_init else 'normal',
+                      pool=pool_shape, spatial_axes=self.spatial_axes)
         self._register_param(w, w_sh, 'w', init_kwargs=w_init, apply_train=True,
                              apply_reg=True)
         act = self.activation_func

@@ -32,9 +32,8 @@ def get_ctx():
     global _ctx
     if _ctx is None:
         import os
-        dev = int(os.environ.get("LOCAL_RANK", "0"))
-        if torch.cuda.is_available() and dev >= torch.cuda.device_count():
-            dev = 0
+        from .. import parallel
+        dev = parallel.local_device()     # raises for a LOCAL_RANK without a GPU under RCCL
         _ctx = backend.Context(dev)
         if os.environ.get("E2_MFMA_DTYPE", "f32") not in ("f32", "float32"):
             _ctx.set_mfma_dtype(os.environ["E2_MFMA_DTYPE"])
@@ -408,6 +407,7 @@ class Plan(object):
         # the pair of the step BEFORE the one just submitted
         self._ev_pairs = [(self.ctx.event(), self.ctx.event()), (self.ctx.event(), self.ctx.event())]
         self._ev_idx = 0
+        self._n_runs = 0                     # run() calls so far (fetch_async pairs slots with runs)
         self._async = None                   # state of fetch_async: pinned loss slots, events
         self._built = True
 
@@ -660,6 +660,7 @@ class Plan(object):
     def run(self):
         """launch the plan on the already-set inputs; returns nothing (async)."""
         self._ev_idx ^= 1
+        self._n_runs += 1
         old = self.ctx.stream
         self.ctx.set_stream(self.stream)
         try:
@@ -703,14 +704,19 @@ class Plan(object):
         dev_loss = self.scratch[nll, 'loss']
         if self._async is None:
             self._async = dict(pin=[torch.empty(1, dtype=torch.float32).pin_memory() for _ in range(2)],
-                               ev=[torch.cuda.Event(), torch.cuda.Event()], n=0)
+                               ev=[torch.cuda.Event(), torch.cuda.Event()], n=0, run=[-1, -1])
         a = self._async
         slot = a['n'] & 1
         with torch.cuda.stream(self.stream):
             a['pin'][slot].copy_(dev_loss.reshape(1), non_blocking=True)
             a['ev'][slot].record(self.stream)
+        a['run'][slot] = self._n_runs
         prev = None, None
-        if a['n'] > 0:
+        # the other slot belongs to the step before this one only if no synchronous call
+        # (fetch) ran in between: the timing pair `_ev_idx ^ 1` and the pinned value are then
+        # those of run n - 1.  Mixed sync / async use gets (None, None) for the step after a
+        # synchronous one rather than an older step's loss paired with another step's time.
+        if a['n'] > 0 and a['run'][slot ^ 1] == self._n_runs - 1:
             a['ev'][slot ^ 1].synchronize()          # the step before the one just queued
             e0, e1 = self._ev_pairs[self._ev_idx ^ 1]
             prev = np.float32(a['pin'][slot ^ 1].item()), self.ctx.elapsed_ms(e0, e1) * 1e-3

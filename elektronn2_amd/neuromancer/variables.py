@@ -146,16 +146,21 @@ def initweights(shape, dtype=floatX, scale='glorot', mode='normal', pool=None,
       2-D matrix and (n_in + n_out / prod(pool)) * prod(kernel) for a conv tensor whose
       non-spatial axes are (n_out, n_in).
 
-    The reference's other modes ('uni', 'ortho' -- config.use_ortho_init --, 'prelu') are
-    not used by any config of the hot path and are rejected."""
+    * ``scale='glorot', mode='uni'``: U(-sqrt(2 / fan), +sqrt(2 / fan));
+    * ``scale='glorot', mode='ortho'`` (``config.use_ortho_init``): rows of the (n_out, rest)
+      matrix = right singular vectors of a normal draw, each scaled to the glorot std.
+
+    'prelu' belongs to an activation the hot path rejects and is not built."""
     if mode == 'const':
         return np.ascontiguousarray(np.full(shape, scale), dtype=dtype)
     if mode == 'fix-uni':
         return np.ascontiguousarray(np.random.uniform(-scale, scale, shape), dtype=dtype)
-    if scale != 'glorot' or mode != 'normal':
+    if scale != 'glorot' or mode not in ('normal', 'uni', 'ortho'):
         raise NotImplementedError("initweights(scale=%r, mode=%r): only 'const', 'fix-uni' and "
-                                  "glorot / 'normal' are built (SURVEY.md 8a-9)" % (scale, mode))
+                                  "glorot with 'normal' / 'uni' / 'ortho' are built "
+                                  "(SURVEY.md 8a-9)" % (scale, mode))
     if len(shape) == 2:
+        n_out, n_in = shape[1], shape[0]
         fan = shape[0] + shape[1]
     else:
         if spatial_axes is None:
@@ -163,4 +168,22 @@ def initweights(shape, dtype=floatX, scale='glorot', mode='normal', pool=None,
         kernel = [s for i, s in enumerate(shape) if i in spatial_axes]
         n_out, n_in = [s for i, s in enumerate(shape) if i not in spatial_axes]
         fan = (n_in + float(n_out) / np.prod(pool)) * np.prod(kernel)
-    return np.ascontiguousarray(np.random.normal(0, np.sqrt(2.0 / fan), shape), dtype=dtype)
+    std = np.sqrt(2.0 / fan)
+    if mode == 'uni':
+        return np.ascontiguousarray(np.random.uniform(-std, std, shape), dtype=dtype)
+    if mode == 'ortho':
+        return np.ascontiguousarray(_ortho_rows(shape, n_out, std), dtype=dtype)
+    return np.ascontiguousarray(np.random.normal(0, std, shape), dtype=dtype)
+
+
+def _ortho_rows(shape, n_out, std):
+    """variables.py:246-262: the first draw always has the tensor's shape (it fixes the RNG
+    stream); with more rows than columns a square matrix is drawn instead and its surplus
+    columns are dropped after the decomposition."""
+    m = np.random.normal(0, std, size=shape).reshape(n_out, -1)
+    cols = m.shape[1]
+    if n_out > cols:
+        m = np.random.normal(0, std, size=(n_out, n_out))
+    vt = np.linalg.svd(m, full_matrices=False)[2]
+    rows = vt * (std / vt.std(axis=1, keepdims=True))
+    return rows[:, :cols].reshape(shape)

@@ -12,6 +12,46 @@ import torch
 import torch.distributed as dist
 
 
+def local_device(backend=None, local_rank=None, device_count=None):
+    """Index of the GPU this rank drives: LOCAL_RANK.  A LOCAL_RANK the node has no GPU for
+    is an ERROR under RCCL ("nccl": one GPU per rank -- a mis-bound 8-rank launch would
+    otherwise put every rank on GPU 0 and only the rank list of the bench line would show it).
+    Only a gloo rehearsal (backend "gloo" / E2_DIST_BACKEND=gloo: several ranks sharing the
+    one card of a test box) wraps around."""
+    idx = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else int(local_rank)
+    if device_count is None:
+        if not torch.cuda.is_available():
+            return idx
+        device_count = torch.cuda.device_count()
+    if idx < device_count:
+        return idx
+    if backend is None:
+        backend = dist.get_backend() if dist.is_initialized() else \
+            os.environ.get("E2_DIST_BACKEND", "nccl")
+    if backend == "gloo" and device_count > 0:
+        return idx % device_count
+    raise RuntimeError("LOCAL_RANK=%d but this node shows %d GPU(s): launch one rank per visible "
+                       "GPU (or set E2_DIST_BACKEND=gloo to rehearse several ranks on one card)"
+                       % (idx, device_count))
+
+
+def check_distinct_devices(ranks, backend):
+    """``ranks``: one dict per rank with 'rank', 'host', 'pci' (and 'uuid').  Under RCCL two
+    ranks on the same GPU of the same host are a mis-bound launch: raise, naming them.  (A
+    gloo rehearsal shares the card on purpose.)"""
+    if backend != "nccl":
+        return
+    seen = {}
+    for r in ranks:
+        key = (r.get("host"), r.get("pci") if r.get("pci") is not None else r.get("uuid"))
+        if key[1] in (None, ""):
+            continue
+        if key in seen:
+            raise RuntimeError("ranks %s and %s both run on GPU %s of host %s: one GPU per rank "
+                               "is required under RCCL" % (seen[key], r.get("rank"), key[1], key[0]))
+        seen[key] = r.get("rank")
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK/WORLD_SIZE/MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -22,8 +62,7 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if torch.cuda.is_available():
-        torch.cuda.set_device(min(int(os.environ.get("LOCAL_RANK", "0")),
-                                  torch.cuda.device_count() - 1))
+        torch.cuda.set_device(local_device(backend))
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
     return world
 

@@ -54,6 +54,41 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def test_launcher_survives_a_noisy_rank_0():
+    # > 64 KiB on rank 0's stdout before the line: a pipe nobody drains would block rank 0 in
+    # write() and the other rank in the barrier behind it
+    r = run(["--gpus", "2", "--workload", "selftest"], {"E2_SELFTEST_NOISE": "300000"}, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.lstrip().startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_a_local_rank_without_a_gpu_is_an_error_under_rccl():
+    from elektronn2_amd import parallel
+    assert parallel.local_device("nccl", local_rank=3, device_count=8) == 3
+    with pytest.raises(RuntimeError, match="LOCAL_RANK=5"):
+        parallel.local_device("nccl", local_rank=5, device_count=4)
+    with pytest.raises(RuntimeError, match="LOCAL_RANK=1"):
+        parallel.local_device("nccl", local_rank=1, device_count=1)
+    # the gloo rehearsal (several ranks on the one card of a test box) wraps around
+    assert parallel.local_device("gloo", local_rank=1, device_count=1) == 0
+    assert parallel.local_device("gloo", local_rank=5, device_count=4) == 1
+
+
+def test_two_ranks_on_one_gpu_fail_the_run_under_rccl():
+    from elektronn2_amd import parallel
+    ok = [{"rank": r, "host": "n0", "pci": r * 16, "uuid": "u%d" % r} for r in range(8)]
+    parallel.check_distinct_devices(ok, "nccl")
+    bad = [dict(d) for d in ok]
+    bad[5]["pci"] = bad[2]["pci"]
+    with pytest.raises(RuntimeError, match="ranks 2 and 5"):
+        parallel.check_distinct_devices(bad, "nccl")
+    parallel.check_distinct_devices(bad, "gloo")                   # a rehearsal shares the card
+    other_host = [dict(d) for d in bad]
+    other_host[5]["host"] = "n1"                                   # same bus id on ANOTHER host
+    parallel.check_distinct_devices(other_host, "nccl")
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_on_one_card():
     r = run(["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],

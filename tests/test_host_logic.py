@@ -114,6 +114,42 @@ def test_param_init_formulas_and_protocol():
         nm.Conv(c, 7, (1, 1, 1), w=np.zeros((7, 3, 1, 1, 1), np.float32))
 
 
+def test_uni_and_ortho_init_modes():
+    """variables.py:205-266: 'uni' and 'ortho' (config.use_ortho_init) next to 'normal'."""
+    from elektronn2_amd.neuromancer.variables import initweights
+    from elektronn2_amd import config
+    kw = dict(scale='glorot', pool=(2, 1, 1), spatial_axes=[2, 3, 4])
+    sh = (40, 6, 2, 3, 3)
+    std = np.sqrt(2.0 / ((6 + 40 / 2.0) * 18))
+    np.random.seed(1)
+    u = initweights(sh, mode='uni', **kw)
+    assert u.shape == sh and u.dtype == np.float32 and abs(u).max() <= std
+    assert abs(u.std() - std / np.sqrt(3)) / u.std() < 0.05
+    np.random.seed(1)
+    o = initweights(sh, mode='ortho', **kw).reshape(40, -1)           # 40 rows of 108
+    g = o @ o.T
+    assert np.abs(g - np.diag(np.diag(g))).max() < 1e-4 * np.diag(g).min()   # orthogonal rows
+    assert np.allclose(o.std(axis=1), std, rtol=1e-4)                 # each at the glorot std
+    # RNG stream: the first draw has the tensor's shape, whatever follows
+    np.random.seed(1); np.random.normal(0, std, size=sh); nxt = np.random.rand()
+    np.random.seed(1); initweights(sh, mode='ortho', **kw)
+    assert np.random.rand() == nxt
+    tall = initweights((30, 2, 1, 3, 3), mode='ortho', scale='glorot', pool=(1, 1, 1),
+                       spatial_axes=[2, 3, 4])                        # more rows than columns
+    assert tall.shape == (30, 2, 1, 3, 3) and np.isfinite(tall).all()
+    config.use_ortho_init = True
+    try:
+        nm.model_manager.reset()
+        c = nm.Conv(nm.Input((1, 4, 9, 20, 20), 'b,f,z,x,y'), 8, (2, 3, 3))
+        w = c.w.get_value().reshape(8, -1)
+        g = w @ w.T
+        assert np.abs(g - np.diag(np.diag(g))).max() < 1e-4 * np.diag(g).min()
+    finally:
+        config.use_ortho_init = False
+    with pytest.raises(NotImplementedError):
+        initweights(sh, mode='prelu', **kw)
+
+
 def test_error_behaviour_matches_reference():
     inp = nm.Input((1, 1, 8, 20, 20), 'b,f,z,x,y')
     with pytest.raises(ValueError, match="dimensionality"):

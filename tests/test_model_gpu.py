@@ -179,6 +179,49 @@ def test_unet_like_merge_parity():
         assert rel(g[names.index(n.name + '_b')], W[n.name][1].grad.numpy()) < TOL, n.name
 
 
+def test_upconv_on_an_input_node_trains():
+    """An UpConv whose parent needs no gradient (directly on the Input): the packed backward
+    gets neither dx nor the data gradient's image (api.hip upconv_bwd).  Loss and
+    gradients against torch-CPU float64 autograd of the oracle's closed forms, eager and
+    replayed."""
+    from elektronn2_amd import neuromancer as nm
+    from oracle import torch_step as TS
+    nm.model_manager.reset()
+    np.random.seed(5)
+    inp = nm.Input((1, 1, 6, 20, 20), 'b,f,z,x,y', name='raw')
+    up = nm.UpConv(inp, 6, (1, 2, 2))
+    c0 = nm.Conv(up, 8, (1, 3, 3))
+    out = nm.Conv(c0, 2, (1, 1, 1), activation_func='lin')
+    probs = nm.Softmax(out)
+    target = nm.Input_like(probs, override_f=1, name='target')
+    loss = nm.AggregateLoss(nm.MultinoulliNLL(probs, target, target_is_sparse=True), name='loss')
+    model = nm.model_manager.getmodel()
+    model.designate_nodes(input_node=inp, target_node=target, loss_node=loss,
+                          prediction_node=probs)
+    rng = np.random.RandomState(6)
+    x = rng.rand(1, 1, 6, 20, 20).astype(np.float32)
+    t = rng.randint(0, 2, [1, 1] + probs.shape.spatial_shape).astype(np.float32)
+
+    def tt(p):
+        return torch.tensor(p.get_value(), dtype=torch.float64, requires_grad=True)
+    W = {n.name: (tt(n.w), tt(n.b)) for n in (up, c0, out)}
+    hu = TS.upconv_node(torch.tensor(x, dtype=torch.float64), *W[up.name], up.pool_shape, 'relu')
+    h0 = TS.conv_node(hu, *W[c0.name], (1, 1, 1), 'relu')
+    lg = TS.conv_node(h0, *W[out.name], (1, 1, 1), 'lin')
+    L, _ = TS.nll_loss(lg, torch.tensor(t, dtype=torch.float64))
+    L.backward()
+    names = list(model.loss_node.all_trainable_params.keys())
+    for _ in range(3):                       # eager, capture, replay
+        g = model.gradients(x, t)
+        for n in (up, c0, out):
+            assert rel(g[names.index(n.name + '_w')], W[n.name][0].grad.numpy()) < TOL, n.name
+            assert rel(g[names.index(n.name + '_b')], W[n.name][1].grad.numpy()) < TOL, n.name
+    l0 = float(model.trainingstep(x, t, optimiser='Adam')[0])
+    assert abs(l0 - float(L)) / float(L) < TOL
+    l1 = float(model.trainingstep(x, t, optimiser='Adam')[0])
+    assert l1 < l0
+
+
 def test_graph_replay_equals_eager_at_baseline_size():
     """C-lite@183 (BASELINE configs[1]): 12 Adam steps replayed from the captured
     hipGraphs against the same 12 steps launched eagerly -- the losses must agree step
@@ -234,6 +277,17 @@ def test_trainingstep_with_deferred_loss():
         assert abs(la[i] - ls[i - 1]) < 1e-5 * abs(ls[i - 1]), (i, la, ls)
     for a, b in zip(pa, ps):
         assert rel(a, b) < 1e-4
+    # the two modes interleaved: a deferred call that follows a synchronous one has no
+    # "previous deferred step" -- it waits for its own loss instead of handing back an older
+    # step's (plan.fetch_async)
+    m = build('lite', sp, params)
+    m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    modes = [False, False, True, False, False, True, True, False]
+    got = [float(m.trainingstep(xs[i % 4], ts[i % 4], optimiser='Adam', sync=modes[i])[0])
+           for i in range(8)]
+    want = [ls[0], ls[0], ls[2], ls[3], ls[3], ls[5], ls[6], ls[7]]
+    for i in range(8):
+        assert abs(got[i] - want[i]) < 1e-5 * abs(want[i]), (i, got, want)
 
 
 def _dense_model(spec, params, patch_sp):

@@ -750,6 +750,13 @@ def test_upconv3d(ctx, case):
     ctx.upconv3d_bwd_packed(dev(x), wp_d, yv, gv, pool, act, dx2, dw2, db2, ws)   # overwrite form
     assert relerr(dw2, O.upconv3d_wgrad(dpre, x, pool)) < TOL
     assert relerr(db2, db_ref) < TOL
+    # an UpConv whose parent needs no gradient (directly on an Input): no dx, no image --
+    # the weight-gradient half reads neither (this call was refused)
+    dw3 = torch.full(w.shape, float("nan"), device="cuda")
+    db3 = torch.full((Co,), float("nan"), device="cuda")
+    ctx.upconv3d_bwd_packed(dev(x), None, yv, gv, pool, act, None, dw3, db3, ws)
+    assert relerr(dw3, O.upconv3d_wgrad(dpre, x, pool)) < TOL
+    assert relerr(db3, db_ref) < TOL
 
 
 def test_transposes_and_copy(ctx):
