@@ -191,7 +191,8 @@ def test_upconv_on_an_input_node_trains():
     inp = nm.Input((1, 1, 6, 20, 20), 'b,f,z,x,y', name='raw')
     up = nm.UpConv(inp, 6, (1, 2, 2))
     c0 = nm.Conv(up, 8, (1, 3, 3))
-    out = nm.Conv(c0, 2, (1, 1, 1), activation_func='lin')
+    c1 = nm.Conv(c0, 8, (1, 3, 3), (1, 2, 2))    # (the field of view must stay centred: model.py:141-152)
+    out = nm.Conv(c1, 2, (1, 1, 1), activation_func='lin')
     probs = nm.Softmax(out)
     target = nm.Input_like(probs, override_f=1, name='target')
     loss = nm.AggregateLoss(nm.MultinoulliNLL(probs, target, target_is_sparse=True), name='loss')
@@ -204,16 +205,17 @@ def test_upconv_on_an_input_node_trains():
 
     def tt(p):
         return torch.tensor(p.get_value(), dtype=torch.float64, requires_grad=True)
-    W = {n.name: (tt(n.w), tt(n.b)) for n in (up, c0, out)}
+    W = {n.name: (tt(n.w), tt(n.b)) for n in (up, c0, c1, out)}
     hu = TS.upconv_node(torch.tensor(x, dtype=torch.float64), *W[up.name], up.pool_shape, 'relu')
     h0 = TS.conv_node(hu, *W[c0.name], (1, 1, 1), 'relu')
-    lg = TS.conv_node(h0, *W[out.name], (1, 1, 1), 'lin')
+    h1 = TS.conv_node(h0, *W[c1.name], (1, 2, 2), 'relu')
+    lg = TS.conv_node(h1, *W[out.name], (1, 1, 1), 'lin')
     L, _ = TS.nll_loss(lg, torch.tensor(t, dtype=torch.float64))
     L.backward()
     names = list(model.loss_node.all_trainable_params.keys())
     for _ in range(3):                       # eager, capture, replay
         g = model.gradients(x, t)
-        for n in (up, c0, out):
+        for n in (up, c0, c1, out):
             assert rel(g[names.index(n.name + '_w')], W[n.name][0].grad.numpy()) < TOL, n.name
             assert rel(g[names.index(n.name + '_b')], W[n.name][1].grad.numpy()) < TOL, n.name
     l0 = float(model.trainingstep(x, t, optimiser='Adam')[0])
