@@ -70,6 +70,11 @@ def _load():
         "e2_head_supported": (C.c_int, [i, i]),
         "e2_head_fwd": (C.c_int, [vp, P5, fp, fp, i, P5, P5, fp]),
         "e2_head_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
+        "e2_tail_supported": (C.c_int, [i, i, i]),
+        "e2_tail_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
+        "e2_tail_fwd_bwd": (C.c_int, [vp, P5, fp, fp, fp, i, fp, fp, i, P5, P5, P5, P5, fp,
+                                      C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+        "e2_tail_reduce": (C.c_int, [vp, C.c_void_p, i, i, i, fp, fp, fp, fp, fp]),
         "e2_head_bwd": (C.c_int, [vp, P5, fp, P5, P5, fp, P5, i, fp, fp, fp, C.c_void_p,
                                   C.c_size_t]),
         "e2_malis_loss_weights": (C.c_int, [i, C.c_void_p, i, C.c_void_p, C.c_void_p,
@@ -363,6 +368,35 @@ class Context:
                               1 if accumulate_dx else 0, _fp(dw), _fp(dbias),
                               _fp(loss_out) if loss_out is not None else None,
                               C.c_void_p(ws.data_ptr()), ws.numel() * 4), "e2_head_bwd")
+
+    # ---- the tail of the neuro3d nets: 1x1x1 conv + head, forward and backward --------
+    @staticmethod
+    def tail_supported(c1, c2, ncls):
+        return bool(_lib.e2_tail_supported(int(c1), int(c2), int(ncls)))
+
+    @staticmethod
+    def tail_ws_bytes(x_shape, c2, ncls):
+        n, _, d, h, w = (int(v) for v in x_shape)
+        return int(_lib.e2_tail_workspace_bytes(n, int(c2), int(ncls), d, h, w))
+
+    def tail_fwd_bwd(self, x, wp_fwd, wp_dgrad, bias1, w_head, b_head, target, probs, dpre, dx,
+                     stats, ws):
+        """csrc/tail.hip: forward and backward of [1x1x1 conv + bias + relu] -> [classifier
+        head] in one launch; returns the number of partial-sum slots written to ``ws``"""
+        n_slots = C.c_int(0)
+        _chk(_lib.e2_tail_fwd_bwd(self.h, C.byref(t5(x)), _fp(wp_fwd), _fp(wp_dgrad), _fp(bias1),
+                                  dpre.shape[1], _fp(w_head), _fp(b_head), probs.shape[1],
+                                  C.byref(t5(target)), C.byref(t5(probs)), C.byref(t5(dpre)),
+                                  C.byref(t5(dx)) if dx is not None else None, _fp(stats),
+                                  C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.byref(n_slots)),
+             "e2_tail_fwd_bwd")
+        return int(n_slots.value)
+
+    def tail_reduce(self, ws, n_slots, c2, ncls, dw_head, db_head, db1, stats, loss_out):
+        _chk(_lib.e2_tail_reduce(self.h, C.c_void_p(ws.data_ptr()), int(n_slots), int(c2),
+                                 int(ncls), _fp(dw_head), _fp(db_head), _fp(db1), _fp(stats),
+                                 _fp(loss_out) if loss_out is not None else None),
+             "e2_tail_reduce")
 
     def conv3d_wgrad(self, x, dy, dw, accumulate=False):
         kd, kh, kw = dw.shape[2:]

@@ -1,0 +1,501 @@
+// tail.hip -- the TAIL of the neuro3d nets in one launch, forward and backward:
+//
+//   x (C1 ch.) -> 1x1x1 conv to C2 channels + bias + relu      (neural.py:662-712 with a
+//                 (1,1,1) kernel = the "tensordot" branch, computations.py:330-335,377-384)
+//              -> 1x1x1 conv to ncls <= 4 'lin' features -> channel softmax
+//                 (computations.py:175-176) -> MultinoulliNLL, sparse targets (loss.py:261-347)
+//   and T.grad of that chain (model.py:182): dlogits, the head's dW / dbias, the gradient of
+//   the 1x1x1 layer's pre-activation `dpre` (its weight gradient's operand; its bias
+//   gradient = the row sums), and the data gradient dx = W^T dpre.
+//
+// Everything here is per position -- both convs have one tap -- so a work-group that owns a
+// tile of positions can run the whole chain out of LDS.  As separate launches this was
+// (examples/neuro3d_lite.py at 183^2, us): 1x1x1 forward 23 + head forward 12 + head backward
+// 18 + activation backward 10 + 1x1x1 data gradient 23 = 86 us for 14 us of matrix work and
+// 11 MB tensors written and read back four times; neuro3d's 2,205-position tail: 61 us for
+// 2.3 us of matrix work.
+//
+//   tile    = NP = 16 * WN consecutive positions of one sample (the tensors are dense in
+//             (z, y, x), so a position is one flat index), all channels; 4 waves = WM x WN:
+//             wave (wm, wn) owns 16 positions and MTW = ceil(13 / WM) of the 13 blocks of
+//             16 channel rows (C1, C2 <= 208).  WM = 1 / 2 / 4 by the host: few positions
+//             (neuro3d: 2,205) -> split the rows, so that 138 work-groups exist instead of 35.
+//   phase A : pre[co][p] = sum_ci Wf[ci][co] x[ci][p]   fp32 MFMA 16x16x4; B from the x tile
+//             in LDS, A from the forward packed image ([k][m], m contiguous: the image
+//             conv_igemm.hip keeps), staged in chunks of 40 k-rows by LDS-DMA, double buffered.
+//   epilogue: h = relu(pre + b1) written over the x tile ([channel][position]); a negative
+//             pre-activation keeps its sign in the zero (-0.0): relu'(0) = 0.5 (Theano) is told
+//             from 0 by it, as in the GEMM epilogues of igemm_core.hpp.
+//   head    : thread (position, channel share) -> partial logits -> LDS -> softmax, probs out,
+//             -log(p_target + 1e-5), dlogits (needs 1 / #labelled: every work-group counts the
+//             labelled voxels of the WHOLE target itself -- 55 KB from L2 -- or reads the count
+//             of a pre-pass for large targets).
+//   dpre    : thread = channel row: dpre = (Wh^T dlogits) * relu'(h), in place in LDS, row sums
+//             (bias gradient) and dWh[c][row] = sum_p dlogits[c][p] h[row][p] in registers ->
+//             ONE partial-sum slot per work-group (no same-address atomics, DESIGN.md lesson 6).
+//   phase C : dx[ci][p] = sum_co Wd[co][ci] dpre[co][p]  (B = the dpre tile, A = the data
+//             gradient's packed image), tile -> LDS -> 4 NP-byte row segments to memory.
+//   A small second kernel adds the slots up (into the zeroed gradient arena) and writes the
+//   loss: it is launched from the BACKWARD half of the plan, behind the arena's zero fill.
+#include "common.hpp"
+#include <algorithm>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+#define E2_EPS_NLL 1e-5f
+
+namespace {
+
+constexpr int kMT = 13;              // 16-row blocks: up to 208 channels on either side
+constexpr int kRows = 16 * kMT;
+constexpr int kKC = 40;              // k-rows per staged weight chunk
+
+struct TailP {
+  const float* x; long xsN, xsC;
+  const float* wpf; int coPf, ciPf;  // forward image [ci][coPf]
+  const float* wpd; int coPd, ciPd;  // data-gradient image [co][coPd] (m = ci)
+  const float* b1;                   // bias of the 1x1x1 layer [C2]
+  const float* wh; const float* bh;  // head [ncls][C2], [ncls]
+  const float* tg; long tsN;         // target [N][1][S]
+  float* pr; long psN, psC;          // probabilities [N][ncls][S]
+  float* dpre; long dsN, dsC;        // gradient of the 1x1x1 layer's pre-activation [N][C2][S]
+  float* dx; long gsN, gsC;          // gradient of x [N][C1][S], or nullptr
+  float* part;                       // [work-groups][PSZ] partial sums
+  float* stats;                      // [0] loss sum (written by the reduce kernel), [1] #labelled
+  int N, C1, C2, S;
+  int tilesPerN;
+  long nTarget;                      // N * S
+  int count_here;                    // 1: count the labelled voxels in this kernel
+};
+
+template <int WM>
+struct Geo {
+  static constexpr int WN = 4 / WM, NP = 16 * WN;
+  // row stride of the tile: odd (thread-per-row passes) and 17 mod 32 (the four k-rows of an
+  // MFMA operand read sit 17 banks apart: one 2-way conflict per read)
+  static constexpr int NPP = NP == 16 ? 17 : NP + 17;
+  static constexpr int MTW = (kMT + WM - 1) / WM;
+  static constexpr int BM = 16 * MTW * WM;
+  static constexpr int BMS = (BM % 32 == 16) ? BM : BM + 16;   // k-rows 16 banks apart
+  static constexpr int NQ = 256 / NP;                          // channel shares of a position
+  static constexpr int TILE_F = ((kRows * NPP + 3) / 4) * 4;
+  static constexpr int WB_F = kKC * BMS;
+};
+template <int WM, int NC>
+constexpr size_t tail_lds_bytes() {
+  using G = Geo<WM>;
+  return sizeof(float) * (size_t)(G::TILE_F + 2 * G::WB_F + G::NQ * NC * G::NP + NC * G::NP + 16);
+}
+
+__host__ __device__ inline int tail_psz(int nc, int c2) { return nc * c2 + nc + c2 + 1; }
+
+template <int WM, int NC>
+__global__ __launch_bounds__(256) void tail_kernel(TailP p) {
+  using G = Geo<WM>;
+  constexpr int WN = G::WN, NP = G::NP, NPP = G::NPP, MTW = G::MTW, BM = G::BM, BMS = G::BMS,
+                NQ = G::NQ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* T = lds;                                   // [kRows][NPP]: x, then h, then dpre, then dx
+  float* WB = lds + G::TILE_F;                      // 2 x [kKC][BMS] weight chunks
+  float* PL = WB + 2 * G::WB_F;                     // [NQ][NC][NP] partial logits
+  float* DL = PL + NQ * NC * NP;                    // [NC][NP] dlogits
+  float* RED = DL + NC * NP;                        // scalars
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wn = wave / WM;
+  const int n = blockIdx.x / p.tilesPerN;
+  const int s0 = (blockIdx.x - n * p.tilesPerN) * NP;
+  const int np = min(NP, p.S - s0);
+  const int pp = tid % NP, pq = tid / NP;           // (position, channel share) of the passes
+
+  // ---- weight chunks: image rows [c * kKC, + kKC) x columns [0, BM) -> LDS by LDS-DMA --------
+  constexpr int PIECES = kKC * BMS / 4;             // 16-byte pieces of a chunk, pad columns too
+  constexpr int NI = (PIECES + 255) / 256;
+  int wrow[NI], wcol[NI];
+#pragma unroll
+  for (int it = 0; it < NI; ++it) {
+    const int pi = min(it * 256 + tid, PIECES - 1);
+    wrow[it] = (pi * 4) / BMS;
+    wcol[it] = min(pi * 4 - wrow[it] * BMS, BM - 4);          // pad columns re-read the last piece
+  }
+  auto stage = [&](const float* img, int coP, int ciP, int c, int buf) {
+    const float* wc = img + (long)c * kKC * coP;
+    unsigned char* lb = reinterpret_cast<unsigned char*>(WB + buf * G::WB_F) + (wave * 64) * 16;
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+      if (it * 256 + tid < PIECES && c * kKC + wrow[it] < ciP)   // (rows past the image: never read)
+        __builtin_amdgcn_global_load_lds((gbl_vp)(wc + (long)wrow[it] * coP + wcol[it]),
+                                         (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
+  };
+  stage(p.wpf, p.coPf, p.ciPf, 0, 0);
+
+  // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
+  float cnt = 0.f;
+  if (p.count_here) {
+    for (int n2 = 0; n2 < p.N; ++n2) {
+      const float* tp = p.tg + (long)n2 * p.tsN;
+      for (int i = tid; i < p.S; i += 256) {
+        const float tv = tp[i];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cnt += (tv == (float)c) ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) RED[wave] = cnt;
+  }
+
+  // ---- the x tile -> LDS: rows of NP positions, zero past the sample and past C1 ------------
+  {
+    const float* xb = p.x + (long)n * p.xsN + s0 + pp;
+    const bool pv = pp < np;
+#pragma unroll 10
+    for (int r = pq; r < kRows; r += NQ) T[r * NPP + pp] = (pv && r < p.C1) ? xb[(long)r * p.xsC] : 0.f;
+  }
+
+  // ---- one GEMM phase: acc[i] (+)= sum_k img[k][m] * T[k][position] --------------------------
+  f32x4 acc[MTW];
+  // chunk c of a phase sits in buffer (buf0 + c) & 1; its first chunk was staged by the caller
+  auto gemm = [&](const float* img, int coP, int ciP, int K, int buf0, const float* img_next,
+                  int coPn, int ciPn) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nch = (K + kKC - 1) / kKC;
+    for (int c = 0; c < nch; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                         // chunk c has landed; the other buffer is free
+      if (c + 1 < nch) stage(img, coP, ciP, c + 1, (buf0 + c + 1) & 1);
+      else if (img_next) stage(img_next, coPn, ciPn, 0, (buf0 + c + 1) & 1);   // the next phase's first chunk
+      const float* wb = WB + ((buf0 + c) & 1) * G::WB_F + (wm * MTW) * 16 + l15;
+      const float* tb = T + (c * kKC) * NPP + wn * 16 + l15;
+      const int nst = min(kKC / 4, (K - c * kKC + 3) >> 2);
+#pragma unroll
+      for (int s = 0; s < kKC / 4; ++s) {
+        if (s < nst) {
+          const float b = tb[(4 * s + kq) * NPP];
+          float a[MTW];
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) a[i] = wb[(4 * s + kq) * BMS + 16 * i];
+#pragma unroll
+          for (int i = 0; i < MTW; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    return nch;
+  };
+
+  // ======== phase A: pre = Wf^T x ================================================================
+  const int nchA = gemm(p.wpf, p.coPf, p.ciPf, p.C1, 0, p.dx ? p.wpd : nullptr, p.coPd, p.ciPd);
+  __syncthreads();                             // every wave is done with the x tile
+  // h = relu(pre + b1) over the tile; rows past C2 are the zero k-rows of phase C
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int r0 = (wm * MTW + i) * 16 + 4 * kq;
+    if (r0 < kRows) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + r;
+        float v = 0.f;
+        if (row < p.C2) {
+          const float t = acc[i][r] + p.b1[row];
+          v = (t > 0.f) ? t : ((t == 0.f) ? 0.f : -0.f);
+        }
+        T[row * NPP + wn * 16 + l15] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ======== head: logits, softmax, loss, dlogits ================================================
+  {
+    const int per = (p.C2 + NQ - 1) / NQ;
+    const int c0 = pq * per, c1 = min(c0 + per, p.C2);
+    float lg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) lg[c] = 0.f;
+    for (int co = c0; co < c1; ++co) {
+      const float hv = fmaxf(T[co * NPP + pp], 0.f);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) lg[c] = fmaf(p.wh[c * p.C2 + co], hv, lg[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) PL[(pq * NC + c) * NP + pp] = lg[c];
+  }
+  __syncthreads();
+  float inv;
+  {
+    float tot = p.count_here ? ((RED[0] + RED[1]) + (RED[2] + RED[3])) : p.stats[1];
+    inv = 1.f / (tot + E2_EPS_NLL);
+    if (blockIdx.x == 0 && tid == 0 && p.count_here) p.stats[1] = tot;
+  }
+  if (wave == 0) {                             // (NP <= 64 positions: lanes 0 .. NP-1)
+    float lsum = 0.f;
+    float d[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) d[c] = 0.f;
+    if (tid < np) {
+      float lg[NC], m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float s = 0.f;
+        for (int q = 0; q < NQ; ++q) s += PL[(q * NC + c) * NP + tid];
+        lg[c] = s + p.bh[c];
+        m = fmaxf(m, lg[c]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) den += expf(lg[c] - m);
+      const float tv = p.tg[(long)n * p.tsN + s0 + tid];
+      float* prp = p.pr + (long)n * p.psN + s0 + tid;
+      float pc[NC], pt = 0.f;
+      int tc = -1;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        pc[c] = expf(lg[c] - m) / den;
+        prp[(long)c * p.psC] = pc[c];
+        if (tv == (float)c) { tc = c; pt = pc[c]; lsum -= logf(pc[c] + E2_EPS_NLL); }
+      }
+      // dL/dp_t = -inv / (p_t + eps);  dlogit_c = p_c (dp_c - sum_k dp_k p_k)   (head.hip)
+      const float gpt = (tc >= 0) ? (-inv / (pt + E2_EPS_NLL)) * pt : 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) d[c] = gpt * ((c == tc ? 1.f : 0.f) - pc[c]);
+    }
+    if (tid < NP) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) DL[c * NP + tid] = d[c];
+    }
+    // this work-group's loss sum and head-bias gradient (lanes >= np hold zeros)
+    float* mine = p.part + (long)blockIdx.x * tail_psz(NC, p.C2);
+    float v = lsum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) mine[NC * p.C2 + NC + p.C2] = v;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      float sb = d[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
+      if (lane == 0) mine[NC * p.C2 + c] = sb;
+    }
+  }
+  __syncthreads();
+
+  // ======== dpre = (Wh^T dlogits) * relu'(h), thread = channel row ============================
+  if (tid < p.C2) {
+    const int row = tid;
+    float w[NC], aw[NC], db = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { w[c] = p.wh[c * p.C2 + row]; aw[c] = 0.f; }
+    float* tr = T + row * NPP;
+#pragma unroll 8
+    for (int q = 0; q < NP; ++q) {
+      const float hv = tr[q];
+      float g = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) g = fmaf(w[c], DL[c * NP + q], g);     // (0 past the sample)
+      const float slope = (hv > 0.f) ? 1.f : (__builtin_signbit(hv) ? 0.f : 0.5f);
+      const float d = g * slope;
+      tr[q] = d;
+      db += d;
+      const float hp = fmaxf(hv, 0.f);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) aw[c] = fmaf(DL[c * NP + q], hp, aw[c]);
+    }
+    float* mine = p.part + (long)blockIdx.x * tail_psz(NC, p.C2);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) mine[c * p.C2 + row] = aw[c];
+    mine[NC * p.C2 + NC + row] = db;
+  }
+  __syncthreads();
+  // the dpre tile to memory (the 1x1x1 layer's weight gradient reads it), rows of NP positions
+  if (pp < np) {
+    float* db_ = p.dpre + (long)n * p.dsN + s0 + pp;
+#pragma unroll 10
+    for (int r = pq; r < p.C2; r += NQ) db_[(long)r * p.dsC] = T[r * NPP + pp];
+  }
+  if (!p.dx) return;                           // (uniform: nothing upstream needs a gradient)
+
+  // ======== phase C: dx = Wd^T dpre =============================================================
+  gemm(p.wpd, p.coPd, p.ciPd, p.C2, nchA & 1, nullptr, 0, 0);
+  __syncthreads();                             // every wave is done with the dpre tile
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int r0 = (wm * MTW + i) * 16 + 4 * kq;
+    if (r0 < kRows) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(r0 + r) * NPP + wn * 16 + l15] = acc[i][r];
+    }
+  }
+  __syncthreads();
+  if (pp < np) {
+    float* gb = p.dx + (long)n * p.gsN + s0 + pp;
+#pragma unroll 10
+    for (int r = pq; r < p.C1; r += NQ) gb[(long)r * p.gsC] = T[r * NPP + pp];
+  }
+}
+
+// the labelled voxels of a LARGE target, once (the tail kernel counts small ones itself)
+template <int NC>
+__global__ __launch_bounds__(256) void tail_count_kernel(const float* tg, long tsN, int S, long nTarget,
+                                                         float* stats) {
+  float cnt = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nTarget; i += (long)gridDim.x * 256) {
+    const float tv = tg[(i / S) * tsN + (i % S)];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cnt += (tv == (float)c) ? 1.f : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0 && cnt != 0.f) unsafeAtomicAdd(stats + 1, cnt);
+}
+
+// slot sums -> dwh / dbh / db1 (ADDED: the gradient arena was zeroed), stats[0] and the loss
+__global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int nWG,
+                                                          int nc, int c2, float* dwh, float* dbh,
+                                                          float* db1, float* stats, float* loss_out) {
+  const int psz = tail_psz(nc, c2);
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= psz) return;
+  if (idx == psz - 1) {                        // the loss sum: one thread, all slots, plain store
+    if (blockIdx.y != 0) return;
+    float s = 0.f;
+    for (int b = 0; b < nWG; ++b) s += part[(long)b * psz + idx];
+    stats[0] = s;
+    if (loss_out) loss_out[0] = s / (stats[1] + E2_EPS_NLL);
+    return;
+  }
+  const int per = (nWG + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(b0 + per, nWG);
+  float s = 0.f;
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) s += part[(long)b * psz + idx];
+  if (s == 0.f) return;
+  float* dst = idx < nc * c2 ? dwh + idx : (idx < nc * c2 + nc ? dbh + (idx - nc * c2)
+                                                                : db1 + (idx - nc * c2 - nc));
+  unsafeAtomicAdd(dst, s);
+}
+
+// dense in (z, y, x): a position is one flat index
+bool flat_sp(const e2_tensor5* t) {
+  return t->sh == t->w && t->sd == (int64_t)t->h * t->w;
+}
+bool same_sp(const e2_tensor5* a, const e2_tensor5* b) {
+  return a->n == b->n && a->d == b->d && a->h == b->h && a->w == b->w;
+}
+
+int tail_wm(long N, long S) {
+  if (N * ((S + 63) / 64) >= 128) return 1;
+  if (N * ((S + 31) / 32) >= 128) return 2;
+  return 4;
+}
+long tail_grid(long N, long S, int wm) {
+  const int np = 16 * (4 / wm);
+  return N * ((S + np - 1) / np);
+}
+
+template <int WM, int NC>
+int launch_tail(e2_ctx* ctx, const TailP& p, long grid) {
+  constexpr size_t ldsb = tail_lds_bytes<WM, NC>();
+  static_assert(ldsb <= 160 * 1024, "tail kernel: LDS");
+  static bool attr_done = false;
+  if (!attr_done) {
+    E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((tail_kernel<WM, NC>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int e2_tail_supported(int c1, int c2, int ncls) {
+  return ncls >= 2 && ncls <= 4 && c1 >= 1 && c1 <= kRows && c2 >= 1 && c2 <= kRows;
+}
+
+extern "C" size_t e2_tail_workspace_bytes(int n, int c2, int ncls, int d, int h, int w) {
+  const long S = (long)d * h * w;
+  return sizeof(float) * (size_t)tail_grid(n, S, 4) * (size_t)tail_psz(ncls, c2);   // (WM = 4: most slots)
+}
+
+/* forward AND backward of [1x1x1 conv c1 -> c2, bias, relu] -> [classifier head] in one launch
+ * (replaces e2_conv3d_fwd_packed_act + e2_head_fwd + e2_head_bwd + e2_bias_act_bwd_out +
+ * e2_conv3d_dgrad_packed of those two layers).  wp_fwd / wp_dgrad: the 1x1x1 layer's packed
+ * images (e2_conv3d_pack modes 0 / 1).  Writes probs, dpre (gradient of the layer's
+ * pre-activation, dense [n][c2][positions]), dx (optional), stats[1] = #labelled, and one slot
+ * of partial sums per work-group to ws; e2_tail_reduce adds those up. */
+extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp_fwd,
+                               const float* wp_dgrad, const float* bias1, int c2,
+                               const float* w_head, const float* b_head, int ncls,
+                               const e2_tensor5* target, const e2_tensor5* probs,
+                               const e2_tensor5* dpre, const e2_tensor5* dx, float* stats,
+                               void* ws, size_t ws_bytes, int* n_slots) {
+  E2_REQUIRE(ctx && x && wp_fwd && bias1 && w_head && b_head && target && probs && dpre &&
+                 stats && ws && n_slots, "tail: null argument");
+  E2_REQUIRE(!dx || wp_dgrad, "tail: the data gradient needs its packed image");
+  E2_REQUIRE(e2_tail_supported(x->c, c2, ncls), "tail: unsupported c1=%d c2=%d ncls=%d", x->c, c2, ncls);
+  E2_REQUIRE(!ctx->mfma_bf16, "tail: an f32 kernel, not offered in bf16 mode");
+  E2_REQUIRE(flat_sp(x) && flat_sp(target) && flat_sp(probs) && flat_sp(dpre) && (!dx || flat_sp(dx)),
+             "tail: tensors need dense (z, y, x) planes");
+  E2_REQUIRE(same_sp(x, target) && same_sp(x, probs) && same_sp(x, dpre) && (!dx || same_sp(x, dx)) &&
+                 target->c == 1 && probs->c == ncls && dpre->c == c2 && (!dx || dx->c == x->c),
+             "tail: shape mismatch");
+  const long S = (long)x->d * x->h * x->w;
+  E2_REQUIRE(S < (1L << 30) && x->n < 65536, "tail: sample too large");
+  TailP p{};
+  p.x = x->ptr; p.xsN = x->sn; p.xsC = x->sc;
+  p.wpf = wp_fwd; p.wpd = wp_dgrad;
+  e2i_pack_dims(c2, x->c, &p.ciPf, &p.coPf);
+  e2i_pack_dims(x->c, c2, &p.ciPd, &p.coPd);
+  p.b1 = bias1; p.wh = w_head; p.bh = b_head;
+  p.tg = target->ptr; p.tsN = target->sn;
+  p.pr = probs->ptr; p.psN = probs->sn; p.psC = probs->sc;
+  p.dpre = dpre->ptr; p.dsN = dpre->sn; p.dsC = dpre->sc;
+  p.dx = dx ? dx->ptr : nullptr; p.gsN = dx ? dx->sn : 0; p.gsC = dx ? dx->sc : 0;
+  p.part = (float*)ws; p.stats = stats;
+  p.N = x->n; p.C1 = x->c; p.C2 = c2; p.S = (int)S;
+  p.nTarget = (long)x->n * S;
+  const int wm = tail_wm(x->n, S);
+  const long grid = tail_grid(x->n, S, wm);
+  p.tilesPerN = (int)(grid / x->n);
+  E2_REQUIRE(grid < (1L << 31), "tail: grid too large");
+  E2_REQUIRE(ws_bytes >= sizeof(float) * (size_t)grid * tail_psz(ncls, c2), "tail: workspace too small");
+  *n_slots = (int)grid;
+  p.count_here = p.nTarget <= (1L << 16) ? 1 : 0;
+  if (!p.count_here) {
+    if (int rc = e2i_fill_flat(ctx, stats + 1, 1, 0.f)) return rc;
+    const int cg = (int)std::min<long>((p.nTarget + 255) / 256, 1024);
+#define E2_TC(NC_) hipLaunchKernelGGL((tail_count_kernel<NC_>), dim3(cg), dim3(256), 0, ctx->stream, \
+                                      p.tg, p.tsN, p.S, p.nTarget, stats)
+    if (ncls == 2) E2_TC(2); else if (ncls == 3) E2_TC(3); else E2_TC(4);
+#undef E2_TC
+    E2_CHECK_HIP(hipGetLastError());
+  }
+#define E2_TL(WM_)                                                   \
+  if (wm == WM_) {                                                   \
+    if (ncls == 2) return launch_tail<WM_, 2>(ctx, p, grid);         \
+    if (ncls == 3) return launch_tail<WM_, 3>(ctx, p, grid);         \
+    return launch_tail<WM_, 4>(ctx, p, grid);                        \
+  }
+  E2_TL(1) E2_TL(2) E2_TL(4)
+#undef E2_TL
+  return 2;
+}
+
+/* slot sums of e2_tail_fwd_bwd: dw_head[ncls * c2], db_head[ncls], db1[c2] are ADDED to (zero
+ * them first), stats[0] = loss sum, loss_out (optional) = stats[0] / (stats[1] + 1e-5). */
+extern "C" int e2_tail_reduce(e2_ctx* ctx, const void* ws, int n_slots, int c2, int ncls,
+                              float* dw_head, float* db_head, float* db1, float* stats,
+                              float* loss_out) {
+  E2_REQUIRE(ctx && ws && dw_head && db_head && db1 && stats && n_slots > 0, "tail_reduce: bad argument");
+  const int psz = tail_psz(ncls, c2);
+  hipLaunchKernelGGL(tail_reduce_kernel, dim3(e2_cdiv(psz, 256), std::min(n_slots, 16)), dim3(256), 0,
+                     ctx->stream, (const float*)ws, n_slots, ncls, c2, dw_head, db_head, db1, stats,
+                     loss_out);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}

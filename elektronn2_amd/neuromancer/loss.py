@@ -123,13 +123,39 @@ class MultinoulliNLL(Node):
         plan.scratch[self.pred, 'fused_nll'] = True
         plan.scratch[self, 'loss'] = plan.zeros_flat(1)
         head = self.pred._head(plan)
-        if head is not None and plan.training:
+        if head is not None and plan.training and self._tail(plan) is None:
             nb = plan.ctx.head_bwd_ws_bytes(plan.out_shape(head.parent), self.n_class)
             plan.scratch[self, 'head_ws'] = plan.empty_flat(nb // 4 + 16)
         plan.out[self] = None        # the element-wise nll array is never materialised
 
+    def _tail(self, plan):
+        """the (1,1,1) relu Conv in front of the fused head when the pair runs as ONE launch,
+        forward and backward (csrc/tail.hip, Conv._tail), else None"""
+        head = self.pred._head(plan)
+        if head is None:
+            return None
+        c = head.parent
+        f = getattr(c, '_tail', None)
+        t = f(plan) if f is not None else None
+        return c if (t is not None and t[2] is self) else None
+
     def _plan_fwd(self, plan):
         stats = plan.scratch[self.pred, 'stats']
+        tail = self._tail(plan)
+        if tail is not None:
+            # forward AND backward of [1x1x1 conv + relu] -> head -> loss: probabilities,
+            # stats[1] = #labelled, the conv's pre-activation gradient, its parent's output
+            # gradient; the partial sums wait in the workspace for the backward half
+            head = self.pred._head(plan)
+            par = tail.parent
+            plan.join_side()
+            dx = plan.grad[par] if plan.needs_grad(par) else None
+            plan.scratch[self, 'tail_slots'] = plan.ctx.tail_fwd_bwd(
+                plan.out[par], plan.scratch[tail, 'wp_f'], plan.scratch.get((tail, 'wp_d')),
+                plan.param(tail.b), plan.param(head.w).reshape(head.n_f, -1), plan.param(head.b),
+                plan.out[self.target], plan.out[self.pred], plan.scratch[tail, 'dy'], dx, stats,
+                plan.scratch[tail, 'tail_ws'])
+            return
         plan.zero_early(stats)
         head = self.pred._head(plan)
         if head is not None:
@@ -141,6 +167,14 @@ class MultinoulliNLL(Node):
 
     def _plan_bwd(self, plan):
         head = self.pred._head(plan)
+        tail = self._tail(plan)
+        if tail is not None:
+            # (behind the zero fill of the gradient arena: the slots are ADDED into it)
+            plan.ctx.tail_reduce(plan.scratch[tail, 'tail_ws'], plan.scratch[self, 'tail_slots'],
+                                 tail.n_f, head.n_f, plan.pgrad(head.w).reshape(head.n_f, -1),
+                                 plan.pgrad(head.b), plan.pgrad(tail.b),
+                                 plan.scratch[self.pred, 'stats'], plan.scratch[self, 'loss'])
+            return
         if head is not None:
             dst, first = (plan.grad_slot(head.parent) if plan.needs_grad(head.parent)
                           else (None, True))

@@ -353,6 +353,41 @@ class Conv(NeuralLayer):
             plan.scratch[key] = sm
         return plan.scratch[key]
 
+    def _tail(self, plan):
+        """The tail of a net in ONE launch (csrc/tail.hip): this (1,1,1) relu conv feeds
+        nothing but a fused classifier head under a MultinoulliNLL of a TRAINING plan -- both
+        convs have one tap, so forward and backward of the pair (and of the loss) run per
+        position tile out of LDS.  Returns (head conv, softmax, nll) or None."""
+        key = (self, 'tail')
+        if key not in plan.scratch:
+            import os
+            r = None
+            kids = list(self.children.values())
+            par = self.parent
+            if (os.environ.get('E2_FUSE_TAIL', '1') == '1' and plan.training
+                    and type(self) is Conv and not self._bn() and not self.mfp
+                    and tuple(self._k3) == (1, 1, 1) and all(p == 1 for p in self._p3)
+                    and self.activation_func == 'relu' and len(kids) == 1
+                    and type(kids[0]) is Conv and not isinstance(par, (list, tuple))
+                    and not self._fused_first(plan)
+                    and getattr(plan.ctx, 'mfma_dtype', 'f32') == 'f32'
+                    and not any(n is self or n is kids[0] for n in plan.outputs)):
+                head = kids[0]
+                sm = head._fused_head(plan)
+                nll = [c for c in (sm.children.values() if sm is not None else [])
+                       if type(c).__name__ == 'MultinoulliNLL' and any(n is c for n in plan.nodes)]
+                # the parent's output gradient has to come from this node alone (the launch
+                # OVERWRITES it, during the forward half of the step)
+                users = [c for c in par.children.values()
+                         if id(c) in plan._loss_anc or c is plan.loss_node]
+                x = plan.out.get(par)
+                if (sm is not None and len(nll) == 1 and len(users) == 1 and users[0] is self
+                        and x is not None and x.is_contiguous()
+                        and plan.ctx.tail_supported(par.shape['f'], self.n_f, head.n_f)):
+                    r = (head, sm, nll[0])
+            plan.scratch[key] = r
+        return plan.scratch[key]
+
     def _fused_act(self, plan):
         """no pooling and a specialised kernel width: bias + activation go into the
         conv kernel's epilogue, the pre-activation is never stored"""
@@ -397,6 +432,27 @@ class Conv(NeuralLayer):
             if plan.training:
                 nb = plan.ctx.conv1_bwd_ws_bytes(plan.out_shape(self), k)
                 plan.scratch[self, 'ws1'] = plan.empty_flat(nb // 4 + 16)
+            return
+        if self._tail(plan) is not None:
+            # neither the activations nor their gradient are materialised; what the launch
+            # leaves behind is `dy` (the pre-activation's gradient: this layer's weight
+            # gradient reads it, 128 B of slack behind it as for any padded gradient) and the
+            # parent's output gradient
+            head = self._tail(plan)[0]
+            plan.out[self] = None
+            cin = self.parent.shape['f']
+            nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
+            plan.scratch[self, 'wp_f'] = plan.zeros_flat(nb // 4 + 64)
+            plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 0))
+            ysh = (N, self.n_f) + tuple(psp)
+            flat = plan.zeros_flat(int(np.prod(ysh)) + 32)
+            plan.scratch[self, 'dy'] = flat[:int(np.prod(ysh))].view(ysh)
+            plan.scratch[self, 'dy_pad'] = plan.scratch[self, 'dy']
+            if plan.needs_grad(self.parent):
+                plan.scratch[self, 'wp_d'] = plan.zeros_flat(nb // 4 + 64)
+                plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_d'], 1))
+            wsb = plan.ctx.tail_ws_bytes(plan.out_shape(self.parent), self.n_f, head.n_f)
+            plan.scratch[self, 'tail_ws'] = plan.empty_flat(wsb // 4 + 16)
             return
         osp = [psp[i] - k[i] + 1 for i in range(3)]
         if not self._fused_act(plan):
@@ -453,6 +509,8 @@ class Conv(NeuralLayer):
             ctx.conv1_pool_act_fwd(x, self._w5(plan.param(self.w)), plan.param(self.b), self._p3,
                                    self.activation_func, plan.out[self])
             return
+        if self._tail(plan) is not None:
+            return                            # done by the NLL node (csrc/tail.hip)
         wp = plan.scratch[self, 'wp_f']       # packed by the plan's multi-pack launch
         plan.join_side()                      # ... which runs on the side stream
         cin = self.parent.shape['f']
@@ -540,7 +598,13 @@ class Conv(NeuralLayer):
                                    plan.pgrad(self.b), ws=plan.scratch[self, 'ws1'])
             return
         dy = plan.scratch[self, 'dy']
-        if self._bn():
+        tail = self._tail(plan) is not None
+        if tail:
+            # the tail launch wrote dy, the parent's output gradient (first and only writer)
+            # and the slots the NLL node's reduction has added into the bias gradient
+            if plan.needs_grad(self.parent):
+                plan.grad_slot(self.parent)
+        elif self._bn():
             train = self.batch_normalisation == 'train'
             pooled = any(p != 1 for p in self._p3)
             lin = plan.scratch[self, 'lin'] if pooled else plan.scratch[self, 'y']
@@ -594,7 +658,7 @@ class Conv(NeuralLayer):
             'wgrad', sigw,
             autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]) + wcands,
             lambda: wgrad(True), fn_tune=lambda: wgrad(False)))
-        if plan.needs_grad(self.parent):
+        if plan.needs_grad(self.parent) and not tail:
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']
             par = self.parent

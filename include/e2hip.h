@@ -325,6 +325,33 @@ int e2_head_bwd(e2_ctx*, const e2_tensor5* x, const float* w, const e2_tensor5* 
                 int accumulate_dx, float* dw, float* dbias, float* loss_out, void* ws,
                 size_t ws_bytes);
 
+/* ---- the TAIL of the neuro3d nets, forward AND backward in one launch (csrc/tail.hip):
+ *      x -> [1x1x1 conv to c2 channels + bias + relu] -> [classifier head as above], i.e. the
+ *      last two Conv nodes of examples/neuro3d.py:61-63 / neuro3d_lite.py:57-59 under
+ *      Softmax + MultinoulliNLL, and T.grad of that chain (model.py:182).  Replaces
+ *      e2_conv3d_fwd_packed_act + e2_head_fwd + e2_head_bwd + e2_bias_act_bwd_out +
+ *      e2_conv3d_dgrad_packed of the two layers: both convs have ONE tap, so a work-group runs
+ *      the whole chain for its tile of positions out of LDS.
+ *      x: (n, c1, d, h, w) with dense (z, y, x) planes, c1, c2 <= 208; wp_fwd / wp_dgrad: the
+ *      1x1x1 layer's packed images (e2_conv3d_pack modes 0 / 1; wp_dgrad only with dx);
+ *      w_head: dense (ncls, c2), ncls <= 4; target (n, 1, d, h, w) float class ids (< 0:
+ *      unlabelled).  Writes probs (n, ncls, ...), dpre = d loss / d (pre-activation of the
+ *      1x1x1 layer) (n, c2, ...) -- the operand of that layer's weight gradient --, dx
+ *      (optional) = d loss / d x, stats[1] = #labelled, and one slot of partial sums per
+ *      work-group to ws (e2_tail_workspace_bytes; *n_slots slots).
+ *      e2_tail_reduce ADDS the slots into dw_head (ncls * c2), db_head (ncls), db1 (c2) --
+ *      zero those first -- and writes stats[0] = sum of -log(p_t + 1e-5) and loss_out =
+ *      stats[0] / (stats[1] + 1e-5).  f32 mode only. ------------------------------------ */
+int e2_tail_supported(int c1, int c2, int ncls);
+size_t e2_tail_workspace_bytes(int n, int c2, int ncls, int d, int h, int w);
+int e2_tail_fwd_bwd(e2_ctx*, const e2_tensor5* x, const float* wp_fwd, const float* wp_dgrad,
+                    const float* bias1, int c2, const float* w_head, const float* b_head,
+                    int ncls, const e2_tensor5* target, const e2_tensor5* probs,
+                    const e2_tensor5* dpre, const e2_tensor5* dx, float* stats, void* ws,
+                    size_t ws_bytes, int* n_slots);
+int e2_tail_reduce(e2_ctx*, const void* ws, int n_slots, int c2, int ncls, float* dw_head,
+                   float* db_head, float* db1, float* stats, float* loss_out);
+
 /* probs = softmax_c(logits); loss_sum += sum_pos -log(p[target]+1e-5);
  * n_lab += #labelled (target in [0,C)).  stats = {loss_sum, n_lab} must be
  * zeroed by the caller.  target: (n,1,d,h,w) float class ids. */

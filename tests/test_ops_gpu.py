@@ -931,6 +931,73 @@ def test_fused_classifier_head(ctx, ncls, cin):
     assert relerr(dx2, dx_ref) < TOL
 
 
+@pytest.mark.parametrize("c1,c2,ncls,N,sp", [
+    (200, 200, 2, 1, (10, 37, 37)),        # neuro3d_lite@183's tail: 214 tiles of 64 positions
+    (200, 200, 2, 1, (5, 21, 21)),         # neuro3d@185's: 2,205 positions -> rows split 4 ways
+    (150, 200, 2, 1, (4, 30, 31)),         # 3,720 positions -> tiles of 32, rows split 2 ways
+    (37, 53, 3, 2, (3, 7, 13)),            # odd channel counts, batch, partial tiles
+    (208, 208, 4, 1, (2, 9, 11)),          # the largest channel counts, 4 classes
+    (200, 24, 2, 3, (1, 5, 7)),            # few positions
+])
+def test_fused_tail(ctx, c1, c2, ncls, N, sp):
+    """csrc/tail.hip: [1x1x1 conv + bias + relu] -> [1x1x1 'lin' conv -> softmax ->
+    MultinoulliNLL], forward and backward in ONE launch + its slot reduction: probabilities,
+    loss, the head's dW / dbias, the 1x1x1 layer's pre-activation gradient (its weight gradient's
+    operand) and bias gradient, and the data gradient, against the float64 oracle; unlabelled
+    voxels, relu units at exactly zero (slope 0.5), all three wave layouts."""
+    rng = np.random.RandomState(c1 + c2 + ncls)
+    k = (1, 1, 1)
+    x = rng.rand(N, c1, *sp).astype(np.float32)
+    w1 = (rng.randn(c2, c1, *k) / np.sqrt(c1)).astype(np.float32)
+    b1 = (rng.randn(c2) / 4).astype(np.float32)
+    # a unit whose pre-activation is EXACTLY zero at every position: weights 0, bias 0
+    w1[3] = 0.0; b1[3] = 0.0
+    wh = (rng.randn(ncls, c2, *k) / np.sqrt(c2)).astype(np.float32)
+    bh = (rng.randn(ncls) / 4).astype(np.float32)
+    t = rng.randint(-1, ncls, (N, 1) + sp).astype(np.float32)
+    pre = O.conv3d_fwd(x, w1)
+    h = O.bias_act_fwd(pre, b1, 'relu')
+    logits = O.conv3d_fwd(h, wh) + bh.reshape(1, -1, 1, 1, 1)
+    loss_ref, dlog, p_ref = O.nll_loss_and_grad(logits, t)
+    dwh_ref = O.conv3d_wgrad(dlog, h, wh.shape)
+    dbh_ref = dlog.sum(axis=(0, 2, 3, 4))
+    dh = O.conv3d_dgrad(dlog, wh, h.shape)
+    dpre_ref, db1_ref = O.bias_act_bwd(dh, pre, b1, 'relu')
+    dx_ref = O.conv3d_dgrad(dpre_ref, w1, x.shape)
+    assert ctx.tail_supported(c1, c2, ncls)
+    wpf = torch.zeros(ctx.conv_ws_bytes(c2, c1, k) // 4 + 64, device="cuda")
+    wpd = torch.zeros_like(wpf)
+    ctx.conv3d_pack(dev(w1), 0, wpf)
+    ctx.conv3d_pack(dev(w1), 1, wpd)
+    probs = torch.full((N, ncls) + sp, float("nan"), device="cuda")
+    dpre = torch.full((N, c2) + sp, float("nan"), device="cuda")
+    dx = torch.full((N, c1) + sp, float("nan"), device="cuda")
+    stats = torch.full((2,), float("nan"), device="cuda")
+    ws = torch.full((ctx.tail_ws_bytes(x.shape, c2, ncls) // 4 + 16,), float("nan"), device="cuda")
+    whd = dev(wh.reshape(ncls, c2))
+    ns = ctx.tail_fwd_bwd(dev(x), wpf, wpd, dev(b1), whd, dev(bh), dev(t), probs, dpre, dx,
+                          stats, ws)
+    dwh = torch.full((ncls, c2), 1.0, device="cuda")
+    dbh = torch.full((ncls,), 2.0, device="cuda")
+    db1 = torch.full((c2,), 3.0, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    ctx.tail_reduce(ws, ns, c2, ncls, dwh, dbh, db1, stats, loss)
+    assert relerr(probs, p_ref) < TOL
+    assert abs(float(stats[1]) - (t >= 0).sum()) < 0.5
+    assert abs(float(loss) - loss_ref) / loss_ref < 1e-5
+    assert relerr(dpre, dpre_ref) < TOL
+    assert relerr(dx, dx_ref) < TOL
+    assert relerr(dwh - 1.0, dwh_ref.reshape(ncls, c2)) < 1e-4       # ADDED to what was there
+    assert relerr(dbh - 2.0, dbh_ref) < 1e-4
+    assert relerr(db1 - 3.0, db1_ref) < 1e-4
+    assert np.abs(dpre_ref[:, 3]).max() > 0                          # the slope-0.5 unit is live
+    # no data gradient wanted (the 1x1x1 layer directly on an input): dx = None
+    dpre2 = torch.full_like(dpre, float("nan"))
+    ns2 = ctx.tail_fwd_bwd(dev(x), wpf, None, dev(b1), whd, dev(bh), dev(t), probs, dpre2, None,
+                           stats, ws)
+    assert ns2 == ns and torch.equal(dpre2, dpre)
+
+
 def test_pack_multi_equals_single_pack(ctx):
     """e2_conv3d_pack_multi rewrites only the weight-carrying part of the (zero-filled)
     images; the result must equal e2_conv3d_pack's full image, in both modes, also after a
