@@ -62,7 +62,7 @@ struct TailP {
   float* pr; long psN, psC;          // probabilities [N][ncls][S]
   float* dpre; long dsN, dsC;        // gradient of the 1x1x1 layer's pre-activation [N][C2][S]
   float* dx; long gsN, gsC;          // gradient of x [N][C1][S], or nullptr
-  float* part;                       // [work-groups][PSZ] partial sums
+  float* part;                       // [PSZ][work-groups] partial sums (an element's slots contiguous)
   float* stats;                      // [0] loss sum (written by the reduce kernel), [1] #labelled
   int N, C1, C2, S;
   int tilesPerN;
@@ -86,7 +86,8 @@ struct Geo {
 template <int WM, int NC>
 constexpr size_t tail_lds_bytes() {
   using G = Geo<WM>;
-  return sizeof(float) * (size_t)(G::TILE_F + 2 * G::WB_F + G::NQ * NC * G::NP + NC * G::NP + 16);
+  return sizeof(float) * (size_t)(G::TILE_F + 2 * G::WB_F + G::NQ * NC * G::NP + NC * G::NP + 16 +
+                                  (NC + 1) * kRows);
 }
 
 __host__ __device__ inline int tail_psz(int nc, int c2) { return nc * c2 + nc + c2 + 1; }
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   float* WB = lds + G::TILE_F;                      // 2 x [kKC][BMS] weight chunks
   float* PL = WB + 2 * G::WB_F;                     // [NQ][NC][NP] partial logits
   float* DL = PL + NQ * NC * NP;                    // [NC][NP] dlogits
-  float* RED = DL + NC * NP;                        // scalars
+  float* RED = DL + NC * NP;                        // scalars (16)
+  float* WH = RED + 16;                             // [NC][kRows] head weights, then b1 [kRows]
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wn = wave / WM;
@@ -134,10 +136,31 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
   float cnt = 0.f;
   if (p.count_here) {
+    // (the first cut read one float per iteration: 54 dependent round trips to L2 = ~35 us of
+    // the kernel on neuro3d_lite's 13,690 targets)
     for (int n2 = 0; n2 < p.N; ++n2) {
       const float* tp = p.tg + (long)n2 * p.tsN;
-      for (int i = tid; i < p.S; i += 256) {
-        const float tv = tp[i];
+      const int head = min(p.S, (int)((4 - (((uintptr_t)tp >> 2) & 3)) & 3));   // floats up to 16-B alignment
+      const int nv = (p.S - head) >> 2;
+      const f32x4* tv4 = reinterpret_cast<const f32x4*>(tp + head);
+      for (int i0 = 0; i0 < nv; i0 += 256 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * 256 + tid;
+          v[u] = i < nv ? tv4[i] : f32x4{-1.f, -1.f, -1.f, -1.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) cnt += (v[u][e] == (float)c) ? 1.f : 0.f;
+      }
+      // the unaligned head and the tail of < 4 floats
+      const int rest = p.S - head - 4 * nv;
+      if (tid < head + rest) {
+        const float tv = tid < head ? tp[tid] : tp[head + 4 * nv + (tid - head)];
 #pragma unroll
         for (int c = 0; c < NC; ++c) cnt += (tv == (float)c) ? 1.f : 0.f;
       }
@@ -147,16 +170,45 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     if (lane == 0) RED[wave] = cnt;
   }
 
-  // ---- the x tile -> LDS: rows of NP positions, zero past the sample and past C1 ------------
+  // ---- the x tile -> LDS: rows of NP positions, zero past the sample and past C1; every load
+  // of the tile is in flight at once ------------------------------------------------------------
   {
     const float* xb = p.x + (long)n * p.xsN + s0 + pp;
     const bool pv = pp < np;
-#pragma unroll 10
-    for (int r = pq; r < kRows; r += NQ) T[r * NPP + pp] = (pv && r < p.C1) ? xb[(long)r * p.xsC] : 0.f;
+    constexpr int NR = kRows / NQ;
+    float xv[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int r = pq + j * NQ;
+      xv[j] = (pv && r < p.C1) ? xb[(long)r * p.xsC] : 0.f;
+    }
+    if (tid < kRows) {                          // head weights and the layer's bias, once
+#pragma unroll
+      for (int c = 0; c < NC; ++c) WH[c * kRows + tid] = tid < p.C2 ? p.wh[c * p.C2 + tid] : 0.f;
+      WH[NC * kRows + tid] = tid < p.C2 ? p.b1[tid] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) T[(pq + j * NQ) * NPP + pp] = xv[j];
   }
 
   // ---- one GEMM phase: acc[i] (+)= sum_k img[k][m] * T[k][position] --------------------------
   f32x4 acc[MTW];
+  auto lds_a = [](const float* q) { return (unsigned)(uintptr_t)(lds_vp)q; };
+  // step s of a chunk: A[i] = chunk[4 s + kq][16 (wm MTW + i) + l15], B = tile[k0 + 4 s + kq][position]
+  auto rd = [&](unsigned wb, unsigned tb, int s, float (&A)[MTW], float& B) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+      asm volatile("ds_read_b32 %0, %1" : "=v"(A[i]) : "v"(wb + (unsigned)(s * 4 * BMS * 4 + i * 64)));
+    asm volatile("ds_read_b32 %0, %1" : "=v"(B) : "v"(tb + (unsigned)(s * 4 * NPP * 4)));
+  };
+  auto fma = [&](float (&A)[MTW], float& B) {
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(A[i]));
+    asm volatile("" : "+v"(B));
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], B, acc[i], 0, 0, 0);
+  };
   // chunk c of a phase sits in buffer (buf0 + c) & 1; its first chunk was staged by the caller
   auto gemm = [&](const float* img, int coP, int ciP, int K, int buf0, const float* img_next,
                   int coPn, int ciPn) {
@@ -168,21 +220,35 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
       __syncthreads();                         // chunk c has landed; the other buffer is free
       if (c + 1 < nch) stage(img, coP, ciP, c + 1, (buf0 + c + 1) & 1);
       else if (img_next) stage(img_next, coPn, ciPn, 0, (buf0 + c + 1) & 1);   // the next phase's first chunk
-      const float* wb = WB + ((buf0 + c) & 1) * G::WB_F + (wm * MTW) * 16 + l15;
-      const float* tb = T + (c * kKC) * NPP + wn * 16 + l15;
+      const unsigned wb = lds_a(WB + ((buf0 + c) & 1) * G::WB_F + (wm * MTW) * 16 + kq * BMS + l15);
+      const unsigned tb = lds_a(T + (c * kKC + kq) * NPP + wn * 16 + l15);
       const int nst = min(kKC / 4, (K - c * kKC + 3) >> 2);
+      // operands of step s + 1 are requested before the MFMAs of step s are issued (inline-asm
+      // reads, counted lgkmcnt: hipcc's own schedule waited for every pair of reads -- two
+      // MFMAs per LDS round trip)
+      float A0[MTW], A1[MTW], B0, B1;
+      rd(wb, tb, 0, A0, B0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < kKC / 4; ++s) {
-        if (s < nst) {
-          const float b = tb[(4 * s + kq) * NPP];
-          float a[MTW];
-#pragma unroll
-          for (int i = 0; i < MTW; ++i) a[i] = wb[(4 * s + kq) * BMS + 16 * i];
-#pragma unroll
-          for (int i = 0; i < MTW; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b, acc[i], 0, 0, 0);
-        }
+      for (int s = 0; s < kKC / 4; s += 2) {
+        if (s >= nst) break;
+        rd(wb, tb, s + 1, A1, B1);             // (past nst: a finite value of the buffer, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MTW + 1 < 15 ? MTW + 1 : 15) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        fma(A0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 >= nst) break;
+        if (s + 2 < kKC / 4) rd(wb, tb, s + 2, A0, B0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < kKC / 4) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MTW + 1 < 15 ? MTW + 1 : 15) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        fma(A1, B1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the read-ahead of a skipped step)
+      __builtin_amdgcn_sched_barrier(0);
     }
     return nch;
   };
@@ -200,7 +266,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
         const int row = r0 + r;
         float v = 0.f;
         if (row < p.C2) {
-          const float t = acc[i][r] + p.b1[row];
+          const float t = acc[i][r] + WH[NC * kRows + row];
           v = (t > 0.f) ? t : ((t == 0.f) ? 0.f : -0.f);
         }
         T[row * NPP + wn * 16 + l15] = v;
@@ -219,7 +285,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     for (int co = c0; co < c1; ++co) {
       const float hv = fmaxf(T[co * NPP + pp], 0.f);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) lg[c] = fmaf(p.wh[c * p.C2 + co], hv, lg[c]);
+      for (int c = 0; c < NC; ++c) lg[c] = fmaf(WH[c * kRows + co], hv, lg[c]);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) PL[(pq * NC + c) * NP + pp] = lg[c];
@@ -268,17 +334,18 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
       for (int c = 0; c < NC; ++c) DL[c * NP + tid] = d[c];
     }
     // this work-group's loss sum and head-bias gradient (lanes >= np hold zeros)
-    float* mine = p.part + (long)blockIdx.x * tail_psz(NC, p.C2);
+    float* mine = p.part + blockIdx.x;             // element e of this slot: mine[e * gridDim.x]
+    const long nS = gridDim.x;
     float v = lsum;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (lane == 0) mine[NC * p.C2 + NC + p.C2] = v;
+    if (lane == 0) mine[(NC * p.C2 + NC + p.C2) * nS] = v;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       float sb = d[c];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) sb += __shfl_xor(sb, o, 64);
-      if (lane == 0) mine[NC * p.C2 + c] = sb;
+      if (lane == 0) mine[(NC * p.C2 + c) * nS] = sb;
     }
   }
   __syncthreads();
@@ -288,7 +355,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     const int row = tid;
     float w[NC], aw[NC], db = 0.f;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { w[c] = p.wh[c * p.C2 + row]; aw[c] = 0.f; }
+    for (int c = 0; c < NC; ++c) { w[c] = WH[c * kRows + row]; aw[c] = 0.f; }
     float* tr = T + row * NPP;
 #pragma unroll 8
     for (int q = 0; q < NP; ++q) {
@@ -304,10 +371,11 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) aw[c] = fmaf(DL[c * NP + q], hp, aw[c]);
     }
-    float* mine = p.part + (long)blockIdx.x * tail_psz(NC, p.C2);
+    float* mine = p.part + blockIdx.x;
+    const long nS = gridDim.x;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) mine[c * p.C2 + row] = aw[c];
-    mine[NC * p.C2 + NC + row] = db;
+    for (int c = 0; c < NC; ++c) mine[(c * p.C2 + row) * nS] = aw[c];
+    mine[(NC * p.C2 + NC + row) * nS] = db;
   }
   __syncthreads();
   // the dpre tile to memory (the 1x1x1 layer's weight gradient reads it), rows of NP positions
@@ -352,30 +420,30 @@ __global__ __launch_bounds__(256) void tail_count_kernel(const float* tg, long t
   if ((threadIdx.x & 63) == 0 && cnt != 0.f) unsafeAtomicAdd(stats + 1, cnt);
 }
 
-// slot sums -> dwh / dbh / db1 (ADDED: the gradient arena was zeroed), stats[0] and the loss
+// slot sums -> dwh / dbh / db1 (ADDED: the gradient arena was zeroed), stats[0] and the loss.
+// One wave per element: its slots are contiguous, the sum has ONE writer (no atomics, a fixed
+// summation order).  (The first cut walked the slots with one thread per element: 214
+// dependent-latency loads for the loss alone, 46 us.)
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int nWG,
                                                           int nc, int c2, float* dwh, float* dbh,
                                                           float* db1, float* stats, float* loss_out) {
   const int psz = tail_psz(nc, c2);
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= psz) return;
-  if (idx == psz - 1) {                        // the loss sum: one thread, all slots, plain store
-    if (blockIdx.y != 0) return;
-    float s = 0.f;
-    for (int b = 0; b < nWG; ++b) s += part[(long)b * psz + idx];
+  const float* row = part + (long)idx * nWG;
+  float s = 0.f;
+  for (int b = lane; b < nWG; b += 64) s += row[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane != 0) return;
+  if (idx == psz - 1) {
     stats[0] = s;
     if (loss_out) loss_out[0] = s / (stats[1] + E2_EPS_NLL);
     return;
   }
-  const int per = (nWG + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(b0 + per, nWG);
-  float s = 0.f;
-#pragma unroll 8
-  for (int b = b0; b < b1; ++b) s += part[(long)b * psz + idx];
-  if (s == 0.f) return;
   float* dst = idx < nc * c2 ? dwh + idx : (idx < nc * c2 + nc ? dbh + (idx - nc * c2)
                                                                 : db1 + (idx - nc * c2 - nc));
-  unsafeAtomicAdd(dst, s);
+  *dst += s;
 }
 
 // dense in (z, y, x): a position is one flat index
@@ -493,7 +561,7 @@ extern "C" int e2_tail_reduce(e2_ctx* ctx, const void* ws, int n_slots, int c2, 
                               float* loss_out) {
   E2_REQUIRE(ctx && ws && dw_head && db_head && db1 && stats && n_slots > 0, "tail_reduce: bad argument");
   const int psz = tail_psz(ncls, c2);
-  hipLaunchKernelGGL(tail_reduce_kernel, dim3(e2_cdiv(psz, 256), std::min(n_slots, 16)), dim3(256), 0,
+  hipLaunchKernelGGL(tail_reduce_kernel, dim3(e2_cdiv(psz, 4)), dim3(256), 0,
                      ctx->stream, (const float*)ws, n_slots, ncls, c2, dw_head, db_head, db1, stats,
                      loss_out);
   E2_CHECK_HIP(hipGetLastError());
