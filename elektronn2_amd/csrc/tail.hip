@@ -39,6 +39,7 @@
 //   loss: it is launched from the BACKWARD half of the plan, behind the arena's zero fill.
 #include "common.hpp"
 #include <algorithm>
+#include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -68,7 +69,14 @@ struct TailP {
   int tilesPerN;
   long nTarget;                      // N * S
   int count_here;                    // 1: count the labelled voxels in this kernel
+  unsigned long long* stamps;        // debug build (E2_TAIL_STAMPS): 12 s_memtime stamps per work-group
 };
+
+#ifdef E2_DEBUG_ENV
+#define TAIL_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[12L * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TAIL_STAMP(i) do {} while (0)
+#endif
 
 template <int WM>
 struct Geo {
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
         __builtin_amdgcn_global_load_lds((gbl_vp)(wc + (long)wrow[it] * coP + wcol[it]),
                                          (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
   };
+  TAIL_STAMP(0);
   stage(p.wpf, p.coPf, p.ciPf, 0, 0);
 
   // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
@@ -170,6 +179,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     if (lane == 0) RED[wave] = cnt;
   }
 
+  TAIL_STAMP(1);
   // ---- the x tile -> LDS: rows of NP positions, zero past the sample and past C1; every load
   // of the tile is in flight at once ------------------------------------------------------------
   {
@@ -253,8 +263,10 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     return nch;
   };
 
+  TAIL_STAMP(2);
   // ======== phase A: pre = Wf^T x ================================================================
   const int nchA = gemm(p.wpf, p.coPf, p.ciPf, p.C1, 0, p.dx ? p.wpd : nullptr, p.coPd, p.ciPd);
+  TAIL_STAMP(3);
   __syncthreads();                             // every wave is done with the x tile
   // h = relu(pre + b1) over the tile; rows past C2 are the zero k-rows of phase C
 #pragma unroll
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   }
   __syncthreads();
 
+  TAIL_STAMP(4);
   // ======== head: logits, softmax, loss, dlogits ================================================
   {
     const int per = (p.C2 + NQ - 1) / NQ;
@@ -291,6 +304,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     for (int c = 0; c < NC; ++c) PL[(pq * NC + c) * NP + pp] = lg[c];
   }
   __syncthreads();
+  TAIL_STAMP(5);
   float inv;
   {
     float tot = p.count_here ? ((RED[0] + RED[1]) + (RED[2] + RED[3])) : p.stats[1];
@@ -350,6 +364,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   }
   __syncthreads();
 
+  TAIL_STAMP(6);
   // ======== dpre = (Wh^T dlogits) * relu'(h), thread = channel row ============================
   if (tid < p.C2) {
     const int row = tid;
@@ -378,6 +393,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     mine[(NC * p.C2 + NC + row) * nS] = db;
   }
   __syncthreads();
+  TAIL_STAMP(7);
   // the dpre tile to memory (the 1x1x1 layer's weight gradient reads it), rows of NP positions
   if (pp < np) {
     float* db_ = p.dpre + (long)n * p.dsN + s0 + pp;
@@ -386,8 +402,10 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   }
   if (!p.dx) return;                           // (uniform: nothing upstream needs a gradient)
 
+  TAIL_STAMP(8);
   // ======== phase C: dx = Wd^T dpre =============================================================
   gemm(p.wpd, p.coPd, p.ciPd, p.C2, nchA & 1, nullptr, 0, 0);
+  TAIL_STAMP(9);
   __syncthreads();                             // every wave is done with the dpre tile
 #pragma unroll
   for (int i = 0; i < MTW; ++i) {
@@ -403,6 +421,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
 #pragma unroll 10
     for (int r = pq; r < p.C1; r += NQ) gb[(long)r * p.gsC] = T[r * NPP + pp];
   }
+  TAIL_STAMP(10);
 }
 
 // the labelled voxels of a LARGE target, once (the tail kernel counts small ones itself)
@@ -465,7 +484,7 @@ long tail_grid(long N, long S, int wm) {
 }
 
 template <int WM, int NC>
-int launch_tail(e2_ctx* ctx, const TailP& p, long grid) {
+int launch_tail(e2_ctx* ctx, TailP p, long grid) {
   constexpr size_t ldsb = tail_lds_bytes<WM, NC>();
   static_assert(ldsb <= 160 * 1024, "tail kernel: LDS");
   static bool attr_done = false;
@@ -474,8 +493,34 @@ int launch_tail(e2_ctx* ctx, const TailP& p, long grid) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
+#ifdef E2_DEBUG_ENV
+  // in-kernel timeline (debug build): mean cycles between the stamps over the work-groups
+  const bool stamps = e2_dbg_env("E2_TAIL_STAMPS") != nullptr && !ctx->capturing;
+  if (stamps) {
+    E2_CHECK_HIP(hipMalloc(&p.stamps, sizeof(unsigned long long) * 12 * grid));
+    E2_CHECK_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 12 * grid, ctx->stream));
+  }
+#endif
   hipLaunchKernelGGL((tail_kernel<WM, NC>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
+#ifdef E2_DEBUG_ENV
+  if (stamps) {
+    E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h(12 * grid);
+    E2_CHECK_HIP(hipMemcpy(h.data(), p.stamps, sizeof(unsigned long long) * 12 * grid, hipMemcpyDeviceToHost));
+    static const char* names[10] = {"count", "x tile", "phase A", "(barrier)", "h epilogue", "logits", "softmax/loss",
+                                    "dpre", "dpre store", "phase C"};
+    double sum[11] = {0};
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (long b = 0; b < grid; ++b) {
+      for (int i = 0; i < 10; ++i) sum[i] += (double)(h[12 * b + i + 1] - h[12 * b + i]);
+      t0 = std::min(t0, h[12 * b]); t1 = std::max(t1, h[12 * b + 10]);
+    }
+    fprintf(stderr, "[e2] tail<%d,%d> grid %ld: first start -> last end %llu shader cycles\n", WM, NC, grid, t1 - t0);
+    for (int i = 0; i < 10; ++i) fprintf(stderr, "   %-14s %9.0f cycles\n", i == 9 ? "phase C + dx" : names[i], sum[i] / grid);
+    (void)hipFree(p.stamps);
+  }
+#endif
   return 0;
 }
 
