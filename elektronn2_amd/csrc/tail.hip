@@ -51,7 +51,6 @@ namespace {
 
 constexpr int kMT = 13;              // 16-row blocks: up to 208 channels on either side
 constexpr int kRows = 16 * kMT;
-constexpr int kKC = 40;              // k-rows per staged weight chunk
 
 struct TailP {
   const float* x; long xsN, xsC;
@@ -78,7 +77,10 @@ struct TailP {
 #define TAIL_STAMP(i) do {} while (0)
 #endif
 
-template <int WM>
+// KC = k-rows per staged weight chunk: 40 (five chunks per 200 channels, one work-group per CU)
+// or 16 (a work-group then fits 80 KB of LDS: TWO per CU, one computes while the other loads,
+// reduces or stores)
+template <int WM, int KC>
 struct Geo {
   static constexpr int WN = 4 / WM, NP = 16 * WN;
   // row stride of the tile: odd (thread-per-row passes) and 17 mod 32 (the four k-rows of an
@@ -89,20 +91,21 @@ struct Geo {
   static constexpr int BMS = (BM % 32 == 16) ? BM : BM + 16;   // k-rows 16 banks apart
   static constexpr int NQ = 256 / NP;                          // channel shares of a position
   static constexpr int TILE_F = ((kRows * NPP + 3) / 4) * 4;
-  static constexpr int WB_F = kKC * BMS;
+  static constexpr int WB_F = KC * BMS;
 };
-template <int WM, int NC>
+template <int WM, int NC, int KC>
 constexpr size_t tail_lds_bytes() {
-  using G = Geo<WM>;
+  using G = Geo<WM, KC>;
   return sizeof(float) * (size_t)(G::TILE_F + 2 * G::WB_F + G::NQ * NC * G::NP + NC * G::NP + 16 +
                                   (NC + 1) * kRows);
 }
 
 __host__ __device__ inline int tail_psz(int nc, int c2) { return nc * c2 + nc + c2 + 1; }
 
-template <int WM, int NC>
+template <int WM, int NC, int KC>
 __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
-  using G = Geo<WM>;
+  using G = Geo<WM, KC>;
+  constexpr int kKC = KC;
   constexpr int WN = G::WN, NP = G::NP, NPP = G::NPP, MTW = G::MTW, BM = G::BM, BMS = G::BMS,
                 NQ = G::NQ;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -473,23 +476,30 @@ bool same_sp(const e2_tensor5* a, const e2_tensor5* b) {
   return a->n == b->n && a->d == b->d && a->h == b->h && a->w == b->w;
 }
 
-int tail_wm(long N, long S) {
-  if (N * ((S + 63) / 64) >= 128) return 1;
-  if (N * ((S + 31) / 32) >= 128) return 2;
-  return 4;
+// (WM, KC): enough 32-position tiles for two work-groups on every CU -> rows split 2 ways,
+// 16-row chunks (< 80 KB of LDS); few positions (neuro3d: 2,205) -> rows split 4 ways, so that
+// 138 work-groups exist instead of 35
+void tail_cfg(const e2_ctx* ctx, long N, long S, int* wm, int* kc) {
+  const long cus = ctx ? ctx->num_cu : 256;
+  if (N * ((S + 31) / 32) >= cus) { *wm = 2; *kc = 16; }
+  else if (N * ((S + 31) / 32) >= cus / 2) { *wm = 2; *kc = 40; }
+  else { *wm = 4; *kc = 40; }
+#ifdef E2_DEBUG_ENV
+  if (const char* f = e2_dbg_env("E2_TAIL_CFG")) sscanf(f, "%d,%d", wm, kc);
+#endif
 }
 long tail_grid(long N, long S, int wm) {
   const int np = 16 * (4 / wm);
   return N * ((S + np - 1) / np);
 }
 
-template <int WM, int NC>
+template <int WM, int NC, int KC>
 int launch_tail(e2_ctx* ctx, TailP p, long grid) {
-  constexpr size_t ldsb = tail_lds_bytes<WM, NC>();
+  constexpr size_t ldsb = tail_lds_bytes<WM, NC, KC>();
   static_assert(ldsb <= 160 * 1024, "tail kernel: LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC>),
+    E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC, KC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -501,7 +511,7 @@ int launch_tail(e2_ctx* ctx, TailP p, long grid) {
     E2_CHECK_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 12 * grid, ctx->stream));
   }
 #endif
-  hipLaunchKernelGGL((tail_kernel<WM, NC>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
+  hipLaunchKernelGGL((tail_kernel<WM, NC, KC>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
 #ifdef E2_DEBUG_ENV
   if (stamps) {
@@ -516,7 +526,7 @@ int launch_tail(e2_ctx* ctx, TailP p, long grid) {
       for (int i = 0; i < 10; ++i) sum[i] += (double)(h[12 * b + i + 1] - h[12 * b + i]);
       t0 = std::min(t0, h[12 * b]); t1 = std::max(t1, h[12 * b + 10]);
     }
-    fprintf(stderr, "[e2] tail<%d,%d> grid %ld: first start -> last end %llu shader cycles\n", WM, NC, grid, t1 - t0);
+    fprintf(stderr, "[e2] tail<%d,%d,%d> grid %ld, %zu B of LDS: first start -> last end %llu shader cycles\n", WM, NC, KC, grid, ldsb, t1 - t0);
     for (int i = 0; i < 10; ++i) fprintf(stderr, "   %-14s %9.0f cycles\n", i == 9 ? "phase C + dx" : names[i], sum[i] / grid);
     (void)hipFree(p.stamps);
   }
@@ -572,7 +582,8 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   p.part = (float*)ws; p.stats = stats;
   p.N = x->n; p.C1 = x->c; p.C2 = c2; p.S = (int)S;
   p.nTarget = (long)x->n * S;
-  const int wm = tail_wm(x->n, S);
+  int wm = 1, kc = 40;
+  tail_cfg(ctx, x->n, S, &wm, &kc);
   const long grid = tail_grid(x->n, S, wm);
   p.tilesPerN = (int)(grid / x->n);
   E2_REQUIRE(grid < (1L << 31), "tail: grid too large");
@@ -588,14 +599,15 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
 #undef E2_TC
     E2_CHECK_HIP(hipGetLastError());
   }
-#define E2_TL(WM_)                                                   \
-  if (wm == WM_) {                                                   \
-    if (ncls == 2) return launch_tail<WM_, 2>(ctx, p, grid);         \
-    if (ncls == 3) return launch_tail<WM_, 3>(ctx, p, grid);         \
-    return launch_tail<WM_, 4>(ctx, p, grid);                        \
+#define E2_TL(WM_, KC_)                                              \
+  if (wm == WM_ && kc == KC_) {                                      \
+    if (ncls == 2) return launch_tail<WM_, 2, KC_>(ctx, p, grid);    \
+    if (ncls == 3) return launch_tail<WM_, 3, KC_>(ctx, p, grid);    \
+    return launch_tail<WM_, 4, KC_>(ctx, p, grid);                   \
   }
-  E2_TL(1) E2_TL(2) E2_TL(4)
+  E2_TL(1, 40) E2_TL(2, 40) E2_TL(4, 40) E2_TL(1, 16) E2_TL(2, 16) E2_TL(4, 16)
 #undef E2_TL
+  e2_set_error("tail: no instance WM=%d KC=%d", wm, kc);
   return 2;
 }
 
