@@ -64,12 +64,20 @@ struct TailP {
   float* dx; long gsN, gsC;          // gradient of x [N][C1][S], or nullptr
   float* part;                       // [PSZ][work-groups] partial sums (an element's slots contiguous)
   float* stats;                      // [0] loss sum (written by the reduce kernel), [1] #labelled
+  const float* zeros;                // >= 1 KiB of zeros (e2_ctx::zeros)
   int N, C1, C2, S;
   int tilesPerN;
   long nTarget;                      // N * S
   int count_here;                    // 1: count the labelled voxels in this kernel
   unsigned long long* stamps;        // debug build (E2_TAIL_STAMPS): 12 s_memtime stamps per work-group
+  int dbg;                           // debug build (E2_TAIL_DBG), timing only: 1 = no weight DMA after
+                                     // the first chunk, 2 = no MFMAs, 4 = no operand reads
 };
+#ifdef E2_DEBUG_ENV
+#define TAIL_DBG(bit) ((p.dbg & (bit)) != 0)
+#else
+#define TAIL_DBG(bit) false
+#endif
 
 #ifdef E2_DEBUG_ENV
 #define TAIL_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[12L * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -90,7 +98,9 @@ struct Geo {
   static constexpr int BM = 16 * MTW * WM;
   static constexpr int BMS = (BM % 32 == 16) ? BM : BM + 16;   // k-rows 16 banks apart
   static constexpr int NQ = 256 / NP;                          // channel shares of a position
-  static constexpr int TILE_F = ((kRows * NPP + 3) / 4) * 4;
+  // tile rows: the K loops run over whole chunks, the rows past the channels hold zeros
+  static constexpr int TR = ((kRows + KC - 1) / KC) * KC;
+  static constexpr int TILE_F = ((TR * NPP + 3) / 4) * 4;
   static constexpr int WB_F = KC * BMS;
 };
 template <int WM, int NC, int KC>
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   constexpr int WN = G::WN, NP = G::NP, NPP = G::NPP, MTW = G::MTW, BM = G::BM, BMS = G::BMS,
                 NQ = G::NQ;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* T = lds;                                   // [kRows][NPP]: x, then h, then dpre, then dx
+  float* T = lds;                                   // [TR][NPP]: x, then h, then dpre, then dx
   float* WB = lds + G::TILE_F;                      // 2 x [kKC][BMS] weight chunks
   float* PL = WB + 2 * G::WB_F;                     // [NQ][NC][NP] partial logits
   float* DL = PL + NQ * NC * NP;                    // [NC][NP] dlogits
@@ -126,24 +136,33 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   // ---- weight chunks: image rows [c * kKC, + kKC) x columns [0, BM) -> LDS by LDS-DMA --------
   constexpr int PIECES = kKC * BMS / 4;             // 16-byte pieces of a chunk, pad columns too
   constexpr int NI = (PIECES + 255) / 256;
-  int wrow[NI], wcol[NI];
+  // piece pi = it * 256 + tid of a chunk [k][BMS]: image row k, columns 4 (pi % (BMS / 4)) ...
+  // (pad columns re-read the row's last piece); offsets for both images, once
+  int wrow[NI], woffF[NI], woffD[NI], wcol[NI];
 #pragma unroll
   for (int it = 0; it < NI; ++it) {
     const int pi = min(it * 256 + tid, PIECES - 1);
     wrow[it] = (pi * 4) / BMS;
-    wcol[it] = min(pi * 4 - wrow[it] * BMS, BM - 4);          // pad columns re-read the last piece
+    wcol[it] = min(pi * 4 - wrow[it] * BMS, BM - 4);
+    woffF[it] = wrow[it] * p.coPf + wcol[it];
+    woffD[it] = wrow[it] * p.coPd + wcol[it];
   }
-  auto stage = [&](const float* img, int coP, int ciP, int c, int buf) {
+  // rows past the image (K padded to whole chunks) come from the context's zero block: the
+  // K loop has ONE trip count -- no early exit around the hand-scheduled steps (an exit per
+  // step made hipcc keep two sets of accumulators and move all 52 registers at every chunk
+  // boundary: 1.2 k cycles per chunk, stamps of the first cut)
+  auto stage = [&](const float* img, int coP, int ciP, const int (&woff)[NI], int c, int buf) {
     const float* wc = img + (long)c * kKC * coP;
     unsigned char* lb = reinterpret_cast<unsigned char*>(WB + buf * G::WB_F) + (wave * 64) * 16;
 #pragma unroll
     for (int it = 0; it < NI; ++it)
-      if (it * 256 + tid < PIECES && c * kKC + wrow[it] < ciP)   // (rows past the image: never read)
-        __builtin_amdgcn_global_load_lds((gbl_vp)(wc + (long)wrow[it] * coP + wcol[it]),
-                                         (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
+      if (it * 256 + tid < PIECES) {
+        const float* src = (c * kKC + wrow[it] < ciP) ? wc + woff[it] : p.zeros + wcol[it];
+        __builtin_amdgcn_global_load_lds((gbl_vp)src, (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
+      }
   };
   TAIL_STAMP(0);
-  stage(p.wpf, p.coPf, p.ciPf, 0, 0);
+  stage(p.wpf, p.coPf, p.ciPf, woffF, 0, 0);
 
   // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
   float cnt = 0.f;
@@ -188,7 +207,8 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   {
     const float* xb = p.x + (long)n * p.xsN + s0 + pp;
     const bool pv = pp < np;
-    constexpr int NR = kRows / NQ;
+    constexpr int NR = G::TR / NQ;
+    static_assert(G::TR % NQ == 0, "tile rows per thread");
     float xv[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -209,6 +229,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   auto lds_a = [](const float* q) { return (unsigned)(uintptr_t)(lds_vp)q; };
   // step s of a chunk: A[i] = chunk[4 s + kq][16 (wm MTW + i) + l15], B = tile[k0 + 4 s + kq][position]
   auto rd = [&](unsigned wb, unsigned tb, int s, float (&A)[MTW], float& B) {
+    if (TAIL_DBG(4)) return;
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
       asm volatile("ds_read_b32 %0, %1" : "=v"(A[i]) : "v"(wb + (unsigned)(s * 4 * BMS * 4 + i * 64)));
@@ -218,24 +239,26 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(A[i]));
     asm volatile("" : "+v"(B));
+    if (TAIL_DBG(2)) return;
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], B, acc[i], 0, 0, 0);
   };
   // chunk c of a phase sits in buffer (buf0 + c) & 1; its first chunk was staged by the caller
-  auto gemm = [&](const float* img, int coP, int ciP, int K, int buf0, const float* img_next,
-                  int coPn, int ciPn) {
+  auto gemm = [&](const float* img, int coP, int ciP, const int (&woff)[NI], int K, int buf0,
+                  bool next_d) {
 #pragma unroll
     for (int i = 0; i < MTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nch = (K + kKC - 1) / kKC;
     for (int c = 0; c < nch; ++c) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                         // chunk c has landed; the other buffer is free
-      if (c + 1 < nch) stage(img, coP, ciP, c + 1, (buf0 + c + 1) & 1);
-      else if (img_next) stage(img_next, coPn, ciPn, 0, (buf0 + c + 1) & 1);   // the next phase's first chunk
+      if (!TAIL_DBG(1)) {
+      if (c + 1 < nch) stage(img, coP, ciP, woff, c + 1, (buf0 + c + 1) & 1);
+      else if (next_d) stage(p.wpd, p.coPd, p.ciPd, woffD, 0, (buf0 + c + 1) & 1);   // phase C's first chunk
+      }
       const unsigned wb = lds_a(WB + ((buf0 + c) & 1) * G::WB_F + (wm * MTW) * 16 + kq * BMS + l15);
       const unsigned tb = lds_a(T + (c * kKC + kq) * NPP + wn * 16 + l15);
-      const int nst = min(kKC / 4, (K - c * kKC + 3) >> 2);
       // operands of step s + 1 are requested before the MFMAs of step s are issued (inline-asm
       // reads, counted lgkmcnt: hipcc's own schedule waited for every pair of reads -- two
       // MFMAs per LDS round trip)
@@ -244,14 +267,12 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < kKC / 4; s += 2) {
-        if (s >= nst) break;
-        rd(wb, tb, s + 1, A1, B1);             // (past nst: a finite value of the buffer, unused)
+        rd(wb, tb, s + 1, A1, B1);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MTW + 1 < 15 ? MTW + 1 : 15) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         fma(A0, B0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 >= nst) break;
         if (s + 2 < kKC / 4) rd(wb, tb, s + 2, A0, B0);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < kKC / 4) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MTW + 1 < 15 ? MTW + 1 : 15) : "memory");
@@ -260,15 +281,13 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
         fma(A1, B1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the read-ahead of a skipped step)
-      __builtin_amdgcn_sched_barrier(0);
     }
     return nch;
   };
 
   TAIL_STAMP(2);
   // ======== phase A: pre = Wf^T x ================================================================
-  const int nchA = gemm(p.wpf, p.coPf, p.ciPf, p.C1, 0, p.dx ? p.wpd : nullptr, p.coPd, p.ciPd);
+  const int nchA = gemm(p.wpf, p.coPf, p.ciPf, woffF, p.C1, 0, p.dx != nullptr);
   TAIL_STAMP(3);
   __syncthreads();                             // every wave is done with the x tile
   // h = relu(pre + b1) over the tile; rows past C2 are the zero k-rows of phase C
@@ -298,6 +317,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     float lg[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) lg[c] = 0.f;
+#pragma unroll 10
     for (int co = c0; co < c1; ++co) {
       const float hv = fmaxf(T[co * NPP + pp], 0.f);
 #pragma unroll
@@ -407,7 +427,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
 
   TAIL_STAMP(8);
   // ======== phase C: dx = Wd^T dpre =============================================================
-  gemm(p.wpd, p.coPd, p.ciPd, p.C2, nchA & 1, nullptr, 0, 0);
+  gemm(p.wpd, p.coPd, p.ciPd, woffD, p.C2, nchA & 1, false);
   TAIL_STAMP(9);
   __syncthreads();                             // every wave is done with the dpre tile
 #pragma unroll
@@ -497,6 +517,8 @@ template <int WM, int NC, int KC>
 int launch_tail(e2_ctx* ctx, TailP p, long grid) {
   constexpr size_t ldsb = tail_lds_bytes<WM, NC, KC>();
   static_assert(ldsb <= 160 * 1024, "tail kernel: LDS");
+  static_assert((KC / 4) % 2 == 0, "the K loop is unrolled by two steps");
+  static_assert(Geo<WM, KC>::BM * 4 <= 1024, "a weight row must fit the context's zero block");
   static bool attr_done = false;
   if (!attr_done) {
     E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC, KC>),
@@ -579,7 +601,7 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   p.pr = probs->ptr; p.psN = probs->sn; p.psC = probs->sc;
   p.dpre = dpre->ptr; p.dsN = dpre->sn; p.dsC = dpre->sc;
   p.dx = dx ? dx->ptr : nullptr; p.gsN = dx ? dx->sn : 0; p.gsC = dx ? dx->sc : 0;
-  p.part = (float*)ws; p.stats = stats;
+  p.part = (float*)ws; p.stats = stats; p.zeros = ctx->zeros;
   p.N = x->n; p.C1 = x->c; p.C2 = c2; p.S = (int)S;
   p.nTarget = (long)x->n * S;
   int wm = 1, kc = 40;
@@ -590,6 +612,7 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   E2_REQUIRE(ws_bytes >= sizeof(float) * (size_t)grid * tail_psz(ncls, c2), "tail: workspace too small");
   *n_slots = (int)grid;
   p.count_here = p.nTarget <= (1L << 16) ? 1 : 0;
+  p.dbg = e2_dbg_env_int("E2_TAIL_DBG");
   if (!p.count_here) {
     if (int rc = e2i_fill_flat(ctx, stats + 1, 1, 0.f)) return rc;
     const int cg = (int)std::min<long>((p.nTarget + 255) / 256, 1024);
