@@ -64,7 +64,7 @@ struct TailP {
   float* dx; long gsN, gsC;          // gradient of x [N][C1][S], or nullptr
   float* part;                       // [PSZ][work-groups] partial sums (an element's slots contiguous)
   float* stats;                      // [0] loss sum (written by the reduce kernel), [1] #labelled
-  const float* zeros;                // >= 1 KiB of zeros (e2_ctx::zeros)
+  int zero_wb;                       // 1: whole chunks of K reach past a packed image's rows
   int N, C1, C2, S;
   int tilesPerN;
   long nTarget;                      // N * S
@@ -147,21 +147,26 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     woffF[it] = wrow[it] * p.coPf + wcol[it];
     woffD[it] = wrow[it] * p.coPd + wcol[it];
   }
-  // rows past the image (K padded to whole chunks) come from the context's zero block: the
-  // K loop has ONE trip count -- no early exit around the hand-scheduled steps (an exit per
-  // step made hipcc keep two sets of accumulators and move all 52 registers at every chunk
-  // boundary: 1.2 k cycles per chunk, stamps of the first cut)
+  // the K loop has ONE trip count -- whole chunks, no early exit around the hand-scheduled
+  // steps (an exit per step made hipcc keep two sets of accumulators and move all 52
+  // registers at every chunk boundary).  Chunk rows past the image (only where K padded to
+  // whole chunks exceeds ciP) are never staged: both buffers are zeroed once instead.
   auto stage = [&](const float* img, int coP, int ciP, const int (&woff)[NI], int c, int buf) {
     const float* wc = img + (long)c * kKC * coP;
     unsigned char* lb = reinterpret_cast<unsigned char*>(WB + buf * G::WB_F) + (wave * 64) * 16;
 #pragma unroll
     for (int it = 0; it < NI; ++it)
-      if (it * 256 + tid < PIECES) {
-        const float* src = (c * kKC + wrow[it] < ciP) ? wc + woff[it] : p.zeros + wcol[it];
-        __builtin_amdgcn_global_load_lds((gbl_vp)src, (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
-      }
+      // (selecting between the image and a zero block per piece made the DMA -- and every load
+      // queued behind it -- 30 % slower: rows past the image are SKIPPED, their LDS rows are
+      // zeroed once, below)
+      if (it * 256 + tid < PIECES && c * kKC + wrow[it] < ciP)
+        __builtin_amdgcn_global_load_lds((gbl_vp)(wc + woff[it]), (lds_vp)(lb + it * 256 * 16), 16, 0, 0);
   };
   TAIL_STAMP(0);
+  if (p.zero_wb) {
+    for (int i = tid; i < 2 * G::WB_F; i += 256) WB[i] = 0.f;
+    __syncthreads();
+  }
   stage(p.wpf, p.coPf, p.ciPf, woffF, 0, 0);
 
   // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
@@ -295,15 +300,12 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   for (int i = 0; i < MTW; ++i) {
     const int r0 = (wm * MTW + i) * 16 + 4 * kq;
     if (r0 < kRows) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(WH + NC * kRows + r0);   // (0 past C2)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = r0 + r;
-        float v = 0.f;
-        if (row < p.C2) {
-          const float t = acc[i][r] + WH[NC * kRows + row];
-          v = (t > 0.f) ? t : ((t == 0.f) ? 0.f : -0.f);
-        }
-        T[row * NPP + wn * 16 + l15] = v;
+        const float t = acc[i][r] + bv[r];       // rows past C2: zero weights, zero bias -> +0.0
+        T[row * NPP + wn * 16 + l15] = (t > 0.f) ? t : ((t == 0.f) ? 0.f : -0.f);
       }
     }
   }
@@ -518,7 +520,6 @@ int launch_tail(e2_ctx* ctx, TailP p, long grid) {
   constexpr size_t ldsb = tail_lds_bytes<WM, NC, KC>();
   static_assert(ldsb <= 160 * 1024, "tail kernel: LDS");
   static_assert((KC / 4) % 2 == 0, "the K loop is unrolled by two steps");
-  static_assert(Geo<WM, KC>::BM * 4 <= 1024, "a weight row must fit the context's zero block");
   static bool attr_done = false;
   if (!attr_done) {
     E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC, KC>),
@@ -601,7 +602,7 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   p.pr = probs->ptr; p.psN = probs->sn; p.psC = probs->sc;
   p.dpre = dpre->ptr; p.dsN = dpre->sn; p.dsC = dpre->sc;
   p.dx = dx ? dx->ptr : nullptr; p.gsN = dx ? dx->sn : 0; p.gsC = dx ? dx->sc : 0;
-  p.part = (float*)ws; p.stats = stats; p.zeros = ctx->zeros;
+  p.part = (float*)ws; p.stats = stats;
   p.N = x->n; p.C1 = x->c; p.C2 = c2; p.S = (int)S;
   p.nTarget = (long)x->n * S;
   int wm = 1, kc = 40;
@@ -611,6 +612,7 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   E2_REQUIRE(grid < (1L << 31), "tail: grid too large");
   E2_REQUIRE(ws_bytes >= sizeof(float) * (size_t)grid * tail_psz(ncls, c2), "tail: workspace too small");
   *n_slots = (int)grid;
+  p.zero_wb = (e2_cdiv(p.C1, kc) * kc > p.ciPf || e2_cdiv(p.C2, kc) * kc > p.ciPd) ? 1 : 0;
   p.count_here = p.nTarget <= (1L << 16) ? 1 : 0;
   p.dbg = e2_dbg_env_int("E2_TAIL_DBG");
   if (!p.count_here) {
