@@ -88,7 +88,7 @@ def _load():
         "e2_stream_join": (C.c_int, [vp, C.c_void_p]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5]),
-        "e2_conv1_pool_act_fwd_pack": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5, vp, i, i]),
+        "e2_conv1_pool_act_fwd_pack": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5, vp, i]),
         "e2_conv1_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp,
                                             C.c_void_p, C.c_size_t]),
@@ -423,9 +423,7 @@ class Context:
             _chk(_lib.e2_pack_job_fill(C.byref(buf, n * rec), _fp(w), C.c_void_p(wp.data_ptr()),
                                        cout, cin, kd, kh, kw, mode), "e2_pack_job_fill")
         host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
-        dev = host.to(self.device)
-        dev.max_taps = max(int(w.shape[2] * w.shape[3] * w.shape[4]) for w, _, _ in jobs)
-        return dev, len(jobs)
+        return host.to(self.device), len(jobs)
 
     def conv3d_pack_multi(self, jobs_dev, njobs):
         _chk(_lib.e2_conv3d_pack_multi(self.h, C.c_void_p(jobs_dev.data_ptr()), njobs),
@@ -447,8 +445,7 @@ class Context:
         _chk(_lib.e2_conv1_pool_act_fwd_pack(self.h, C.byref(t5(x)), _fp(w), _fp(bias), w.shape[0],
                                              w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
                                              C.byref(t5(out)), C.c_void_p(jobs_dev.data_ptr()),
-                                             njobs, int(getattr(jobs_dev, 'max_taps', 248))),
-             "e2_conv1_pool_act_fwd_pack")
+                                             njobs), "e2_conv1_pool_act_fwd_pack")
 
     @staticmethod
     def conv1_bwd_ws_bytes(dout_shape, k):

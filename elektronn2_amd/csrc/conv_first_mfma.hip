@@ -214,10 +214,8 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
 template <int KH, int KW, int PY, int PX, int MG>
 __global__ __launch_bounds__(256) void firstm_fwd_pack_kernel(FirstM p, const PackJobDev* __restrict__ jobs,
                                                               int njobs, int PB, int nF) {
-  // (dynamic LDS, sized for the largest tap volume among the jobs -- ~9-13 KB: with the
-  // repack's static 32 KB tile only five work-groups fit a CU and the first layer lost a
-  // third of its residency)
-  extern __shared__ __attribute__((aligned(16))) float sh[];
+  __shared__ float sh[kPackTileFloats];
+  static_assert(Geo<KH, KW, PY, PX, MG>::RT * kTW <= kPackTileFloats, "first-layer tile");
   const int g = blockIdx.x >> 3, slot = blockIdx.x & 7;
   if (slot < 3) {
     const int f = 3 * g + slot;
@@ -375,14 +373,12 @@ int launch_fwd(e2_ctx* ctx, const FirstM& p, int grid) {
   return 0;
 }
 template <int KH, int KW, int PY, int PX, int MG>
-int launch_fwd_pack(e2_ctx* ctx, const FirstM& p, int nF, const void* jobs, int njobs, int max_taps) {
+int launch_fwd_pack(e2_ctx* ctx, const FirstM& p, int nF, const void* jobs, int njobs) {
   // repack blocks per job: the largest images have ~1,000 tiles; 128 blocks x 20 jobs = 2,560
   // blocks next to <= 768 first-layer blocks
   const int PB = 128;
   const int groups = std::max(e2_cdiv(nF, 3), e2_cdiv(njobs * PB, 5));
-  // tile[k * 33 + ol], k < ICT * T < 32 + T (pack_core.hpp)
-  const size_t lds = sizeof(float) * std::max<size_t>(33 * (size_t)(32 + max_taps), Geo<KH, KW, PY, PX, MG>::RT * kTW);
-  hipLaunchKernelGGL((firstm_fwd_pack_kernel<KH, KW, PY, PX, MG>), dim3(8 * groups), dim3(256), lds, ctx->stream,
+  hipLaunchKernelGGL((firstm_fwd_pack_kernel<KH, KW, PY, PX, MG>), dim3(8 * groups), dim3(256), 0, ctx->stream,
                      p, (const PackJobDev*)jobs, njobs, PB, nF);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
@@ -447,13 +443,13 @@ int e2i_firstm_fwd(e2_ctx* ctx, int v, const e2_tensor5* x, const float* w, cons
 // the same + the weight repack of all layers (jobs_dev: e2_pack_job_fill records) in one launch
 int e2i_firstm_fwd_pack(e2_ctx* ctx, int v, const e2_tensor5* x, const float* w, const float* bias,
                         int cout, int py, int px, int act, const e2_tensor5* out,
-                        const void* jobs_dev, int njobs, int max_taps) {
+                        const void* jobs_dev, int njobs) {
   const int mg = e2i_firstm_mg(cout);
   FirstM p{};
   fill(p, x, out, cout, py, px);
   p.w = w; p.bias = bias; p.out = out->ptr; p.act = act;
   const int grid = e2i_firstm_grid(ctx, p.nTiles);
-  E2_FM_DISPATCH(launch_fwd_pack, ctx, p, grid, jobs_dev, njobs, max_taps)
+  E2_FM_DISPATCH(launch_fwd_pack, ctx, p, grid, jobs_dev, njobs)
   e2_set_error("conv1(mfma): no instance for variant %d, %d channels", v, cout);
   return 2;
 }

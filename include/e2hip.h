@@ -197,8 +197,7 @@ int e2_conv1_pool_act_fwd(e2_ctx*, const e2_tensor5* x, const float* w,
  * the shared weight variables theano.function reads, graphutils.py:376-387) */
 int e2_conv1_pool_act_fwd_pack(e2_ctx*, const e2_tensor5* x, const float* w, const float* bias,
                                int cout, int kh, int kw, int py, int px, int act,
-                               const e2_tensor5* out, const void* jobs_dev, int njobs,
-                               int max_taps /* largest kd*kh*kw among the jobs */);
+                               const e2_tensor5* out, const void* jobs_dev, int njobs);
 /* workspace of the backward: per-tile partial sums, (n, cout, d, ho, wo) = dims of
  * the POOLED output gradient */
 size_t e2_conv1_bwd_workspace_bytes(int n, int cout, int d, int ho, int wo, int kh, int kw);
