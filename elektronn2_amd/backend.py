@@ -88,7 +88,6 @@ def _load():
         "e2_stream_join": (C.c_int, [vp, C.c_void_p]),
         "e2_conv1_supported": (C.c_int, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_fwd": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5]),
-        "e2_conv1_pool_act_fwd_pack": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5, vp, i]),
         "e2_conv1_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i, i]),
         "e2_conv1_pool_act_bwd": (C.c_int, [vp, P5, fp, fp, P5, i, i, i, i, i, fp, fp,
                                             C.c_void_p, C.c_size_t]),
@@ -438,14 +437,6 @@ class Context:
         _chk(_lib.e2_conv1_pool_act_fwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias), w.shape[0],
                                         w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
                                         C.byref(t5(out))), "e2_conv1_pool_act_fwd")
-
-    def conv1_pool_act_fwd_pack(self, x, w, bias, pool, act, out, jobs_dev, njobs):
-        """the first layer's forward AND the repack of every layer's weight images
-        (conv3d_pack_multi) in one launch"""
-        _chk(_lib.e2_conv1_pool_act_fwd_pack(self.h, C.byref(t5(x)), _fp(w), _fp(bias), w.shape[0],
-                                             w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
-                                             C.byref(t5(out)), C.c_void_p(jobs_dev.data_ptr()),
-                                             njobs), "e2_conv1_pool_act_fwd_pack")
 
     @staticmethod
     def conv1_bwd_ws_bytes(dout_shape, k):

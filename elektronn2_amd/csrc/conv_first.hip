@@ -218,8 +218,6 @@ int e2i_firstm_fwd(e2_ctx*, int v, const e2_tensor5* x, const float* w, const fl
                    int py, int px, int act, const e2_tensor5* out);
 int e2i_firstm_bwd(e2_ctx*, int v, const e2_tensor5* x, const float* w, const float* bias,
                    const e2_tensor5* dout, int py, int px, int act, float* part, int* nslots);
-int e2i_firstm_fwd_pack(e2_ctx*, int v, const e2_tensor5* x, const float* w, const float* bias, int cout,
-                        int py, int px, int act, const e2_tensor5* out, const void* jobs_dev, int njobs);
 
 static int first_supported(int kd, int kh, int kw, int pz, int py, int px) {
   if (kd != 1 || pz != 1) return 0;
@@ -272,23 +270,6 @@ extern "C" int e2_conv1_pool_act_fwd(e2_ctx* ctx, const e2_tensor5* x, const flo
     hipLaunchKernelGGL((first_fwd_kernel<3, 3, 1, 1>), dim3(grid), dim3(256), 0, ctx->stream, p, (int)nTiles);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
-}
-
-/* e2_conv1_pool_act_fwd + e2_conv3d_pack_multi(jobs_dev, njobs): where the first layer runs on
- * the matrix cores the two share ONE launch (conv_first_mfma.hip), else two launches. */
-extern "C" int e2_conv1_pool_act_fwd_pack(e2_ctx* ctx, const e2_tensor5* x, const float* w,
-                                          const float* bias, int cout, int kh, int kw, int py,
-                                          int px, int act, const e2_tensor5* out,
-                                          const void* jobs_dev, int njobs) {
-  E2_REQUIRE(ctx && w && bias && jobs_dev && njobs > 0 && njobs < 65536, "conv1_pool_act_fwd_pack: bad argument");
-  const int v = first_supported(1, kh, kw, 1, py, px);
-  if (v && e2i_firstm_mg(cout) && !e2_dbg_env("E2_FIRST_VALU") && !e2_dbg_env("E2_FIRST_NOPACK")) {
-    First p{};
-    if (int rc = first_fill(p, x, out, cout, kh, kw, py, px, "conv1_pool_act_fwd_pack")) return rc;
-    return e2i_firstm_fwd_pack(ctx, v, x, w, bias, cout, py, px, act, out, jobs_dev, njobs);
-  }
-  if (int rc = e2_conv3d_pack_multi(ctx, jobs_dev, njobs)) return rc;
-  return e2_conv1_pool_act_fwd(ctx, x, w, bias, cout, kh, kw, py, px, act, out);
 }
 
 extern "C" size_t e2_conv1_bwd_workspace_bytes(int n, int cout, int d, int ho, int wo, int kh,

@@ -24,7 +24,7 @@
 //       gradient (Theano's MaxPoolGrad), relu'(0) = 0.5.
 //   Work-groups are persistent over the tiles; a wave keeps its dW / dbias partial sums in
 //   registers and writes them once (workspace + the reduce kernel of conv_first.hip).
-#include "pack_core.hpp"
+#include "common.hpp"
 #include <algorithm>
 #include <utility>
 
@@ -150,10 +150,10 @@ __device__ __forceinline__ void conv_rows(const float* xw, int lane,
   });
 }
 
-// persistent work-group b of nb (xt: RT * kTW floats of LDS)
 template <int KH, int KW, int PY, int PX, int MG>
-__device__ __forceinline__ void firstm_fwd_body(const FirstM& p, float* xt, int b, int nb) {
+__global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
   using G = Geo<KH, KW, PY, PX, MG>;
+  __shared__ float xt[G::RT * kTW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float aw[G::NAV];
   load_weights<KH, KW, PY, PX, MG>(p, lane, aw);
@@ -162,7 +162,7 @@ __device__ __forceinline__ void firstm_fwd_body(const FirstM& p, float* xt, int 
   for (int g = 0; g < MG; ++g)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bs[g][r] = (4 * g + r < p.Cout) ? p.bias[4 * g + r] : 0.f;
-  for (int tile = b; tile < p.nTiles; tile += nb) {
+  for (int tile = blockIdx.x; tile < p.nTiles; tile += gridDim.x) {
     int n, z, row0, col0;
     __syncthreads();                       // the previous tile's reads are done
     load_tile<KH, KW, PY, PX, MG>(p, tile, xt, n, z, row0, col0);
@@ -193,40 +193,6 @@ __device__ __forceinline__ void firstm_fwd_body(const FirstM& p, float* xt, int 
           if (ok && !(FM_DBG(p, 4) && ch > 0)) ob[(long)ch * p.osC] = v;
         }
       }
-  }
-}
-
-template <int KH, int KW, int PY, int PX, int MG>
-__global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
-  __shared__ float xt[Geo<KH, KW, PY, PX, MG>::RT * kTW];
-  firstm_fwd_body<KH, KW, PY, PX, MG>(p, xt, blockIdx.x, gridDim.x);
-}
-
-// The forward pass of the first layer AND the repack of every layer's weight images
-// (e2_conv3d_pack_multi) in ONE launch.  The two are independent -- the first layer reads the
-// raw weights, the images are read from the second layer on -- and neither fills the chip:
-// the first layer is issue-bound with three persistent work-groups per CU (finding 26), the
-// repack waits for memory (1,024-element tiles between two barriers).  As two launches they
-// cost 17 + 19 us (neuro3d_lite) / 37 + 25 us (neuro3d) at the head of every step; as graph
-// BRANCHES the fork / join cost more than the overlap saved (finding 14).  Here the block index
-// picks the role: of every 8 consecutive blocks 3 run first-layer tiles and 5 run repack tiles,
-// so that both kinds are resident on every CU from the start.
-template <int KH, int KW, int PY, int PX, int MG>
-__global__ __launch_bounds__(256) void firstm_fwd_pack_kernel(FirstM p, const PackJobDev* __restrict__ jobs,
-                                                              int njobs, int PB, int nF) {
-  __shared__ float sh[kPackTileFloats];
-  static_assert(Geo<KH, KW, PY, PX, MG>::RT * kTW <= kPackTileFloats, "first-layer tile");
-  const int g = blockIdx.x >> 3, slot = blockIdx.x & 7;
-  if (slot < 3) {
-    const int f = 3 * g + slot;
-    if (f < nF) firstm_fwd_body<KH, KW, PY, PX, MG>(p, sh, f, nF);
-  } else {
-    const int q = 5 * g + (slot - 3);
-    if (q < njobs * PB) {
-      const int job = q / PB;
-      const PackJobDev j = jobs[job];
-      e2_pack_job_tiles(j, sh, q - job * PB, PB);
-    }
   }
 }
 
@@ -373,17 +339,6 @@ int launch_fwd(e2_ctx* ctx, const FirstM& p, int grid) {
   return 0;
 }
 template <int KH, int KW, int PY, int PX, int MG>
-int launch_fwd_pack(e2_ctx* ctx, const FirstM& p, int nF, const void* jobs, int njobs) {
-  // repack blocks per job: the largest images have ~1,000 tiles; 128 blocks x 20 jobs = 2,560
-  // blocks next to <= 768 first-layer blocks
-  const int PB = 128;
-  const int groups = std::max(e2_cdiv(nF, 3), e2_cdiv(njobs * PB, 5));
-  hipLaunchKernelGGL((firstm_fwd_pack_kernel<KH, KW, PY, PX, MG>), dim3(8 * groups), dim3(256), 0, ctx->stream,
-                     p, (const PackJobDev*)jobs, njobs, PB, nF);
-  E2_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-template <int KH, int KW, int PY, int PX, int MG>
 int launch_bwd(e2_ctx* ctx, const FirstM& p, int grid, float* part) {
   using G = Geo<KH, KW, PY, PX, MG>;
   const size_t lds = sizeof(float) * (4 * 64 * PY * G::CH + G::RT * kTW);
@@ -436,20 +391,6 @@ int e2i_firstm_fwd(e2_ctx* ctx, int v, const e2_tensor5* x, const float* w, cons
   p.w = w; p.bias = bias; p.out = out->ptr; p.act = act;
   const int grid = e2i_firstm_grid(ctx, p.nTiles);
   E2_FM_DISPATCH(launch_fwd, ctx, p, grid)
-  e2_set_error("conv1(mfma): no instance for variant %d, %d channels", v, cout);
-  return 2;
-}
-
-// the same + the weight repack of all layers (jobs_dev: e2_pack_job_fill records) in one launch
-int e2i_firstm_fwd_pack(e2_ctx* ctx, int v, const e2_tensor5* x, const float* w, const float* bias,
-                        int cout, int py, int px, int act, const e2_tensor5* out,
-                        const void* jobs_dev, int njobs) {
-  const int mg = e2i_firstm_mg(cout);
-  FirstM p{};
-  fill(p, x, out, cout, py, px);
-  p.w = w; p.bias = bias; p.out = out->ptr; p.act = act;
-  const int grid = e2i_firstm_grid(ctx, p.nTiles);
-  E2_FM_DISPATCH(launch_fwd_pack, ctx, p, grid, jobs_dev, njobs)
   e2_set_error("conv1(mfma): no instance for variant %d, %d channels", v, cout);
   return 2;
 }

@@ -506,12 +506,6 @@ class Conv(NeuralLayer):
             return                            # done by the Softmax / NLL node
         x = plan.out[self.parent]
         if self._fused_first(plan):
-            if getattr(plan, '_pack_with', None) is self:     # ... and every layer's weight repack
-                plan._pack_with = None
-                ctx.conv1_pool_act_fwd_pack(x, self._w5(plan.param(self.w)), plan.param(self.b),
-                                            self._p3, self.activation_func, plan.out[self],
-                                            *plan._pack_dev)
-                return
             ctx.conv1_pool_act_fwd(x, self._w5(plan.param(self.w)), plan.param(self.b), self._p3,
                                    self.activation_func, plan.out[self])
             return

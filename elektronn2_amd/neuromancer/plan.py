@@ -421,34 +421,11 @@ class Plan(object):
 
     # ---- kernel sequences ----------------------------------------------------------------
     def _emit_forward(self):
-        # all packed weight images, one launch -- which the fused first layer shares where it
-        # leads the forward pass (Conv._plan_fwd -> e2_conv1_pool_act_fwd_pack): it reads the
-        # raw weights, every later node the images
-        self._pack_with = None
-        if self._pack_dev is not None:
-            lead = self._pack_carrier()
-            if lead is not None and not self.use_side_pack:
-                self._pack_with = lead
-            else:
-                self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
+        if self._pack_dev is not None:       # all packed weight images, one launch
+            self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
         for n in self.nodes:
             n._plan_fwd(self)
-        if self._pack_with is not None:
-            raise RuntimeError("the weight repack was not launched")
         self.join_side()
-
-    def _pack_carrier(self):
-        """the fused first-layer Conv whose forward launch can carry the weight repack: the
-        first node of the plan that launches anything (only Input nodes before it)"""
-        import os
-        if os.environ.get('E2_PACK_WITH_FIRST', '1') != '1':
-            return None
-        for n in self.nodes:
-            if getattr(n, 'is_source', False):
-                continue
-            f = getattr(n, '_fused_first', None)
-            return n if (f is not None and f(self)) else None
-        return None
 
     def _bwd_nodes(self):
         return [n for n in reversed(self.nodes)

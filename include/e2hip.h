@@ -190,14 +190,6 @@ int e2_conv1_supported(int cin, int kd, int kh, int kw, int pz, int py, int px);
 int e2_conv1_pool_act_fwd(e2_ctx*, const e2_tensor5* x, const float* w,
                           const float* bias, int cout, int kh, int kw, int py,
                           int px, int act, const e2_tensor5* out);
-/* the same AND e2_conv3d_pack_multi(jobs_dev, njobs) -- the repack of every layer's weight
- * images, which the first layer does not read -- in ONE launch where the first layer runs on
- * the matrix cores (cout <= 32), two launches otherwise: the two head every training step and
- * neither fills the chip (model.py:548-600 trainingstep; the images are this build's form of
- * the shared weight variables theano.function reads, graphutils.py:376-387) */
-int e2_conv1_pool_act_fwd_pack(e2_ctx*, const e2_tensor5* x, const float* w, const float* bias,
-                               int cout, int kh, int kw, int py, int px, int act,
-                               const e2_tensor5* out, const void* jobs_dev, int njobs);
 /* workspace of the backward: per-tile partial sums, (n, cout, d, ho, wo) = dims of
  * the POOLED output gradient */
 size_t e2_conv1_bwd_workspace_bytes(int n, int cout, int d, int ho, int wo, int kh, int kw);

@@ -890,27 +890,6 @@ def test_fused_first_layer(ctx, k, sp, pool):
     ctx.conv1_pool_act_bwd(dev(x), dev(w), dev(b), dev(dout), pool, 'relu', dw, db)
     assert relerr(dw, dw_ref) < TOL
     assert relerr(db, db_ref) < TOL
-    # the forward that carries the weight repack of OTHER layers in its launch
-    # (e2_conv1_pool_act_fwd_pack): the same output bit for bit, the same images as
-    # e2_conv3d_pack_multi alone -- conv, data-gradient and UpConv images, many / few tiles
-    shapes = [(200, 150, 1, 3, 3), (40, 20, 3, 3, 3), (2, 200, 1, 1, 1), (80, 40, 4, 4, 4)]
-    ws = [dev(rng.randn(*s_)) for s_ in shapes]
-    up = dev(rng.randn(24, 16, 1, 2, 2))
-    jobs, ref_jobs = [], []
-    for w_ in ws + [up]:
-        co, ci = w_.shape[:2]
-        kk = tuple(w_.shape[2:])
-        modes = (2, 3) if w_ is up else (0, 1)
-        for mode in modes:
-            nb = (ctx.upconv_image_bytes(co, ci, kk) if w_ is up else ctx.conv_ws_bytes(co, ci, kk)) // 4 + 64
-            jobs.append((w_, torch.zeros(nb, device="cuda"), mode))
-            ref_jobs.append((w_, torch.zeros(nb, device="cuda"), mode))
-    ctx.conv3d_pack_multi(*ctx.make_pack_jobs(ref_jobs))
-    out2 = torch.full(out_ref.shape, float("nan"), device="cuda")
-    ctx.conv1_pool_act_fwd_pack(dev(x), dev(w), dev(b), pool, 'relu', out2, *ctx.make_pack_jobs(jobs))
-    assert torch.equal(out2, out)
-    for (_, img, _), (_, ref, _) in zip(jobs, ref_jobs):
-        assert torch.equal(img, ref)
 
 
 @pytest.mark.parametrize("ncls,cin", [(2, 200), (3, 37), (4, 300)])
