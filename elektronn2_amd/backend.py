@@ -136,6 +136,9 @@ def _load():
         "e2_get_mfma_dtype": (C.c_int, [vp]),
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
+        "e2_set_loss_grad_mode": (C.c_int, [vp, i, fp]),
+        "e2_adam_step_ex": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp, fp, C.c_float, i]),
+        "e2_sgd_step_ex": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp, fp, C.c_float, i]),
         "e2_graph_begin": (C.c_int, [vp]),
         "e2_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
         "e2_graph_launch": (C.c_int, [vp, vp]),
@@ -692,15 +695,25 @@ class Context:
                                C.byref(t5(dlogits)) if dlogits is not None else None,
                                _fp(loss_sum)), "e2_malis_nll")
 
-    def adam_step(self, p, g, m, s, seg_off, seg_reg, hyper):
-        _chk(_lib.e2_adam_step(self.h, _fp(p), _fp(g), _fp(m), _fp(s), p.numel(),
-                               C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
-                               seg_reg.numel(), _fp(hyper)), "e2_adam_step")
+    def set_loss_grad_mode(self, sum_mode, count_out=None):
+        """sum_mode: the NLL backward launches that follow leave the gradient unnormalised and
+        write this rank's labelled count to ``count_out`` (one-element device tensor)"""
+        _chk(_lib.e2_set_loss_grad_mode(self.h, int(bool(sum_mode)), _fp(count_out)),
+             "e2_set_loss_grad_mode")
 
-    def sgd_step(self, p, g, d, seg_off, seg_reg, hyper):
-        _chk(_lib.e2_sgd_step(self.h, _fp(p), _fp(g), _fp(d), p.numel(),
-                              C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
-                              seg_reg.numel(), _fp(hyper)), "e2_sgd_step")
+    def adam_step(self, p, g, m, s, seg_off, seg_reg, hyper, gdiv=None, gmul=1.0, zero_g=False):
+        """gdiv / gmul: the update sees g * gmul / (gdiv[0] + 1e-5) (gdiv: device scalar, or
+        None); zero_g: g is left zero for the next backward pass"""
+        _chk(_lib.e2_adam_step_ex(self.h, _fp(p), _fp(g), _fp(m), _fp(s), p.numel(),
+                                  C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
+                                  seg_reg.numel(), _fp(hyper), _fp(gdiv), float(gmul),
+                                  int(bool(zero_g))), "e2_adam_step_ex")
+
+    def sgd_step(self, p, g, d, seg_off, seg_reg, hyper, gdiv=None, gmul=1.0, zero_g=False):
+        _chk(_lib.e2_sgd_step_ex(self.h, _fp(p), _fp(g), _fp(d), p.numel(),
+                                 C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
+                                 seg_reg.numel(), _fp(hyper), _fp(gdiv), float(gmul),
+                                 int(bool(zero_g))), "e2_sgd_step_ex")
 
     # ---- graph capture / events --------------------------------------------------------
     def graph_begin(self):

@@ -48,6 +48,8 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->fork_next = 0;
   c->mfma_bf16 = 0;
   c->skip_zero_fill = 0;
+  c->loss_sum_mode = 0;
+  c->loss_count_out = nullptr;
   c->last_fill_ptr = nullptr;
   c->last_fill_n = 0;
   c->tiling[0][0] = c->tiling[1][0] = 0;
@@ -58,6 +60,19 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
     return 1;
   }
   *out = c;
+  return 0;
+}
+
+/* Data-parallel normalisation (loss.py:342-344 divides by the labelled voxels of the WHOLE
+ * batch): with sum_mode != 0 the NLL backward launches that follow (e2_tail_fwd_bwd, e2_head_bwd,
+ * e2_softmax_nll_bwd) leave the gradient UNNORMALISED (loss values are unaffected) and write
+ * this rank's labelled count to count_out (optional: e2_tail_reduce / e2_head_bwd /
+ * e2_softmax_nll_bwd), so that sum-all-reduce + e2_adam_step_ex(gdiv = summed count) is the
+ * whole-batch gradient.  (0, NULL) restores the per-rank normalisation. */
+extern "C" int e2_set_loss_grad_mode(e2_ctx* ctx, int sum_mode, float* count_out) {
+  E2_REQUIRE(ctx, "set_loss_grad_mode: null context");
+  ctx->loss_sum_mode = sum_mode ? 1 : 0;
+  ctx->loss_count_out = count_out;
   return 0;
 }
 

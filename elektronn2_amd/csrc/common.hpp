@@ -20,6 +20,8 @@ struct e2_ctx {
   float* last_fill_ptr;     // flat region the last conv launch zero-filled (n = 0: none)
   size_t last_fill_n;
   char tiling[2][64];       // e2_set_tiling: forced tiling of the igemm / wgrad launches ("" = cost model)
+  int loss_sum_mode;        // e2_set_loss_grad_mode: 1 = NLL gradients are NOT divided by the labelled count
+  float* loss_count_out;    // ... and the count is also written here (the slot behind the gradient arena)
 };
 
 // Debug switches (timing ablations, in-kernel stamps, verbose launch log) are compiled in

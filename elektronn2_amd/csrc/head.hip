@@ -118,15 +118,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(HView x, const float* __r
                                                        HView dx, int want_dx, int accumulate,
                                                        float* __restrict__ part,
                                                        float* __restrict__ loss_out,
-                                                       int tilesPerN, int nTiles) {
+                                                       int tilesPerN, int nTiles, int sum_mode,
+                                                       float* __restrict__ count_out) {
   extern __shared__ float hs[];
   const int C = x.c;
   float* dl = hs;                         // [NC][HT]
   float* xs = hs + NC * HT;               // [C][HT + 1]
   const int tid = threadIdx.x;
   const int S = x.d * x.h * x.w;
-  const float inv = 1.f / (stats[1] + E2_EPS_NLL);
+  float inv = 1.f / (stats[1] + E2_EPS_NLL);
   if (blockIdx.x == 0 && tid == 0 && loss_out) loss_out[0] = stats[0] * inv;
+  if (blockIdx.x == 0 && tid == 0 && count_out) count_out[0] = stats[1];
+  if (sum_mode) inv = 1.f;                  // (e2_set_loss_grad_mode: unnormalised gradients)
   // thread ci < C (two rounds when C > 256) owns dW[c][ci]
   float aw[2][NC];
 #pragma unroll
@@ -347,7 +350,8 @@ extern "C" int e2_head_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
     }                                                                                    \
     hipLaunchKernelGGL((head_bwd_kernel<NC>), dim3(grid), dim3(256), lds, ctx->stream,   \
                        hv(x), w, hv(probs), hv(target), stats, vdx, dx ? 1 : 0,          \
-                       accumulate_dx, part, loss_out, (int)tilesPerN, (int)nTiles);      \
+                       accumulate_dx, part, loss_out, (int)tilesPerN, (int)nTiles,       \
+                       ctx->loss_sum_mode, ctx->loss_count_out);                         \
   } while (0)
   if (ncls == 2) E2_HB(2); else if (ncls == 3) E2_HB(3); else E2_HB(4);
 #undef E2_HB

@@ -576,13 +576,17 @@ __global__ void softmax_nll_fwd_kernel(View5 lg, View5 tg, View5 pr,
 }
 
 __global__ void softmax_nll_bwd_kernel(View5 pr, View5 tg, const float* __restrict__ stats,
-                                       View5 dl, float* __restrict__ loss_out) {
+                                       View5 dl, float* __restrict__ loss_out, int sum_mode,
+                                       float* __restrict__ count_out) {
   const long S = (long)pr.d * pr.h * pr.w;
   const long s = blockIdx.x * 256L + threadIdx.x;
   const int n = blockIdx.z;
-  const float inv = 1.f / (stats[1] + E2_EPS_NLL);
-  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0 && loss_out)
-    loss_out[0] = stats[0] * inv;
+  float inv = 1.f / (stats[1] + E2_EPS_NLL);
+  if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    if (loss_out) loss_out[0] = stats[0] * inv;
+    if (count_out) count_out[0] = stats[1];
+  }
+  if (sum_mode) inv = 1.f;                  // (e2_set_loss_grad_mode: unnormalised gradients)
   if (s >= S) return;
   const int x = (int)(s % pr.w);
   const long t = s / pr.w;
@@ -664,27 +668,37 @@ __device__ __forceinline__ float seg_mult_lds(const long* so, const float* sr, i
   return sr[lo];
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+// gdiv / gmul: the gradient that enters the update is g * gmul / (gdiv ? gdiv[0] + 1e-5 : 1) --
+// the data-parallel step sums UNNORMALISED gradients over the ranks and divides by the summed
+// labelled-voxel count here (one device scalar behind the arena) instead of in elementwise
+// launches of its own.  zero_g: the arena is left ZERO for the next backward pass, which then
+// needs no fill launch (e2_adam_step_ex).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ s, size_t n,
                                                    const int64_t* __restrict__ seg_off,
                                                    const float* __restrict__ seg_reg, int n_seg,
-                                                   float* __restrict__ hyper) {
+                                                   float* __restrict__ hyper,
+                                                   const float* __restrict__ gdiv, float gmul, int zero_g) {
   __shared__ long so[kOptMaxSeg];
   __shared__ float sr[kOptMaxSeg];
   for (int i = threadIdx.x; i < n_seg; i += blockDim.x) { so[i] = seg_off[i]; sr[i] = seg_reg[i]; }
   const float lr = hyper[0], mom = hyper[1], b2 = hyper[2], wd = hyper[3];
   const float t = hyper[4] + 1.f;
   const float fac = sqrtf(1.f - powf(b2, t)) / (1.f - powf(mom, t));
+  const float gs = gdiv ? gmul / (gdiv[0] + 1e-5f) : gmul;
   __syncthreads();
   const size_t n4 = n >> 2;
   float4* p4 = reinterpret_cast<float4*>(p);
-  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* g4 = reinterpret_cast<float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m);
   float4* s4 = reinterpret_cast<float4*>(s);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
-    const float4 gv = g4[i], mv = m4[i], sv = s4[i];
+    float4 gv = g4[i];
+    const float4 mv = m4[i], sv = s4[i];
     float4 pv = p4[i];
+    if (gs != 1.f) { gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs; }
+    if (zero_g) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float mult = seg_mult_lds(so, sr, n_seg, 4 * i) * wd;
     float4 nm, ns;
 #define E2_ADAM1(c)                                                      \
@@ -701,7 +715,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
   if (blockIdx.x == 0)                                 // (n is a multiple of 4 in the plan's arena)
     for (size_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
-      const float gi = g[i];
+      const float gi = g[i] * gs;
+      if (zero_g) g[i] = 0.f;
       const float nm = mom * m[i] + (1.f - mom) * gi;
       const float ns = b2 * s[i] + (1.f - b2) * gi * gi;
       float dir = fac * nm / sqrtf(ns + E2_EPS_ADAM);
@@ -723,24 +738,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g,
                                                   float* __restrict__ d, size_t n,
                                                   const int64_t* __restrict__ seg_off,
                                                   const float* __restrict__ seg_reg, int n_seg,
-                                                  const float* __restrict__ hyper) {
+                                                  const float* __restrict__ hyper,
+                                                  const float* __restrict__ gdiv, float gmul, int zero_g) {
   __shared__ long so[kOptMaxSeg];
   __shared__ float sr[kOptMaxSeg];
   for (int i = threadIdx.x; i < n_seg; i += blockDim.x) { so[i] = seg_off[i]; sr[i] = seg_reg[i]; }
   const float lr = hyper[0], mom = hyper[1], wd = hyper[3];
+  const float gs = gdiv ? gmul / (gdiv[0] + 1e-5f) : gmul;
   __syncthreads();
   const size_t n4 = n >> 2;
   float4* p4 = reinterpret_cast<float4*>(p);
-  const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* g4 = reinterpret_cast<float4*>(g);
   float4* d4 = reinterpret_cast<float4*>(d);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4;
        i += (size_t)gridDim.x * blockDim.x) {
-    const float4 gv = g4[i], dv = d4[i];
+    float4 gv = g4[i];
+    const float4 dv = d4[i];
     float4 pv = p4[i];
+    if (gs != 1.f) { gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs; }
+    if (zero_g) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float mult = seg_mult_lds(so, sr, n_seg, 4 * i) * wd;
     float4 nd;
 #define E2_SGD1(c)                                                       \
@@ -752,7 +772,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
   if (blockIdx.x == 0)
     for (size_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
-      const float nd = g[i] + mom * d[i];
+      const float nd = g[i] * gs + mom * d[i];
+      if (zero_g) g[i] = 0.f;
       const float mult = seg_mult_lds(so, sr, n_seg, i) * wd;
       const float pi = p[i];
       d[i] = nd;
@@ -1128,7 +1149,7 @@ extern "C" int e2_softmax_nll_bwd(e2_ctx* ctx, const e2_tensor5* probs,
   const long S = (long)p.d * p.h * p.w;
   dim3 grid((unsigned)((S + 255) / 256), 1, (unsigned)p.n);
   hipLaunchKernelGGL(softmax_nll_bwd_kernel, grid, dim3(256), 0, ctx->stream, p, t, stats, d,
-                     loss_out);
+                     loss_out, ctx->loss_sum_mode, ctx->loss_count_out);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1159,6 +1180,14 @@ extern "C" int e2_malis_nll(e2_ctx* ctx, const e2_tensor5* probs, const float* p
 extern "C" int e2_adam_step(e2_ctx* ctx, float* p, const float* g, float* m, float* s,
                             size_t n, const int64_t* seg_off, const float* seg_reg,
                             int n_seg, const float* hyper) {
+  return e2_adam_step_ex(ctx, p, const_cast<float*>(g), m, s, n, seg_off, seg_reg, n_seg, hyper,
+                         nullptr, 1.f, 0);
+}
+
+extern "C" int e2_adam_step_ex(e2_ctx* ctx, float* p, float* g, float* m, float* s,
+                               size_t n, const int64_t* seg_off, const float* seg_reg,
+                               int n_seg, const float* hyper, const float* gdiv, float gmul,
+                               int zero_g) {
   E2_REQUIRE(ctx && p && g && m && s && seg_off && seg_reg && hyper && n_seg > 0,
              "adam_step: null argument");
   E2_REQUIRE(n_seg <= kOptMaxSeg, "adam_step: %d parameter tensors (at most %d)", n_seg, kOptMaxSeg);
@@ -1166,7 +1195,7 @@ extern "C" int e2_adam_step(e2_ctx* ctx, float* p, const float* g, float* m, flo
              "adam_step: arenas must be 16-byte aligned");
   const int grid = (int)std::min<size_t>(std::max<size_t>((n / 4 + 255) / 256, 1), ctx->num_cu);
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, g, m, s, n,
-                     seg_off, seg_reg, n_seg, const_cast<float*>(hyper));
+                     seg_off, seg_reg, n_seg, const_cast<float*>(hyper), gdiv, gmul, zero_g ? 1 : 0);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1174,13 +1203,20 @@ extern "C" int e2_adam_step(e2_ctx* ctx, float* p, const float* g, float* m, flo
 extern "C" int e2_sgd_step(e2_ctx* ctx, float* p, const float* g, float* d, size_t n,
                            const int64_t* seg_off, const float* seg_reg, int n_seg,
                            const float* hyper) {
+  return e2_sgd_step_ex(ctx, p, const_cast<float*>(g), d, n, seg_off, seg_reg, n_seg, hyper,
+                        nullptr, 1.f, 0);
+}
+
+extern "C" int e2_sgd_step_ex(e2_ctx* ctx, float* p, float* g, float* d, size_t n,
+                              const int64_t* seg_off, const float* seg_reg, int n_seg,
+                              const float* hyper, const float* gdiv, float gmul, int zero_g) {
   E2_REQUIRE(ctx && p && g && d && seg_off && seg_reg && hyper && n_seg > 0,
              "sgd_step: null argument");
   E2_REQUIRE(n_seg <= kOptMaxSeg, "sgd_step: %d parameter tensors (at most %d)", n_seg, kOptMaxSeg);
   E2_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)d) & 15) == 0, "sgd_step: arenas must be 16-byte aligned");
   const int grid = (int)std::min<size_t>(std::max<size_t>((n / 4 + 255) / 256, 1), 2 * (size_t)ctx->num_cu);
   hipLaunchKernelGGL(sgd_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, g, d, n, seg_off,
-                     seg_reg, n_seg, hyper);
+                     seg_reg, n_seg, hyper, gdiv, gmul, zero_g ? 1 : 0);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -65,6 +65,7 @@ struct TailP {
   float* part;                       // [PSZ][work-groups] partial sums (an element's slots contiguous)
   float* stats;                      // [0] loss sum (written by the reduce kernel), [1] #labelled
   int zero_wb;                       // 1: whole chunks of K reach past a packed image's rows
+  int sum_mode;                      // 1: dlogits are not divided by the labelled count (e2_set_loss_grad_mode)
   int N, C1, C2, S;
   int tilesPerN;
   long nTarget;                      // N * S
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
         if (tv == (float)c) { tc = c; pt = pc[c]; lsum -= logf(pc[c] + E2_EPS_NLL); }
       }
       // dL/dp_t = -inv / (p_t + eps);  dlogit_c = p_c (dp_c - sum_k dp_k p_k)   (head.hip)
-      const float gpt = (tc >= 0) ? (-inv / (pt + E2_EPS_NLL)) * pt : 0.f;
+      const float gpt = (tc >= 0) ? (-(p.sum_mode ? 1.f : inv) / (pt + E2_EPS_NLL)) * pt : 0.f;
 #pragma unroll
       for (int c = 0; c < NC; ++c) d[c] = gpt * ((c == tc ? 1.f : 0.f) - pc[c]);
     }
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(256) void tail_count_kernel(const float* tg, long t
 // dependent-latency loads for the loss alone, 46 us.)
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int nWG,
                                                           int nc, int c2, float* dwh, float* dbh,
-                                                          float* db1, float* stats, float* loss_out) {
+                                                          float* db1, float* stats, float* loss_out,
+                                                          float* count_out) {
   const int psz = tail_psz(nc, c2);
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= psz) return;
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restric
   if (idx == psz - 1) {
     stats[0] = s;
     if (loss_out) loss_out[0] = s / (stats[1] + E2_EPS_NLL);
+    if (count_out) count_out[0] = stats[1];
     return;
   }
   float* dst = idx < nc * c2 ? dwh + idx : (idx < nc * c2 + nc ? dbh + (idx - nc * c2)
@@ -602,7 +605,7 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   p.pr = probs->ptr; p.psN = probs->sn; p.psC = probs->sc;
   p.dpre = dpre->ptr; p.dsN = dpre->sn; p.dsC = dpre->sc;
   p.dx = dx ? dx->ptr : nullptr; p.gsN = dx ? dx->sn : 0; p.gsC = dx ? dx->sc : 0;
-  p.part = (float*)ws; p.stats = stats;
+  p.part = (float*)ws; p.stats = stats; p.sum_mode = ctx->loss_sum_mode;
   p.N = x->n; p.C1 = x->c; p.C2 = c2; p.S = (int)S;
   p.nTarget = (long)x->n * S;
   int wm = 1, kc = 40;
@@ -645,7 +648,7 @@ extern "C" int e2_tail_reduce(e2_ctx* ctx, const void* ws, int n_slots, int c2, 
   const int psz = tail_psz(ncls, c2);
   hipLaunchKernelGGL(tail_reduce_kernel, dim3(e2_cdiv(psz, 4)), dim3(256), 0,
                      ctx->stream, (const float*)ws, n_slots, ncls, c2, dw_head, db_head, db1, stats,
-                     loss_out);
+                     loss_out, ctx->loss_count_out);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -150,11 +150,12 @@ class MultinoulliNLL(Node):
             par = tail.parent
             plan.join_side()
             dx = plan.grad[par] if plan.needs_grad(par) else None
-            plan.scratch[self, 'tail_slots'] = plan.ctx.tail_fwd_bwd(
-                plan.out[par], plan.scratch[tail, 'wp_f'], plan.scratch.get((tail, 'wp_d')),
-                plan.param(tail.b), plan.param(head.w).reshape(head.n_f, -1), plan.param(head.b),
-                plan.out[self.target], plan.out[self.pred], plan.scratch[tail, 'dy'], dx, stats,
-                plan.scratch[tail, 'tail_ws'])
+            with plan.loss_grad_mode():
+                plan.scratch[self, 'tail_slots'] = plan.ctx.tail_fwd_bwd(
+                    plan.out[par], plan.scratch[tail, 'wp_f'], plan.scratch.get((tail, 'wp_d')),
+                    plan.param(tail.b), plan.param(head.w).reshape(head.n_f, -1),
+                    plan.param(head.b), plan.out[self.target], plan.out[self.pred],
+                    plan.scratch[tail, 'dy'], dx, stats, plan.scratch[tail, 'tail_ws'])
             return
         plan.zero_early(stats)
         head = self.pred._head(plan)
@@ -166,6 +167,10 @@ class MultinoulliNLL(Node):
                                  plan.out[self.pred], stats)
 
     def _plan_bwd(self, plan):
+        with plan.loss_grad_mode():
+            self._plan_bwd_launches(plan)
+
+    def _plan_bwd_launches(self, plan):
         head = self.pred._head(plan)
         tail = self._tail(plan)
         if tail is not None:

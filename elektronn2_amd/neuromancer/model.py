@@ -201,6 +201,11 @@ class Model(GraphManager):
         self._G_store = torch.zeros(max(self.n_train, 4) + 4, dtype=torch.float32,
                                     device=ctx.device)
         self.G = self._G_store[:max(self.n_train, 4)]
+        self.G_spare = self._G_store[max(self.n_train, 4):max(self.n_train, 4) + 1]
+        # the gradient arena is all zeros: a training plan whose optimiser kernel clears it
+        # (e2_adam_step_ex zero_g) skips the fill launch of the next backward pass while this
+        # holds; any other writer of G (a gradient plan) resets it
+        self._g_clean = True
         seg_off, seg_reg = [], []
         for p in params:
             o, n, sh = self._slots[id(p)]
@@ -263,15 +268,19 @@ class Model(GraphManager):
             import torch
             torch.cuda.current_stream(self.P.device).synchronize()
 
-    def allreduce_grads(self, count=None):
-        ex = self.grad_exchange(count)
+    def allreduce_grads(self, count=None, raw=False):
+        ex = self.grad_exchange(count, raw=raw)
         ex.start(0, self.G.numel())
         ex.finish()
 
-    def grad_exchange(self, count=None):
+    def grad_exchange(self, count=None, raw=False):
         """sliced exchange of the gradient arena (parallel.BucketedMean); ``count``: this
-        rank's labelled-voxel count on the device (weighted mean, see enable_data_parallel)"""
+        rank's labelled-voxel count on the device (weighted mean, see enable_data_parallel);
+        ``raw``: sums only -- the plan's kernels normalise (Plan._dp_scale)"""
         from ..parallel import BucketedMean
+        if raw:
+            return BucketedMean(self.G, self._dp_group, spare=True, raw=True,
+                                force=getattr(self, '_dp_force', False))
         return BucketedMean(self.G, self._dp_group,
                             count=count if getattr(self, '_dp_weighted', False) else None,
                             spare=True, force=getattr(self, '_dp_force', False))

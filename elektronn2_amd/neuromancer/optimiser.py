@@ -108,6 +108,18 @@ class Optimiser(object):
     def device_update(self, plan):
         raise NotImplementedError
 
+    def _grad_scaling(self, plan):
+        """keyword arguments of the update launch: the data-parallel normalisation applied
+        on the way in (Plan._dp_scale), the gradient arena cleared on the way out"""
+        kw = dict(zero_g=plan._upd_zeroes_g())
+        sc = plan._dp_scale()
+        if sc is not None:
+            if sc[0] == 'sum':
+                kw['gdiv'] = self.model.G_spare
+            else:
+                kw['gmul'] = sc[1]
+        return kw
+
     def state_dict(self):
         return {}
 
@@ -137,7 +149,8 @@ class SGD(Optimiser):
     def device_update(self, plan):
         m = self.model
         plan.ctx.sgd_step(m.P[:m.n_train] if m.n_train < m.P.numel() else m.P, m.G,
-                          self.last_dir, m.seg_off, m.seg_reg, self._hyper)
+                          self.last_dir, m.seg_off, m.seg_reg, self._hyper,
+                          **self._grad_scaling(plan))
 
     def clear_last_dir(self):
         if self.last_dir is not None:
@@ -200,7 +213,7 @@ class Adam(Optimiser):
         m = self.model
         plan.ctx.adam_step(m.P[:m.n_train] if m.n_train < m.P.numel() else m.P, m.G,
                            self.momentum, self.squared_accum, m.seg_off, m.seg_reg,
-                           self._hyper)
+                           self._hyper, **self._grad_scaling(plan))
 
     @property
     def t(self):

@@ -439,7 +439,8 @@ class Plan(object):
             k = self._dp_cut()[0]
             nodes = nodes[:k] if part == 0 else nodes[k:]
         if part in (None, 0):
-            self.zero_early(self.model.G)
+            if not self._upd_zeroes_g():       # (else: the optimiser kernel left it zero)
+                self.zero_early(self.model.G)
             self._grad_written = set()
         for n in nodes:
             n._plan_bwd(self)
@@ -489,6 +490,43 @@ class Plan(object):
         if self.step in ('Adam', 'SGD'):
             self.model.optimisers[self.step].device_update(self)
 
+    def _upd_zeroes_g(self):
+        """the optimiser launch of this plan clears the gradient arena for the next step
+        (e2_adam_step_ex zero_g): no fill launch at the head of the backward pass.  G is
+        zero on entry because the last step left it so -- or _run_device fills it first
+        (Model._g_clean)."""
+        return (self.training and self.step in ('Adam', 'SGD')
+                and os.environ.get('E2_ZERO_IN_UPDATE', '1') == '1')
+
+    def _dp_scale(self):
+        """how the data-parallel step normalises: None = the exchange object scales with
+        elementwise launches (parallel.BucketedMean); ('sum',) = the loss kernels leave the
+        gradients unnormalised and put the labelled count into the slot behind the arena, the
+        collectives only SUM, the optimiser kernel divides by the summed count; ('mean', 1/w)
+        = plain mean, the factor applied by the optimiser kernel."""
+        if not (self.training and self.step in ('Adam', 'SGD') and self.model.dp_world() > 1
+                and os.environ.get('E2_DP_FUSED_SCALE', '1') == '1' and self.model.G.is_cuda):
+            return None
+        if getattr(self.model, '_dp_weighted', False):
+            return ('sum',) if self._labelled_count() is not None else None
+        import torch.distributed as dist
+        return ('mean', 1.0 / dist.get_world_size(self.model._dp_group))
+
+    def loss_grad_mode(self):
+        """context manager around the NLL backward launches of a loss node"""
+        plan = self
+
+        class _M(object):
+            def __enter__(self_):
+                self_.on = plan._dp_scale() == ('sum',)
+                if self_.on:
+                    plan.ctx.set_loss_grad_mode(True, plan.model.G_spare)
+
+            def __exit__(self_, *a):
+                if self_.on:
+                    plan.ctx.set_loss_grad_mode(False, None)
+        return _M()
+
     def _segments(self):
         """The step as a list of (emit, after): ``emit`` issues launches on the plan's
         stream (each segment is captured into its own hipGraph), ``after`` is host code
@@ -511,8 +549,8 @@ class Plan(object):
                     if upd and not dp:
                         self._emit_update()
             segs.append((self._emit_forward, host_steps))
-            segs.append((rest, (lambda: self.model.allreduce_grads(self._labelled_count()))
-                         if dp else None))
+            segs.append((rest, (lambda: self.model.allreduce_grads(
+                self._labelled_count(), raw=self._dp_scale() is not None)) if dp else None))
             if dp:
                 segs.append((self._emit_update, None))
             return segs
@@ -526,7 +564,8 @@ class Plan(object):
                 self._emit_backward(0)
 
             def start_tail():
-                self._ex = self.model.grad_exchange(self._labelled_count())
+                self._ex = self.model.grad_exchange(self._labelled_count(),
+                                                    raw=self._dp_scale() is not None)
                 self._ex.start(cut[1], n_train)
 
             def finish():
@@ -541,8 +580,8 @@ class Plan(object):
                 self._emit_backward()
                 if upd and not dp:
                     self._emit_update()
-        segs.append((whole, (lambda: self.model.allreduce_grads(self._labelled_count()))
-                     if dp else None))
+        segs.append((whole, (lambda: self.model.allreduce_grads(
+            self._labelled_count(), raw=self._dp_scale() is not None)) if dp else None))
         if dp:
             segs.append((self._emit_update, None))
         return segs
@@ -560,6 +599,10 @@ class Plan(object):
                 self._calls = 0          # one eager run of the new segmentation first
             self._graphs = None
             self._dp_cut_cache = False
+        if self.training:
+            if self._upd_zeroes_g() and not self.model._g_clean:
+                ctx.fill(self.model.G, 0.0)            # (someone else wrote G: eager, outside the graphs)
+            self.model._g_clean = False
         capture = self.use_graph and self._calls >= 1
         if capture and self._graphs is None:
             # the first captured call runs segment by segment: a host step between two
@@ -601,6 +644,7 @@ class Plan(object):
             autotune.save()
             ctx.record(self._ev1)
             self._calls += 1
+            self.model._g_clean = self._upd_zeroes_g()
             return
         ctx.record(self._ev0)
         if not capture:
@@ -615,6 +659,8 @@ class Plan(object):
                 after()
         ctx.record(self._ev1)
         self._calls += 1
+        if self.training:
+            self.model._g_clean = self._upd_zeroes_g()
 
     # ---- call ----------------------------------------------------------------------------------
     def set_inputs(self, args):

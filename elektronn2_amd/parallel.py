@@ -93,7 +93,7 @@ class BucketedMean:
     current stream (RCCL runs it on its own stream); finish() makes the current stream
     wait for every slice."""
 
-    def __init__(self, flat, group=None, count=None, spare=False, force=False):
+    def __init__(self, flat, group=None, count=None, spare=False, force=False, raw=False):
         """``count``: one-element tensor with this rank's number of LABELLED target voxels.
         The reference normalises the NLL by the labelled count of the WHOLE batch
         (loss.py:342-344); a rank's gradient is normalised by its own count, so with
@@ -106,6 +106,11 @@ class BucketedMean:
         element (the model's gradient arena does).  The count then travels IN the first
         slice that reaches the arena's end -- no collective of its own, which at these
         sizes is pure latency; without a spare slot it takes a one-element all-reduce."""
+        # raw: SUM only -- no pre-scaling by the count, no division afterwards.  The training
+        # plan's form: its loss kernels leave the gradients unnormalised and put the labelled
+        # count into the spare slot, the optimiser kernel divides by the summed count
+        # (e2_set_loss_grad_mode / e2_adam_step_ex): no elementwise launch around the collective.
+        self.raw = bool(raw)
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force: run the collectives in a one-rank group too (the sums are identities)
@@ -113,7 +118,7 @@ class BucketedMean:
         self._work, self._covered = [], 0
         self._count, self._total = count, None
         self._ext = None
-        if count is not None and spare:
+        if (count is not None or raw) and spare:
             n = flat.numel()
             self._ext = flat.as_strided((n + 1,), (1,), flat.storage_offset())
 
@@ -121,7 +126,10 @@ class BucketedMean:
         if self._skip or hi <= lo:
             return
         buf = self.flat
-        if self._count is not None:
+        if self.raw:
+            if self._ext is not None and hi == self.flat.numel():     # the slot behind the tail
+                buf, hi = self._ext, hi + 1
+        elif self._count is not None:
             self.flat[lo:hi].mul_(self._count)               # n_r * g_r
             if self._ext is not None:
                 if hi == self.flat.numel():                  # the count rides behind the tail
@@ -142,7 +150,9 @@ class BucketedMean:
         if self._covered != self.flat.numel():
             raise RuntimeError("BucketedMean: slices cover %d of %d elements"
                                % (self._covered, self.flat.numel()))
-        if self._count is None:
+        if self.raw:
+            pass
+        elif self._count is None:
             self.flat.mul_(1.0 / self.world)
         else:
             tot = self._ext[self.flat.numel():] if self._ext is not None else self._total

@@ -389,6 +389,29 @@ int e2_sgd_step(e2_ctx*, float* p, const float* g, float* d, size_t n,
                 const int64_t* seg_off, const float* seg_reg, int n_seg,
                 const float* hyper /* device: lr,mom,_,wd,_ */);
 
+/* Data-parallel normalisation: the reference divides the NLL by the labelled voxels of the
+ * WHOLE batch (loss.py:342-344).  With sum_mode != 0 the NLL backward launches that follow
+ * (e2_tail_fwd_bwd, e2_head_bwd, e2_softmax_nll_bwd) leave the gradient UNNORMALISED -- loss
+ * values are unaffected -- and e2_tail_reduce / e2_head_bwd / e2_softmax_nll_bwd also write this
+ * rank's labelled count to count_out (a slot behind the gradient arena, so that it rides in
+ * the same all-reduce); sum-all-reduce + e2_adam_step_ex(gdiv = the summed count) then IS the
+ * whole-batch gradient, with no elementwise launch around the collective.  (0, NULL) restores
+ * the per-rank normalisation. */
+int e2_set_loss_grad_mode(e2_ctx*, int sum_mode, float* count_out);
+
+/* the same with the gradient scaled on the way in and the arena cleared on the way out:
+ * the update sees g * gmul / (gdiv ? gdiv[0] + 1e-5 : 1); zero_g != 0 leaves g ZERO for the
+ * next backward pass (no fill launch).  gdiv: device scalar -- the data-parallel step sums
+ * unnormalised gradients (and the labelled-voxel counts, in a slot behind the arena) over the
+ * ranks and divides here, which is the reference's whole-batch normalisation
+ * (loss.py:342-344) without elementwise launches around the collective. */
+int e2_adam_step_ex(e2_ctx*, float* p, float* g, float* m, float* s, size_t n,
+                    const int64_t* seg_off, const float* seg_reg, int n_seg,
+                    const float* hyper, const float* gdiv, float gmul, int zero_g);
+int e2_sgd_step_ex(e2_ctx*, float* p, float* g, float* d, size_t n, const int64_t* seg_off,
+                   const float* seg_reg, int n_seg, const float* hyper, const float* gdiv,
+                   float gmul, int zero_g);
+
 /* ---- step capture (replaces theano.function, graphutils.py:376-387) ---- */
 typedef struct e2_graph e2_graph;
 int e2_graph_begin(e2_ctx*);                 /* hipStreamBeginCapture      */
