@@ -188,7 +188,7 @@ def dense_prediction_bench(args, rank, world):
                         "peak": peak, "unit": "TFLOP/s",
                         "frac": passes * fwd_gf / dt / 1e3 / peak, "traffic": None}}
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def dense_unet_bench(args, rank, world):
@@ -237,7 +237,7 @@ def dense_unet_bench(args, rank, world):
                         "peak": peak, "unit": "TFLOP/s",
                         "frac": n_tiles * fwd_gf / dt / 1e3 / peak, "traffic": None}}
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def warp_bench(args, rank, world):
@@ -300,7 +300,7 @@ def warp_bench(args, rank, world):
                                "kind": "port", "sample": "3 patches (median), NumPy restatement of "
                                "warp_slice + greyAugment (the reference uses numba-parallel gathers)"}
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def _free_port():
@@ -388,7 +388,7 @@ def selftest_bench(args, rank, world):
     if world > 1:
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "selftest", "value": float(v.item()), "unit": "rank",
+        emit({"metric": "selftest", "value": float(v.item()), "unit": "rank",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "config": {"workload": "selftest (no GPU)", "ranks": ranks}}))
 
@@ -471,6 +471,28 @@ def time_training(workload, args, rank, world, dev, steps, warmup):
                 plan=plan, xs=xs, ts=ts, dt=dt, dev_ms=dev_ms, loss=loss)
 
 
+_REAL_STDOUT = None
+
+
+def claim_stdout():
+    """stdout carries the ONE JSON line and nothing else: libraries print there too (RCCL's
+    version banner at communicator creation, gloo's connection notes) -- everything written
+    to fd 1 from here on goes to stderr, the line itself to the saved descriptor."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -507,6 +529,7 @@ def main():
             sys.stdout.flush()
         sys.exit(rc)
 
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world != args.gpus:
@@ -654,7 +677,7 @@ def main():
             "cpu_model": cpu_model(),
             "torch": torch.__version__,
         }
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":
