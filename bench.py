@@ -390,7 +390,7 @@ def selftest_bench(args, rank, world):
     if rank == 0:
         emit({"metric": "selftest", "value": float(v.item()), "unit": "rank",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "config": {"workload": "selftest (no GPU)", "ranks": ranks}}))
+                          "config": {"workload": "selftest (no GPU)", "ranks": ranks}})
 
 
 def time_training(workload, args, rank, world, dev, steps, warmup):
