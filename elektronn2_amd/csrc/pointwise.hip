@@ -241,6 +241,7 @@ __device__ __forceinline__ void pw_storeN(float* p, int nv, const float (&g)[NO]
     for (int e = 0; e < NO; ++e) if (e < nv) p[e] = g[e];
   }
 }
+constexpr int kMaxParts = 8;      // split-K partial-sum slabs a consumer adds up (e2hip.h)
 template <int PZ, int PY, int PX, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const float* __restrict__ bias,
                                                              int act, View5 out, FastDiv dvw,
@@ -275,12 +276,18 @@ __global__ __launch_bounds__(256) void pool_fwd_fixed_kernel(View5 y, const floa
         float* row = src + a * y.sd + b * y.sh;
         pw_load4(row, nvo * PX, 0.f, w);
         if (nparts > 1) {      // split-K partial sums: add them up, leave the sum in part 0
-          for (int q = 1; q < nparts; ++q) {
-            float u[4];
-            pw_load4(row + q * pstride, nvo * PX, 0.f, u);
+          // (all parts requested before the first add: a load per loop trip cost the
+          // launches of neuro3d's 0.5-2 MB layers 8 dependent round trips, 5.8 us each)
+          float u[kMaxParts - 1][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] += u[e];
-          }
+          for (int q = 1; q < kMaxParts; ++q)
+            if (q < nparts) pw_load4(row + q * pstride, nvo * PX, 0.f, u[q - 1]);
+#pragma unroll
+          for (int q = 1; q < kMaxParts; ++q)
+            if (q < nparts) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] += u[q - 1][e];
+            }
           pw_store4(row, nvo * PX, w);
         }
 #pragma unroll
@@ -339,11 +346,18 @@ __global__ __launch_bounds__(256) void pool_bwd_fixed_kernel(View5 dout, View5 y
       }
     float g[NO];
     pw_loadN<NO>(gbase + (long)zo * dout.sd + (long)yo * dout.sh + xo, nvo, g);
-    for (int q = 1; q < gparts; ++q) {      // dout arrives as split-K partial sums
-      float u[NO];
-      pw_loadN<NO>(gbase + q * gstride + (long)zo * dout.sd + (long)yo * dout.sh + xo, nvo, u);
+    if (gparts > 1) {                       // dout arrives as split-K partial sums
+      float u[kMaxParts - 1][NO];
 #pragma unroll
-      for (int j = 0; j < NO; ++j) g[j] += u[j];
+      for (int q = 1; q < kMaxParts; ++q)
+        if (q < gparts)
+          pw_loadN<NO>(gbase + q * gstride + (long)zo * dout.sd + (long)yo * dout.sh + xo, nvo, u[q - 1]);
+#pragma unroll
+      for (int q = 1; q < kMaxParts; ++q)
+        if (q < gparts) {
+#pragma unroll
+          for (int j = 0; j < NO; ++j) g[j] += u[q - 1][j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < NO; ++j) {
@@ -415,11 +429,17 @@ __global__ __launch_bounds__(256) void act_bwd_out_kernel(View5 dout, View5 out,
 #pragma unroll
       for (int e = 0; e < 4; ++e) { g[e] = e < nv ? gp[e] : 0.f; o[e] = e < nv ? op[e] : 1.f; }
     }
-    for (int q = 1; q < gparts; ++q) {      // dout arrives as split-K partial sums
-      float u[4];
-      pw_load4(gp + q * gstride, nv, 0.f, u);
+    if (gparts > 1) {                       // dout arrives as split-K partial sums
+      float u[kMaxParts - 1][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] += u[e];
+      for (int q = 1; q < kMaxParts; ++q)
+        if (q < gparts) pw_load4(gp + q * gstride, nv, 0.f, u[q - 1]);
+#pragma unroll
+      for (int q = 1; q < kMaxParts; ++q)
+        if (q < gparts) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[e] += u[q - 1][e];
+        }
     }
     if (act == E2_ACT_RELU) {
 #pragma unroll
@@ -937,7 +957,8 @@ extern "C" int e2_pool_bias_act_fwd(e2_ctx* ctx, const e2_tensor5* y, const floa
 extern "C" int e2_pool_bias_act_fwd_parts(e2_ctx* ctx, const e2_tensor5* y, int64_t part_stride,
                                           int nparts, const float* bias, int pz, int py, int px,
                                           int act, const e2_tensor5* out) {
-  E2_REQUIRE(nparts >= 1 && (nparts == 1 || part_stride > 0), "pool_bias_act_fwd_parts: bad parts");
+  E2_REQUIRE(nparts >= 1 && nparts <= kMaxParts && (nparts == 1 || part_stride > 0),
+             "pool_bias_act_fwd_parts: bad parts (1 .. %d)", kMaxParts);
   return pool_fwd_impl(ctx, y, bias, pz, py, px, act, out, nparts, part_stride);
 }
 static int pool_fwd_impl(e2_ctx* ctx, const e2_tensor5* y, const float* bias, int pz, int py,
@@ -1024,8 +1045,8 @@ extern "C" int e2_pool_bias_act_bwd_parts(e2_ctx* ctx, const e2_tensor5* dout,
                                           int px, int act, const e2_tensor5* dy, float* dbias) {
   E2_REQUIRE(ctx, "pool_bias_act_bwd_parts: null ctx");
   E2_REQUIRE(act == E2_ACT_LIN || act == E2_ACT_RELU, "pool_bias_act_bwd_parts: bad act %d", act);
-  E2_REQUIRE(dout_parts >= 1 && (dout_parts == 1 || dout_part_stride > 0),
-             "pool_bias_act_bwd_parts: bad parts");
+  E2_REQUIRE(dout_parts >= 1 && dout_parts <= kMaxParts && (dout_parts == 1 || dout_part_stride > 0),
+             "pool_bias_act_bwd_parts: bad parts (1 .. %d)", kMaxParts);
   return pool_bwd_common(ctx, dout, y, bias, pz, py, px, act, dy, dbias, 0, dout_parts,
                          dout_part_stride);
 }
@@ -1040,8 +1061,8 @@ extern "C" int e2_bias_act_bwd_out_parts(e2_ctx* ctx, const e2_tensor5* dout,
                                          int64_t dout_part_stride, int dout_parts,
                                          const e2_tensor5* out, int act, const e2_tensor5* dy,
                                          float* dbias) {
-  E2_REQUIRE(dout_parts >= 1 && (dout_parts == 1 || dout_part_stride > 0),
-             "bias_act_bwd_out_parts: bad parts");
+  E2_REQUIRE(dout_parts >= 1 && dout_parts <= kMaxParts && (dout_parts == 1 || dout_part_stride > 0),
+             "bias_act_bwd_out_parts: bad parts (1 .. %d)", kMaxParts);
   return act_bwd_out_impl(ctx, dout, out, act, dy, dbias, dout_parts, dout_part_stride);
 }
 static int act_bwd_out_impl(e2_ctx* ctx, const e2_tensor5* dout, const e2_tensor5* out, int act,

@@ -211,6 +211,7 @@ int e2_conv1_pool_act_bwd(e2_ctx*, const e2_tensor5* x, const float* w,
  * tensor anyway adds the parts up on its way:
  *   e2_pool_bias_act_fwd_parts   y = sum of the parts (left in part 0), out = act(pool(y) + b)
  *   e2_pool_bias_act_bwd_parts / e2_bias_act_bwd_out_parts   dout = sum of the parts
+ * (at most 8 parts: a consumer requests every part of an element before it adds them up)
  * Partial sums are added up for the pooling windows (1,1,1), (1,2,2), (2,1,1), (2,2,2). */
 int e2_conv3d_fwd_packed_parts(e2_ctx*, const e2_tensor5* x, const void* wp, int cout, int kd,
                                int kh, int kw, const e2_tensor5* y, int64_t part_stride,
