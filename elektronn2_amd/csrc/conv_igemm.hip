@@ -168,28 +168,16 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobDev* __res
     const int ot = tl_ % nOT, it = tl_ / nOT;
     const int oc0 = ot * 32, ic0 = it * ICT;
     // ---- read: consecutive threads walk the tensor's contiguous axis -----------------
-    // (eight elements per thread with all their loads in flight before the first LDS store:
-    // one load per loop trip made a tile eight dependent round trips, and with a tile per
-    // work-group the launch lasted 37 us for 33 MB on neuro3d)
-    for (int e0 = tid; e0 < 32 * KT; e0 += 256 * 8) {
-      float v[8];
-      int at[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + 256 * u;
-        int ol, k;                                    // local oc, local (ic, source tap)
-        if (oc_major) { ol = pdiv(e, j.dKT); k = e - ol * KT; }
-        else { const int il = pdiv(e, j.d32T); const int r = e - il * (32 * T);
-               ol = pdiv(r, j.dT); k = il * T + (r - ol * T); }
-        const int il = pdiv(k, j.dT), ts = k - il * T;
-        const int oc = oc0 + ol, ic = ic0 + il;
-        v[u] = 0.f;
-        at[u] = e < 32 * KT ? k * 33 + ol : -1;       // (k stride 33: conflict-free both ways)
-        if (at[u] >= 0 && oc < j.Cout && ic < j.Cin) v[u] = j.w[(long)oc * j.wsO + (long)ic * j.wsI + ts];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (at[u] >= 0) tile[at[u]] = v[u];
+    for (int e = tid; e < 32 * KT; e += 256) {
+      int ol, k;                                      // local oc, local (ic, source tap)
+      if (oc_major) { ol = pdiv(e, j.dKT); k = e - ol * KT; }
+      else { const int il = pdiv(e, j.d32T); const int r = e - il * (32 * T);
+             ol = pdiv(r, j.dT); k = il * T + (r - ol * T); }
+      const int il = pdiv(k, j.dT), ts = k - il * T;
+      const int oc = oc0 + ol, ic = ic0 + il;
+      float v = 0.f;
+      if (oc < j.Cout && ic < j.Cin) v = j.w[(long)oc * j.wsO + (long)ic * j.wsI + ts];
+      tile[k * 33 + ol] = v;                          // (k stride 33: conflict-free both ways)
     }
     __syncthreads();
     // ---- write: 32 consecutive output channels per (ic, tap) -------------------------
