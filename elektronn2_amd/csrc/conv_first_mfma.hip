@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
   }
 }
 
-// part[slot][co][T + 1]: taps 0..T-1 (unflipped tap index) and the bias gradient
+// part[co][T + 1][slot]: taps 0..T-1 (unflipped tap index) and the bias gradient, one slot per
+// work-group
 template <int KH, int KW, int PY, int PX, int MG>
 __global__ __launch_bounds__(256) void firstm_bwd_kernel(FirstM p, float* __restrict__ part) {
   using G = Geo<KH, KW, PY, PX, MG>;
@@ -327,9 +328,12 @@ __global__ __launch_bounds__(256) void firstm_bwd_kernel(FirstM p, float* __rest
       if (lane == 0) rw[T] = sb;
     }
   __syncthreads();
-  float* ps = part + (long)blockIdx.x * p.Cout * (T + 1);
+  // slot-major: part[element][slot] -- the reduction reads an element's slots as ONE contiguous
+  // run per wave (first_bwd_reduce_sm_kernel) instead of 64 strided partial sums + atomics
+  float* ps = part + blockIdx.x;
+  const long nS = gridDim.x;
   for (int e = threadIdx.x; e < p.Cout * (T + 1); e += 256)
-    ps[e] = (red[e] + red[CH * (T + 1) + e]) + (red[2 * CH * (T + 1) + e] + red[3 * CH * (T + 1) + e]);
+    ps[e * nS] = (red[e] + red[CH * (T + 1) + e]) + (red[2 * CH * (T + 1) + e] + red[3 * CH * (T + 1) + e]);
 }
 
 template <int KH, int KW, int PY, int PX, int MG>
