@@ -67,6 +67,7 @@ def _load():
         "e2_pack_job_bytes": (sz, []),
         "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
         "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
+        "e2_conv3d_pack_multi_ex": (C.c_int, [vp, vp, i, i]),
         "e2_head_supported": (C.c_int, [i, i]),
         "e2_head_fwd": (C.c_int, [vp, P5, fp, fp, i, P5, P5, fp]),
         "e2_head_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
@@ -425,11 +426,14 @@ class Context:
             _chk(_lib.e2_pack_job_fill(C.byref(buf, n * rec), _fp(w), C.c_void_p(wp.data_ptr()),
                                        cout, cin, kd, kh, kw, mode), "e2_pack_job_fill")
         host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
-        return host.to(self.device), len(jobs)
+        dev = host.to(self.device)
+        dev.max_taps = max(int(w.shape[2] * w.shape[3] * w.shape[4]) for w, _, _ in jobs)
+        return dev, len(jobs)
 
     def conv3d_pack_multi(self, jobs_dev, njobs):
-        _chk(_lib.e2_conv3d_pack_multi(self.h, C.c_void_p(jobs_dev.data_ptr()), njobs),
-             "e2_conv3d_pack_multi")
+        _chk(_lib.e2_conv3d_pack_multi_ex(self.h, C.c_void_p(jobs_dev.data_ptr()), njobs,
+                                          int(getattr(jobs_dev, 'max_taps', 248))),
+             "e2_conv3d_pack_multi_ex")
 
     # ---- fused first layer ----------------------------------------------------
     @staticmethod

@@ -140,7 +140,9 @@ __host__ __device__ inline int e2_pack_ict(int T) {
   return ict < 1 ? 1 : ict;
 }
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobDev* __restrict__ jobs) {
-  __shared__ float tile[kPackTileFloats];
+  // (dynamic: 33 * (32 + largest tap volume) floats, e2_conv3d_pack_multi_ex -- with the full
+  // 32 KB only five work-groups fit a CU)
+  extern __shared__ __attribute__((aligned(16))) float tile[];
   const PackJobDev j = jobs[blockIdx.y];
   if (j.up) {
     // UpConv (one tap, Wp[cg][qd][oc']): the whole image, as pack_weights_kernel writes it
@@ -240,14 +242,20 @@ extern "C" int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, i
 }
 
 extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs) {
-  E2_REQUIRE(ctx && jobs_dev && njobs > 0 && njobs < 65536, "pack_multi: bad argument");
-  // (tap volumes whose tile would not fit the static LDS buffer -- beyond 5x5x5 -- are not
-  // used by any net here; such a job list takes the plain gather kernel)
+  return e2_conv3d_pack_multi_ex(ctx, jobs_dev, njobs, 248);
+}
+
+/* max_taps: the largest kd * kh * kw among the jobs (<= 248) -- sizes the launch's LDS tile
+ * (tile[k * 33 + oc], k < ICT * T < 32 + T), so that more work-groups share a CU */
+extern "C" int e2_conv3d_pack_multi_ex(e2_ctx* ctx, const void* jobs_dev, int njobs, int max_taps) {
+  E2_REQUIRE(ctx && jobs_dev && njobs > 0 && njobs < 65536 && max_taps > 0 && max_taps <= 248,
+             "pack_multi: bad argument");
+  const size_t lds = sizeof(float) * std::min<size_t>(kPackTileFloats, 33 * (size_t)(32 + max_taps));
   if (e2_dbg_env("E2_PACK_GATHER"))
     hipLaunchKernelGGL(pack_multi_gather_kernel, dim3(256, njobs), dim3(256), 0, ctx->stream,
                        (const PackJobDev*)jobs_dev);
   else
-    hipLaunchKernelGGL(pack_multi_kernel, dim3(512, njobs), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(512, njobs), dim3(256), lds, ctx->stream,
                        (const PackJobDev*)jobs_dev);
   E2_CHECK_HIP(hipGetLastError());
   return 0;

@@ -179,6 +179,8 @@ size_t e2_pack_job_bytes(void);
 int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin,
                      int kd, int kh, int kw, int mode);
 int e2_conv3d_pack_multi(e2_ctx*, const void* jobs_dev, int njobs);
+/* the same with the launch's LDS tile sized for the largest kd * kh * kw among the jobs */
+int e2_conv3d_pack_multi_ex(e2_ctx*, const void* jobs_dev, int njobs, int max_taps);
 
 /* ---- first layer, fused (Conv node on a 1-channel input: conv -> pool -> +b ->
  *      act in one pass; neural.py:662-712).  Supported: kd = 1, pool z = 1 and
