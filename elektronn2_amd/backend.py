@@ -72,10 +72,10 @@ def _load():
         "e2_head_fwd": (C.c_int, [vp, P5, fp, fp, i, P5, P5, fp]),
         "e2_head_bwd_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
         "e2_tail_supported": (C.c_int, [i, i, i]),
-        "e2_tail_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i]),
-        "e2_tail_fwd_bwd": (C.c_int, [vp, P5, fp, fp, fp, i, fp, fp, i, P5, P5, P5, P5, fp,
+        "e2_tail_workspace_bytes": (C.c_size_t, [i, i, i, i, i, i, i]),
+        "e2_tail_fwd_bwd": (C.c_int, [vp, P5, fp, fp, fp, i, fp, fp, i, P5, P5, P5, P5, i, P5, fp, fp,
                                       C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
-        "e2_tail_reduce": (C.c_int, [vp, C.c_void_p, i, i, i, fp, fp, fp, fp, fp]),
+        "e2_tail_reduce": (C.c_int, [vp, C.c_void_p, i, i, i, fp, fp, fp, fp, fp, i, fp]),
         "e2_head_bwd": (C.c_int, [vp, P5, fp, P5, P5, fp, P5, i, fp, fp, fp, C.c_void_p,
                                   C.c_size_t]),
         "e2_malis_loss_weights": (C.c_int, [i, C.c_void_p, i, C.c_void_p, C.c_void_p,
@@ -380,27 +380,34 @@ class Context:
 
     @staticmethod
     def tail_ws_bytes(x_shape, c2, ncls):
-        n, _, d, h, w = (int(v) for v in x_shape)
-        return int(_lib.e2_tail_workspace_bytes(n, int(c2), int(ncls), d, h, w))
+        n, c1, d, h, w = (int(v) for v in x_shape)
+        return int(_lib.e2_tail_workspace_bytes(n, c1, int(c2), int(ncls), d, h, w))
 
     def tail_fwd_bwd(self, x, wp_fwd, wp_dgrad, bias1, w_head, b_head, target, probs, dpre, dx,
-                     stats, ws):
+                     stats, ws, gm_mode=0, gm_src=None, gm_bias=None):
         """csrc/tail.hip: forward and backward of [1x1x1 conv + bias + relu] -> [classifier
-        head] in one launch; returns the number of partial-sum slots written to ``ws``"""
+        head] in one launch; returns the number of partial-sum slots written to ``ws``.
+        ``gm_mode``: dx goes through the activation backward of the layer that produced x
+        (1: slope from ``gm_src`` = its activated output, 2: from ``gm_src`` = its
+        pre-activation + ``gm_bias``, 3: linear) and that layer's bias gradient joins the slots"""
         n_slots = C.c_int(0)
         _chk(_lib.e2_tail_fwd_bwd(self.h, C.byref(t5(x)), _fp(wp_fwd), _fp(wp_dgrad), _fp(bias1),
                                   dpre.shape[1], _fp(w_head), _fp(b_head), probs.shape[1],
                                   C.byref(t5(target)), C.byref(t5(probs)), C.byref(t5(dpre)),
-                                  C.byref(t5(dx)) if dx is not None else None, _fp(stats),
+                                  C.byref(t5(dx)) if dx is not None else None, int(gm_mode),
+                                  C.byref(t5(gm_src)) if gm_src is not None else None,
+                                  _fp(gm_bias), _fp(stats),
                                   C.c_void_p(ws.data_ptr()), ws.numel() * 4, C.byref(n_slots)),
              "e2_tail_fwd_bwd")
         return int(n_slots.value)
 
-    def tail_reduce(self, ws, n_slots, c2, ncls, dw_head, db_head, db1, stats, loss_out):
+    def tail_reduce(self, ws, n_slots, c2, ncls, dw_head, db_head, db1, stats, loss_out,
+                    db_parent=None):
         _chk(_lib.e2_tail_reduce(self.h, C.c_void_p(ws.data_ptr()), int(n_slots), int(c2),
                                  int(ncls), _fp(dw_head), _fp(db_head), _fp(db1), _fp(stats),
-                                 _fp(loss_out) if loss_out is not None else None),
-             "e2_tail_reduce")
+                                 _fp(loss_out) if loss_out is not None else None,
+                                 0 if db_parent is None else int(db_parent.numel()),
+                                 _fp(db_parent)), "e2_tail_reduce")
 
     def conv3d_wgrad(self, x, dy, dw, accumulate=False):
         kd, kh, kw = dw.shape[2:]

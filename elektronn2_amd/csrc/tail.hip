@@ -61,7 +61,15 @@ struct TailP {
   const float* tg; long tsN;         // target [N][1][S]
   float* pr; long psN, psC;          // probabilities [N][ncls][S]
   float* dpre; long dsN, dsC;        // gradient of the 1x1x1 layer's pre-activation [N][C2][S]
-  float* dx; long gsN, gsC;          // gradient of x [N][C1][S], or nullptr
+  float* dx; long gsN, gsC, gsD, gsH; // gradient of x [N][C1][D][H][W] (any row / plane pitch), or nullptr
+  int H, W;                          // plane extents (position s -> z, y, x for dx's strides)
+  // dx is written THROUGH the activation backward of the layer that produced x (gm != 0): out =
+  // dx * act'(.), and the row sums (that layer's bias gradient) go to the slot.  gm = 1: slope
+  // from gm_src = that layer's activated output (a zero's sign tells 0.5 from 0), 2: from gm_src
+  // = its pre-activation + gm_bias[row], 3: linear activation (slope 1)
+  int gm;
+  const float* gm_src; long msN, msC;
+  const float* gm_bias;
   float* part;                       // [PSZ][work-groups] partial sums (an element's slots contiguous)
   float* stats;                      // [0] loss sum (written by the reduce kernel), [1] #labelled
   int zero_wb;                       // 1: whole chunks of K reach past a packed image's rows
@@ -111,7 +119,8 @@ constexpr size_t tail_lds_bytes() {
                                   (NC + 1) * kRows);
 }
 
-__host__ __device__ inline int tail_psz(int nc, int c2) { return nc * c2 + nc + c2 + 1; }
+// slot elements: dWh [nc][c2], dbh [nc], db1 [c2], loss sum, then (gm) the parent's bias gradient [c1]
+__host__ __device__ inline int tail_psz(int nc, int c2, int c1gm = 0) { return nc * c2 + nc + c2 + 1 + c1gm; }
 
 template <int WM, int NC, int KC>
 __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
@@ -442,10 +451,45 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     }
   }
   __syncthreads();
-  if (pp < np) {
-    float* gb = p.dx + (long)n * p.gsN + s0 + pp;
+  {
+    const int sp = s0 + min(pp, np - 1);
+    const int z = sp / (p.H * p.W), rem = sp - z * (p.H * p.W);
+    const int y = rem / p.W, xx = rem - y * p.W;
+    float* gb = p.dx + (long)n * p.gsN + (long)z * p.gsD + (long)y * p.gsH + xx;
+    if (p.gm == 0) {
+      if (pp < np) {
 #pragma unroll 10
-    for (int r = pq; r < p.C1; r += NQ) gb[(long)r * p.gsC] = T[r * NPP + pp];
+        for (int r = pq; r < p.C1; r += NQ) gb[(long)r * p.gsC] = T[r * NPP + pp];
+      }
+    } else {
+      // through the producing layer's activation backward; its bias gradient = the row sums,
+      // reduced over the NP lanes of a row (each lane holds ONE position of the row)
+      const float* sb = p.gm_src ? p.gm_src + (long)n * p.msN + s0 + min(pp, np - 1) : nullptr;
+      float* red = WB;                           // [C1] row sums (the weight buffers are free)
+      constexpr int NR = kRows / NQ;
+#pragma unroll 2
+      for (int j = 0; j < NR; ++j) {
+        const int r = pq + j * NQ;               // (uniform per NP lanes)
+        float d = 0.f;
+        if (r < p.C1 && pp < np) {
+          d = T[r * NPP + pp];
+          if (p.gm == 1) {
+            const float o = sb[(long)r * p.msC];
+            d *= (o > 0.f) ? 1.f : (__builtin_signbit(o) ? 0.f : 0.5f);
+          } else if (p.gm == 2) {
+            const float o = sb[(long)r * p.msC] + p.gm_bias[r];
+            d *= (o > 0.f) ? 1.f : ((o == 0.f) ? 0.5f : 0.f);
+          }
+          gb[(long)r * p.gsC] = d;
+        }
+#pragma unroll
+        for (int o = NP / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (pp == 0 && r < p.C1) red[r] = d;
+      }
+      __syncthreads();
+      if (tid < p.C1)
+        p.part[((long)(NC * p.C2 + NC + p.C2 + 1) + tid) * gridDim.x + blockIdx.x] = red[tid];
+    }
   }
   TAIL_STAMP(10);
 }
@@ -472,8 +516,8 @@ __global__ __launch_bounds__(256) void tail_count_kernel(const float* tg, long t
 __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restrict__ part, int nWG,
                                                           int nc, int c2, float* dwh, float* dbh,
                                                           float* db1, float* stats, float* loss_out,
-                                                          float* count_out) {
-  const int psz = tail_psz(nc, c2);
+                                                          float* count_out, int c1gm, float* dbp) {
+  const int psz = tail_psz(nc, c2, c1gm);
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= psz) return;
   const float* row = part + (long)idx * nWG;
@@ -482,14 +526,15 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(const float* __restric
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane != 0) return;
-  if (idx == psz - 1) {
+  if (idx == nc * c2 + nc + c2) {
     stats[0] = s;
     if (loss_out) loss_out[0] = s / (stats[1] + E2_EPS_NLL);
     if (count_out) count_out[0] = stats[1];
     return;
   }
-  float* dst = idx < nc * c2 ? dwh + idx : (idx < nc * c2 + nc ? dbh + (idx - nc * c2)
-                                                                : db1 + (idx - nc * c2 - nc));
+  float* dst = idx < nc * c2 ? dwh + idx
+             : (idx < nc * c2 + nc ? dbh + (idx - nc * c2)
+             : (idx < nc * c2 + nc + c2 ? db1 + (idx - nc * c2 - nc) : dbp + (idx - nc * c2 - nc - c2 - 1)));
   *dst += s;
 }
 
@@ -566,30 +611,40 @@ extern "C" int e2_tail_supported(int c1, int c2, int ncls) {
   return ncls >= 2 && ncls <= 4 && c1 >= 1 && c1 <= kRows && c2 >= 1 && c2 <= kRows;
 }
 
-extern "C" size_t e2_tail_workspace_bytes(int n, int c2, int ncls, int d, int h, int w) {
+extern "C" size_t e2_tail_workspace_bytes(int n, int c1, int c2, int ncls, int d, int h, int w) {
   const long S = (long)d * h * w;
-  return sizeof(float) * (size_t)tail_grid(n, S, 4) * (size_t)tail_psz(ncls, c2);   // (WM = 4: most slots)
+  return sizeof(float) * (size_t)tail_grid(n, S, 4) * (size_t)tail_psz(ncls, c2, c1);   // (WM = 4: most slots)
 }
 
 /* forward AND backward of [1x1x1 conv c1 -> c2, bias, relu] -> [classifier head] in one launch
  * (replaces e2_conv3d_fwd_packed_act + e2_head_fwd + e2_head_bwd + e2_bias_act_bwd_out +
  * e2_conv3d_dgrad_packed of those two layers).  wp_fwd / wp_dgrad: the 1x1x1 layer's packed
  * images (e2_conv3d_pack modes 0 / 1).  Writes probs, dpre (gradient of the layer's
- * pre-activation, dense [n][c2][positions]), dx (optional), stats[1] = #labelled, and one slot
- * of partial sums per work-group to ws; e2_tail_reduce adds those up. */
+ * pre-activation, dense [n][c2][positions]), dx (optional, any row / plane pitch), stats[1] =
+ * #labelled, and one slot of partial sums per work-group to ws; e2_tail_reduce adds those up.
+ * gm_mode != 0: dx goes THROUGH the activation backward of the layer that produced x -- dx *=
+ * act'(.), that layer's bias gradient (row sums) joins the slots: 1 = relu slope from gm_src = its
+ * activated output (signed zeros, e2_conv3d_fwd_packed_act), 2 = from gm_src = its pre-activation
+ * + gm_bias, 3 = linear. */
 extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp_fwd,
                                const float* wp_dgrad, const float* bias1, int c2,
                                const float* w_head, const float* b_head, int ncls,
                                const e2_tensor5* target, const e2_tensor5* probs,
-                               const e2_tensor5* dpre, const e2_tensor5* dx, float* stats,
+                               const e2_tensor5* dpre, const e2_tensor5* dx, int gm_mode,
+                               const e2_tensor5* gm_src, const float* gm_bias, float* stats,
                                void* ws, size_t ws_bytes, int* n_slots) {
   E2_REQUIRE(ctx && x && wp_fwd && bias1 && w_head && b_head && target && probs && dpre &&
                  stats && ws && n_slots, "tail: null argument");
   E2_REQUIRE(!dx || wp_dgrad, "tail: the data gradient needs its packed image");
   E2_REQUIRE(e2_tail_supported(x->c, c2, ncls), "tail: unsupported c1=%d c2=%d ncls=%d", x->c, c2, ncls);
   E2_REQUIRE(!ctx->mfma_bf16, "tail: an f32 kernel, not offered in bf16 mode");
-  E2_REQUIRE(flat_sp(x) && flat_sp(target) && flat_sp(probs) && flat_sp(dpre) && (!dx || flat_sp(dx)),
+  E2_REQUIRE(flat_sp(x) && flat_sp(target) && flat_sp(probs) && flat_sp(dpre),
              "tail: tensors need dense (z, y, x) planes");
+  E2_REQUIRE(gm_mode >= 0 && gm_mode <= 3 && (gm_mode == 0 || dx), "tail: bad gm_mode %d", gm_mode);
+  E2_REQUIRE((gm_mode != 1 && gm_mode != 2) ||
+                 (gm_src && flat_sp(gm_src) && same_sp(x, gm_src) && gm_src->c == x->c),
+             "tail: gm_src must be a dense tensor of x's shape");
+  E2_REQUIRE(gm_mode != 2 || gm_bias, "tail: gm_mode 2 needs the producing layer's bias");
   E2_REQUIRE(same_sp(x, target) && same_sp(x, probs) && same_sp(x, dpre) && (!dx || same_sp(x, dx)) &&
                  target->c == 1 && probs->c == ncls && dpre->c == c2 && (!dx || dx->c == x->c),
              "tail: shape mismatch");
@@ -604,7 +659,13 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   p.tg = target->ptr; p.tsN = target->sn;
   p.pr = probs->ptr; p.psN = probs->sn; p.psC = probs->sc;
   p.dpre = dpre->ptr; p.dsN = dpre->sn; p.dsC = dpre->sc;
-  p.dx = dx ? dx->ptr : nullptr; p.gsN = dx ? dx->sn : 0; p.gsC = dx ? dx->sc : 0;
+  p.dx = dx ? dx->ptr : nullptr;
+  if (dx) { p.gsN = dx->sn; p.gsC = dx->sc; p.gsD = dx->sd; p.gsH = dx->sh; }
+  p.H = x->h; p.W = x->w;
+  p.gm = gm_mode;
+  p.gm_src = (gm_mode == 1 || gm_mode == 2) ? gm_src->ptr : nullptr;
+  if (p.gm_src) { p.msN = gm_src->sn; p.msC = gm_src->sc; }
+  p.gm_bias = gm_bias;
   p.part = (float*)ws; p.stats = stats; p.sum_mode = ctx->loss_sum_mode;
   p.N = x->n; p.C1 = x->c; p.C2 = c2; p.S = (int)S;
   p.nTarget = (long)x->n * S;
@@ -613,7 +674,8 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   const long grid = tail_grid(x->n, S, wm);
   p.tilesPerN = (int)(grid / x->n);
   E2_REQUIRE(grid < (1L << 31), "tail: grid too large");
-  E2_REQUIRE(ws_bytes >= sizeof(float) * (size_t)grid * tail_psz(ncls, c2), "tail: workspace too small");
+  E2_REQUIRE(ws_bytes >= sizeof(float) * (size_t)grid * tail_psz(ncls, c2, gm_mode ? x->c : 0),
+             "tail: workspace too small");
   *n_slots = (int)grid;
   p.zero_wb = (e2_cdiv(p.C1, kc) * kc > p.ciPf || e2_cdiv(p.C2, kc) * kc > p.ciPd) ? 1 : 0;
   p.count_here = p.nTarget <= (1L << 16) ? 1 : 0;
@@ -643,12 +705,13 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
  * them first), stats[0] = loss sum, loss_out (optional) = stats[0] / (stats[1] + 1e-5). */
 extern "C" int e2_tail_reduce(e2_ctx* ctx, const void* ws, int n_slots, int c2, int ncls,
                               float* dw_head, float* db_head, float* db1, float* stats,
-                              float* loss_out) {
+                              float* loss_out, int c1_gm, float* db_parent) {
   E2_REQUIRE(ctx && ws && dw_head && db_head && db1 && stats && n_slots > 0, "tail_reduce: bad argument");
-  const int psz = tail_psz(ncls, c2);
+  E2_REQUIRE(c1_gm >= 0 && (c1_gm == 0 || db_parent), "tail_reduce: the parent's bias gradient is missing");
+  const int psz = tail_psz(ncls, c2, c1_gm);
   hipLaunchKernelGGL(tail_reduce_kernel, dim3(e2_cdiv(psz, 4)), dim3(256), 0,
                      ctx->stream, (const float*)ws, n_slots, ncls, c2, dw_head, db_head, db1, stats,
-                     loss_out, ctx->loss_count_out);
+                     loss_out, ctx->loss_count_out, c1_gm, db_parent);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -150,12 +150,19 @@ class MultinoulliNLL(Node):
             par = tail.parent
             plan.join_side()
             dx = plan.grad[par] if plan.needs_grad(par) else None
+            gm = tail._tail_gm(plan) if dx is not None else None
+            kw = {}
+            if gm is not None:
+                # the parent's activation backward rides along: the launch writes the parent's
+                # zero-padded gradient buffer (interior) and its bias gradient's slots
+                dx = plan.scratch[par, 'dy']
+                kw = dict(gm_mode=gm[0], gm_src=gm[1], gm_bias=gm[2])
             with plan.loss_grad_mode():
                 plan.scratch[self, 'tail_slots'] = plan.ctx.tail_fwd_bwd(
                     plan.out[par], plan.scratch[tail, 'wp_f'], plan.scratch.get((tail, 'wp_d')),
                     plan.param(tail.b), plan.param(head.w).reshape(head.n_f, -1),
                     plan.param(head.b), plan.out[self.target], plan.out[self.pred],
-                    plan.scratch[tail, 'dy'], dx, stats, plan.scratch[tail, 'tail_ws'])
+                    plan.scratch[tail, 'dy'], dx, stats, plan.scratch[tail, 'tail_ws'], **kw)
             return
         plan.zero_early(stats)
         head = self.pred._head(plan)
@@ -175,10 +182,13 @@ class MultinoulliNLL(Node):
         tail = self._tail(plan)
         if tail is not None:
             # (behind the zero fill of the gradient arena: the slots are ADDED into it)
+            par = tail.parent
+            gm = tail._tail_gm(plan) if plan.needs_grad(par) else None
             plan.ctx.tail_reduce(plan.scratch[tail, 'tail_ws'], plan.scratch[self, 'tail_slots'],
                                  tail.n_f, head.n_f, plan.pgrad(head.w).reshape(head.n_f, -1),
                                  plan.pgrad(head.b), plan.pgrad(tail.b),
-                                 plan.scratch[self.pred, 'stats'], plan.scratch[self, 'loss'])
+                                 plan.scratch[self.pred, 'stats'], plan.scratch[self, 'loss'],
+                                 db_parent=plan.pgrad(par.b) if gm is not None else None)
             return
         if head is not None:
             dst, first = (plan.grad_slot(head.parent) if plan.needs_grad(head.parent)

@@ -388,6 +388,28 @@ class Conv(NeuralLayer):
             plan.scratch[key] = r
         return plan.scratch[key]
 
+    def _tail_gm(self, plan):
+        """the tail launch of this node can carry the activation backward of its PARENT (which
+        feeds only this node -- Conv._tail): a plain Conv without pooling / batch norm, relu or
+        lin, with gradient buffers of its own.  Returns (mode, src tensor, bias) for
+        e2_tail_fwd_bwd or None (the launch writes the parent's plain output gradient)."""
+        import os
+        par = self.parent
+        if not (os.environ.get('E2_TAIL_GM', '1') == '1' and type(par) is Conv and not par._bn()
+                and all(p == 1 for p in par._p3) and par.activation_func in ('relu', 'lin')
+                and (par, 'dy') in plan.scratch and not par._fused_first(plan)
+                and par._fused_head(plan) is None and par._tail(plan) is None
+                and not par._mfp_pool() and plan.needs_grad(par)):
+            return None
+        if par.activation_func == 'lin':
+            return (3, None, None)
+        if par._fused_act(plan):
+            return (1, plan.out[par], None)            # activated output, signed zeros
+        y = plan.scratch.get((par, 'y'))
+        if y is None or not y.is_contiguous():
+            return None
+        return (2, y, plan.param(par.b))               # pre-activation (+ bias)
+
     def _fused_act(self, plan):
         """no pooling and a specialised kernel width: bias + activation go into the
         conv kernel's epilogue, the pre-activation is never stored"""
@@ -604,6 +626,8 @@ class Conv(NeuralLayer):
             # and the slots the NLL node's reduction has added into the bias gradient
             if plan.needs_grad(self.parent):
                 plan.grad_slot(self.parent)
+                if self._tail_gm(plan) is not None:    # ... through its activation backward
+                    plan.scratch[self.parent, 'dy_done'] = True
         elif self._bn():
             train = self.batch_normalisation == 'train'
             pooled = any(p != 1 for p in self._p3)

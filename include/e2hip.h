@@ -346,14 +346,23 @@ int e2_head_bwd(e2_ctx*, const e2_tensor5* x, const float* w, const e2_tensor5* 
  *      zero those first -- and writes stats[0] = sum of -log(p_t + 1e-5) and loss_out =
  *      stats[0] / (stats[1] + 1e-5).  f32 mode only. ------------------------------------ */
 int e2_tail_supported(int c1, int c2, int ncls);
-size_t e2_tail_workspace_bytes(int n, int c2, int ncls, int d, int h, int w);
+size_t e2_tail_workspace_bytes(int n, int c1, int c2, int ncls, int d, int h, int w);
+/* gm_mode != 0: dx is written THROUGH the activation backward of the layer that produced x
+ * (e2_bias_act_bwd_out / e2_pool_bias_act_bwd with a (1,1,1) window): dx *= act'(.), and that
+ * layer's bias gradient (the row sums) joins the slots (e2_tail_reduce: c1_gm = c1, db_parent);
+ * dx may then be the interior of that layer's zero-padded gradient buffer (any row / plane
+ * pitch).  1: relu slope read off gm_src = its activated output (signed zeros, as
+ * e2_conv3d_fwd_packed_act stores them), 2: off gm_src = its pre-activation + gm_bias[c],
+ * 3: linear activation. */
 int e2_tail_fwd_bwd(e2_ctx*, const e2_tensor5* x, const float* wp_fwd, const float* wp_dgrad,
                     const float* bias1, int c2, const float* w_head, const float* b_head,
                     int ncls, const e2_tensor5* target, const e2_tensor5* probs,
-                    const e2_tensor5* dpre, const e2_tensor5* dx, float* stats, void* ws,
+                    const e2_tensor5* dpre, const e2_tensor5* dx, int gm_mode,
+                    const e2_tensor5* gm_src, const float* gm_bias, float* stats, void* ws,
                     size_t ws_bytes, int* n_slots);
 int e2_tail_reduce(e2_ctx*, const void* ws, int n_slots, int c2, int ncls, float* dw_head,
-                   float* db_head, float* db1, float* stats, float* loss_out);
+                   float* db_head, float* db1, float* stats, float* loss_out, int c1_gm,
+                   float* db_parent);
 
 /* probs = softmax_c(logits); loss_sum += sum_pos -log(p[target]+1e-5);
  * n_lab += #labelled (target in [0,C)).  stats = {loss_sum, n_lab} must be

@@ -991,6 +991,36 @@ def test_fused_tail(ctx, c1, c2, ncls, N, sp):
     assert relerr(dbh - 2.0, dbh_ref) < 1e-4
     assert relerr(db1 - 3.0, db1_ref) < 1e-4
     assert np.abs(dpre_ref[:, 3]).max() > 0                          # the slope-0.5 unit is live
+    # dx THROUGH the activation backward of the layer that produced x, into the interior of that
+    # layer's zero-padded gradient buffer (row pitch W + 2, two border planes), its bias gradient
+    # from the slots: relu slope off the activated output (mode 1: signed zeros), off the
+    # pre-activation + bias (mode 2), linear (mode 3)
+    pre0 = rng.randn(N, c1, *sp).astype(np.float32)
+    pre0[:, 1] = 0.0                                             # units at exactly zero
+    b0 = (rng.randn(c1) / 4).astype(np.float32); b0[1] = 0.0
+    x0 = O.bias_act_fwd(pre0, b0, 'relu')                        # what the layer before emits
+    signed = np.where(pre0 + b0.reshape(1, -1, 1, 1, 1) < 0, np.float32(-0.0), x0).astype(np.float32)
+    pre_b = O.conv3d_fwd(x0, w1)
+    h_b = O.bias_act_fwd(pre_b, b1, 'relu')
+    lg_b = O.conv3d_fwd(h_b, wh) + bh.reshape(1, -1, 1, 1, 1)
+    _, dlog_b, _ = O.nll_loss_and_grad(lg_b, t)
+    dpre_b, _ = O.bias_act_bwd(O.conv3d_dgrad(dlog_b, wh, h_b.shape), pre_b, b1, 'relu')
+    dx_b = O.conv3d_dgrad(dpre_b, w1, x0.shape)
+    for mode in (1, 2, 3):
+        dy0_ref, db0_ref = O.bias_act_bwd(dx_b, pre0, b0, 'lin' if mode == 3 else 'relu')
+        padded = torch.zeros((N, c1, sp[0] + 2, sp[1], sp[2] + 2), device="cuda")
+        view = padded[:, :, 1:-1, :, 1:-1]
+        src = {1: dev(signed), 2: dev(pre0), 3: None}[mode]
+        ns3 = ctx.tail_fwd_bwd(dev(x0), wpf, wpd, dev(b1), whd, dev(bh), dev(t), probs, dpre, view,
+                               stats, ws, gm_mode=mode, gm_src=src,
+                               gm_bias=dev(b0) if mode == 2 else None)
+        dbp = torch.full((c1,), 5.0, device="cuda")
+        dwh.zero_(); dbh.zero_(); db1.zero_()
+        ctx.tail_reduce(ws, ns3, c2, ncls, dwh, dbh, db1, stats, loss, db_parent=dbp)
+        assert relerr(view, dy0_ref) < TOL, mode
+        assert relerr(dbp - 5.0, db0_ref) < 1e-4, mode
+        assert float(padded[:, :, 0].abs().max()) == 0.0 and float(padded[..., 0].abs().max()) == 0.0
+        assert relerr(dpre, dpre_b) < TOL
     # no data gradient wanted (the 1x1x1 layer directly on an input): dx = None
     dpre2 = torch.full_like(dpre, float("nan"))
     ns2 = ctx.tail_fwd_bwd(dev(x), wpf, None, dev(b1), whd, dev(bh), dev(t), probs, dpre2, None,
