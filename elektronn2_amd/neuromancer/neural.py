@@ -627,7 +627,7 @@ class Conv(NeuralLayer):
             if plan.needs_grad(self.parent):
                 plan.grad_slot(self.parent)
                 if self._tail_gm(plan) is not None:    # ... through its activation backward
-                    plan.scratch[self.parent, 'dy_done'] = True
+                    plan.scratch[self.parent, 'dy_by_tail'] = True
         elif self._bn():
             train = self.batch_normalisation == 'train'
             pooled = any(p != 1 for p in self._p3)
@@ -640,8 +640,9 @@ class Conv(NeuralLayer):
                                   plan.pgrad(self.b))
             if pooled:
                 ctx.maxpool3d_bwd(dlin, plan.scratch[self, 'y'], self._p3, dy)
-        elif plan.scratch.get((self, 'dy_done')):
-            pass        # the consumer's data-gradient launch wrote dy and dbias (below)
+        elif plan.scratch.get((self, 'dy_done')) or plan.scratch.get((self, 'dy_by_tail')):
+            pass        # the consumer's data-gradient launch (below) or the tail launch
+                        # (Conv._tail_gm) wrote dy and dbias
         elif self._fused_act(plan):
             gn = plan.scratch.get((self, 'grad_nparts'), 1)
             if gn > 1:
