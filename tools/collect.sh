@@ -1,5 +1,5 @@
 #!/bin/bash
-# every number DESIGN.md / README.md quote, in one go (GPU box): tools/r3_collect.sh <tag>
+# every number DESIGN.md / README.md quote, in one go (GPU box): tools/collect.sh <tag>
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/${1:-collect}
