@@ -122,9 +122,13 @@ def test_unet3d_valid_patch_sizes_and_refusal():
         nets.unet3d((None, 1, 96, 100, 100))
 
 
-# bounds of the same-decisions comparison of the bf16 U-Net step (measured values in the test's
-# docstring / printout; set after the first run on the GPU)
-BF16_SAME_LOSS, BF16_SAME_ELEM, BF16_SAME_COS = 1e-2, 0.3, 0.98
+# bounds of the same-decisions comparison of the bf16 U-Net step.  Measured (round 4): worst
+# tensor 0.0139 of its largest element (conv8_w), lowest cosine 0.999931 (conv6_w), loss 5.9e-7
+# -- against 0.240 / 0.98349 with the decisions left free: the distance there is decisions, not
+# arithmetic.  (A float64 evaluation that also rounds every GEMM operand to bf16 would bound the
+# summation-order error alone, as the op tests do at 2e-5; it needs the library to report which
+# launches ran in their bf16 form -- tilings without one run in f32 -- and was not built.)
+BF16_SAME_LOSS, BF16_SAME_ELEM, BF16_SAME_COS = 1e-4, 0.03, 0.9995
 
 
 @pytest.fixture()
