@@ -255,8 +255,8 @@ extern "C" int e2_conv3d_pack_multi_ex(e2_ctx* ctx, const void* jobs_dev, int nj
     hipLaunchKernelGGL(pack_multi_gather_kernel, dim3(256, njobs), dim3(256), 0, ctx->stream,
                        (const PackJobDev*)jobs_dev);
   else
-    hipLaunchKernelGGL(pack_multi_kernel, dim3(512, njobs), dim3(256), lds, ctx->stream,
-                       (const PackJobDev*)jobs_dev);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(e2_dbg_env("E2_PACK_GRID") ? e2_dbg_env_int("E2_PACK_GRID") : 512, njobs),
+                       dim3(256), lds, ctx->stream, (const PackJobDev*)jobs_dev);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
