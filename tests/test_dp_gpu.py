@@ -97,6 +97,96 @@ def test_two_rank_step_overlapped_exchange():
             off += (ref.size + 3) // 4 * 4
 
 
+def _ragged_data(rank):
+    """rank 0: every voxel labelled; rank 1: three quarters unlabelled"""
+    x, t = _data(rank)
+    if rank == 1:
+        rng = np.random.RandomState(99)
+        t = t.copy()
+        t[rng.rand(*t.shape) < 0.75] = -1
+    return x, t
+
+
+def _ragged_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), LOCAL_RANK="0")
+    from elektronn2_amd import nets, neuromancer as nm, parallel
+    assert parallel.init_from_env("gloo") == world
+    x, t = _ragged_data(rank)
+    out = {}
+    for fused in ("1", "0"):
+        os.environ["E2_DP_FUSED_SCALE"] = fused
+        nm.model_manager.reset()
+        m = nets.neuro3d_lite((None, 1) + SP, params=O.init_net(O.NEURO3D_LITE, 1, seed=5))
+        m.set_opt_meta_params('SGD', dict(lr=1e-2, mom=0.9, wd=0.0))
+        m.loss(x, t)
+        m.enable_data_parallel()
+        losses = [float(m.trainingstep(x, t, optimiser='SGD')[0]) for _ in range(2)]
+        plan = m.optimisers['SGD'].step.func
+        out[fused] = dict(P=m.P.cpu().numpy().copy(), losses=losses, scale=plan._dp_scale(),
+                          g_after=float(m.G.abs().max()))
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_with_ragged_label_counts():
+    """The reference normalises the NLL by the labelled voxels of the WHOLE batch
+    (loss.py:342-344).  Two ranks whose batches hold very different numbers of labelled voxels,
+    two SGD steps (SGD: the scale of the gradient matters, Adam's first steps hide it): the
+    plan's fused form -- unnormalised gradients, the count behind the arena, sum-all-reduce,
+    division inside the optimiser kernel -- equals the scaling form of round 3 and the
+    torch-CPU port stepping on the BATCH of the two samples; the arena is left zero."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=500) for _ in range(2))
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0]["1"]["scale"] == ('sum',) and res[0]["0"]["scale"] is None
+    assert res[0]["1"]["g_after"] == 0.0                       # cleared by the optimiser launch
+    for fused in ("1", "0"):
+        assert np.array_equal(res[0][fused]["P"], res[1][fused]["P"]), "replicas diverged"
+    a, b = res[0]["1"]["P"], res[0]["0"]["P"]
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+    # oracle: ONE net on the batch of both samples (nll_loss divides by the batch's labelled count)
+    torch.set_num_threads(8)
+    net = TS.TorchNet(O.NEURO3D_LITE, O.init_net(O.NEURO3D_LITE, 1, seed=5), dtype=torch.float64)
+    xb = torch.tensor(np.concatenate([_ragged_data(r)[0] for r in range(2)]), dtype=torch.float64)
+    tb = torch.tensor(np.concatenate([_ragged_data(r)[1] for r in range(2)]), dtype=torch.float64)
+    params = net.w + net.b
+    d = [torch.zeros_like(p_) for p_ in params]
+    for _ in range(2):
+        net.loss_and_grads(xb, tb)
+        with torch.no_grad():
+            for p_, d_ in zip(params, d):
+                d_.mul_(0.9).add_(p_.grad)                     # optimiser.py:146-160, wd = 0
+                p_.sub_(1e-2 * d_)
+    want = [p_.detach().numpy() for p_ in params]
+    nw = len(net.w)
+    off = 0
+    for i in range(nw):
+        for ref in (want[i], want[nw + i]):
+            got = a[off:off + ref.size].reshape(ref.shape)
+            err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
+            assert err < 1e-4, (i, ref.shape, err)
+            off += (ref.size + 3) // 4 * 4
+    # ... and it is NOT the plain mean of the two ranks' gradients (that is what ragged counts
+    # distinguish): a net stepping on the hand-averaged per-rank gradients ends elsewhere
+    nets_ = [TS.TorchNet(O.NEURO3D_LITE, O.init_net(O.NEURO3D_LITE, 1, seed=5), dtype=torch.float64)
+             for _ in range(2)]
+    for n_, r in zip(nets_, range(2)):
+        x_, t_ = _ragged_data(r)
+        n_.loss_and_grads(torch.tensor(x_, dtype=torch.float64), torch.tensor(t_, dtype=torch.float64))
+    gm = 0.5 * (nets_[0].w[-1].grad + nets_[1].w[-1].grad).numpy()
+    net2 = TS.TorchNet(O.NEURO3D_LITE, O.init_net(O.NEURO3D_LITE, 1, seed=5), dtype=torch.float64)
+    net2.loss_and_grads(xb, tb)
+    gb = net2.w[-1].grad.numpy()
+    assert np.abs(gm - gb).max() > 1e-2 * np.abs(gb).max()
+
+
 def _rccl_worker(port, q):
     os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       LOCAL_RANK="0")
