@@ -179,44 +179,6 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   }
   stage(p.wpf, p.coPf, p.ciPf, woffF, 0, 0);
 
-  // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
-  float cnt = 0.f;
-  if (p.count_here) {
-    // (the first cut read one float per iteration: 54 dependent round trips to L2 = ~35 us of
-    // the kernel on neuro3d_lite's 13,690 targets)
-    for (int n2 = 0; n2 < p.N; ++n2) {
-      const float* tp = p.tg + (long)n2 * p.tsN;
-      const int head = min(p.S, (int)((4 - (((uintptr_t)tp >> 2) & 3)) & 3));   // floats up to 16-B alignment
-      const int nv = (p.S - head) >> 2;
-      const f32x4* tv4 = reinterpret_cast<const f32x4*>(tp + head);
-      for (int i0 = 0; i0 < nv; i0 += 256 * 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = i0 + u * 256 + tid;
-          v[u] = i < nv ? tv4[i] : f32x4{-1.f, -1.f, -1.f, -1.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) cnt += (v[u][e] == (float)c) ? 1.f : 0.f;
-      }
-      // the unaligned head and the tail of < 4 floats
-      const int rest = p.S - head - 4 * nv;
-      if (tid < head + rest) {
-        const float tv = tid < head ? tp[tid] : tp[head + 4 * nv + (tid - head)];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) cnt += (tv == (float)c) ? 1.f : 0.f;
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if (lane == 0) RED[wave] = cnt;
-  }
-
-  TAIL_STAMP(1);
   // ---- the x tile -> LDS: rows of NP positions, zero past the sample and past C1; every load
   // of the tile is in flight at once ------------------------------------------------------------
   {
@@ -229,6 +191,43 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     for (int j = 0; j < NR; ++j) {
       const int r = pq + j * NQ;
       xv[j] = (pv && r < p.C1) ? xb[(long)r * p.xsC] : 0.f;
+    }
+    // (the count's loads are requested BEHIND the tile's: one round trip to memory for both)
+    // ---- the labelled voxels of the whole target (every work-group for itself) -----------------
+    float cnt = 0.f;
+    if (p.count_here) {
+      // (the first cut read one float per iteration: 54 dependent round trips to L2 = ~35 us of
+      // the kernel on neuro3d_lite's 13,690 targets)
+      for (int n2 = 0; n2 < p.N; ++n2) {
+        const float* tp = p.tg + (long)n2 * p.tsN;
+        const int head = min(p.S, (int)((4 - (((uintptr_t)tp >> 2) & 3)) & 3));   // floats up to 16-B alignment
+        const int nv = (p.S - head) >> 2;
+        const f32x4* tv4 = reinterpret_cast<const f32x4*>(tp + head);
+        for (int i0 = 0; i0 < nv; i0 += 256 * 8) {
+          f32x4 v[8];
+  #pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256 + tid;
+            v[u] = i < nv ? tv4[i] : f32x4{-1.f, -1.f, -1.f, -1.f};
+          }
+  #pragma unroll
+          for (int u = 0; u < 8; ++u)
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+  #pragma unroll
+              for (int c = 0; c < NC; ++c) cnt += (v[u][e] == (float)c) ? 1.f : 0.f;
+        }
+        // the unaligned head and the tail of < 4 floats
+        const int rest = p.S - head - 4 * nv;
+        if (tid < head + rest) {
+          const float tv = tid < head ? tp[tid] : tp[head + 4 * nv + (tid - head)];
+  #pragma unroll
+          for (int c = 0; c < NC; ++c) cnt += (tv == (float)c) ? 1.f : 0.f;
+        }
+      }
+  #pragma unroll
+      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+      if (lane == 0) RED[wave] = cnt;
     }
     if (tid < kRows) {                          // head weights and the layer's bias, once
 #pragma unroll
