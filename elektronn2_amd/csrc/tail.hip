@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
       for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
       if (lane == 0) RED[wave] = cnt;
     }
+    TAIL_STAMP(1);
     if (tid < kRows) {                          // head weights and the layer's bias, once
 #pragma unroll
       for (int c = 0; c < NC; ++c) WH[c * kRows + tid] = tid < p.C2 ? p.wh[c * p.C2 + tid] : 0.f;
@@ -601,7 +602,7 @@ int launch_tail(e2_ctx* ctx, TailP p, long grid) {
     E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<unsigned long long> h(12 * grid);
     E2_CHECK_HIP(hipMemcpy(h.data(), p.stamps, sizeof(unsigned long long) * 12 * grid, hipMemcpyDeviceToHost));
-    static const char* names[10] = {"count", "x tile", "phase A", "(barrier)", "h epilogue", "logits", "softmax/loss",
+    static const char* names[10] = {"x loads + count", "x tile to LDS", "phase A", "(barrier)", "h epilogue", "logits", "softmax/loss",
                                     "dpre", "dpre store", "phase C"};
     double sum[11] = {0};
     unsigned long long t0 = ~0ull, t1 = 0;
