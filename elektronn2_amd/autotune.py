@@ -121,9 +121,8 @@ def igemm_candidates(cout, cin, k, out_sp, split_k=True):
     ccs = sorted(set(c for c in opts + even if 4 <= c <= max(cinp, 4) and c <= (64 if fast else 32)))
     for mt in _best_mts(mblocks, IGEMM_MTS, keep=4):
         nmt = -(-mblocks // mt)
-        for nt in (1, 2, 3, 4):
-            # (192-position tiles: specialised kernel widths, up to 5 row blocks -- round 4)
-            if (nt >= 3 and mt > 5) or (nt == 2 and mt > 10) or (nt == 3 and not fast):
+        for nt in (1, 2, 4):
+            if (nt == 4 and mt > 5) or (nt == 2 and mt > 10):
                 continue
             base = out_sp[0] * (-(-q // (64 * nt))) * nmt
             sks = (1,) if (base >= 200 or not split_k) else (1, 2, 3, 4, 5, 6, 8)

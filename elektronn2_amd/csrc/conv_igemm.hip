@@ -337,8 +337,8 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   for (int MT : kMTs) {
     if (MT > mblocks && MT != 1) continue;
     const int nMT = e2_cdiv(mblocks, MT);
-    for (int NT = 1; NT <= 4; ++NT) {
-      if (NT >= 3 && MT > 5) continue;
+    for (int NT = 1; NT <= 4; NT *= 2) {
+      if (NT == 4 && MT > 5) continue;
       const int BN = 64 * NT;
       const int nPT = (int)((Q + BN - 1) / BN);
       for (int CC = 4; CC <= ccMax && CC <= std::max(cinP, 4); CC += 4) {
@@ -506,11 +506,10 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   }
   const bool fast = has_fast_kw(a.kw);
   // the gradient-mask epilogue lives in the specialised-width 16x16x4 kernel
-  // (... whose row sums reduce over power-of-two lane groups: not the 192-position tile)
-  const bool gm = a.gm && fast && a.upz * a.upy * a.upx == 1 && a.Wo >= 4 && c.NT != 3;
+  const bool gm = a.gm && fast && a.upz * a.upy * a.upx == 1 && a.Wo >= 4;
   E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC <= (fast ? 64 : 32),
              "igemm: CC must be a multiple of 4, at most %d", fast ? 64 : 32);
-  E2_REQUIRE(c.NT >= 1 && c.NT <= 4 && (c.NT != 3 || fast), "igemm: NT must be 1, 2, 3 (specialised kernel widths) or 4");
+  E2_REQUIRE(c.NT == 1 || c.NT == 2 || c.NT == 4, "igemm: NT must be 1, 2 or 4");
   E2_REQUIRE(c.SK >= 1, "igemm: SK must be >= 1");
   IgemmP p;
   p.in = a.in; p.wp = a.wp; p.out = a.out;

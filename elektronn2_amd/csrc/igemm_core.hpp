@@ -494,9 +494,7 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
   if (p.wide) {
     constexpr int STR = 16 * NT + 4;           // row stride: 4*STR == 16 (mod 32) banks
     constexpr int LPR = 4 * NT;                // lanes per tile row
-    constexpr int RPI = 64 / LPR;              // rows per store instruction (NT = 3: 5 rows, the
-                                               // lanes 60..63 idle)
-    constexpr int NIT = (16 * MT + RPI - 1) / RPI;
+    constexpr int RPI = 64 / LPR;              // rows per store instruction
     __syncthreads();                           // every wave is done with the input spans
     float* tile = smem + wave * (16 * MT * STR);
 #pragma unroll
@@ -520,12 +518,11 @@ __global__ __launch_bounds__(512, 1) void igemm_kernel(IgemmP p) {
     const float* gb = (p.gm && p.gm_src) ? p.gm_src + (long)n * p.gsN + (long)z * p.gsZ + qw : nullptr;
     float* bsum = smem + 4 * (16 * MT * STR);      // [4 waves][16*MT rows], behind the tiles
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = min(it * RPI + rl_, 16 * MT - 1);
-      const bool row_on = rl_ < RPI && it * RPI + rl_ < 16 * MT;
+    for (int it = 0; it < (16 * MT) / RPI; ++it) {
+      const int row = it * RPI + rl_;
       f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * STR + 4 * c4);
       const int co = m0 + row;
-      if (row_on && co < p.Cout) {             // (the LPR lanes of a row decide alike)
+      if (co < p.Cout) {                       // (the LPR lanes of a row decide alike)
         if (p.bias) {
           const float bv = p.bias[co];
 #pragma unroll
@@ -694,12 +691,8 @@ static int igemm_dispatch(e2_ctx* ctx, const IgemmP& p, int MT, int NT, int grid
   case M:                                                                       \
     if (NT == 1) return igemm_launch<M, 1, KW, GU, BF>(ctx, p, grid, lds);          \
     if (NT == 2) return igemm_launch<M, 2, KW, GU, BF>(ctx, p, grid, lds);          \
-    if (NT == 3) return igemm_launch<M, 3, KW, GU, BF>(ctx, p, grid, lds);          \
     if (NT == 4) return igemm_launch<M, 4, KW, GU, BF>(ctx, p, grid, lds);          \
     break;
-  // NT = 3 (192-position tiles, round 4): the position-tile count is what decides how many
-  // ROUNDS of work-groups a launch takes -- 651 work-groups of 256 positions on 512 slots are two
-  // rounds, the second a quarter full; 861 of 192 positions are 1.7 (finding 40).
   // (13 x 2 blocks: two operand sets + 104 accumulators do not fit 256 registers; the
   // compiler spills operand registers that inline-asm loads are still filling -- the build
   // refuses scratch in these kernels, csrc/check_scratch.py -- so 13 blocks come with NT = 1)

@@ -145,49 +145,6 @@ def test_conv3d_5x4_block_tiling_fwd_and_dgrad(ctx, kw, force):
     assert relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < TOL
 
 
-@pytest.mark.parametrize("kw", [1, 3, 4, 5])
-@pytest.mark.parametrize("force", ["1,3,8,1", "2,3,16,1", "3,3,8,2", "4,3,24,1", "5,3,8,3"])
-def test_conv3d_192_position_tiles(ctx, kw, force):
-    """NT = 3 (round 4, finding 40): tiles of 192 positions -- 12 lanes per tile row in the wide
-    epilogue, five rows per store instruction, four idle lanes -- for every tap width and row-block
-    count: forward, forward with the fused bias + relu epilogue (signed zeros), data gradient
-    into a strided view, split-K with atomics and with partial-sum slabs; channel and position
-    counts that are not multiples of the tile."""
-    rng = np.random.RandomState(300 + kw)
-    k = (2, 2, kw)
-    Ci, Co = 44, 75
-    x = rng.rand(2, Ci, 3, 9, 43).astype(np.float32)
-    w = (rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k))).astype(np.float32)
-    b = (rng.randn(Co) / 4).astype(np.float32)
-    y_ref = O.conv3d_fwd(x, w)
-    dy = rng.randn(*y_ref.shape).astype(np.float32)
-    y = torch.full(y_ref.shape, float("nan"), device="cuda")
-    dx = torch.full(x.shape, float("nan"), device="cuda")
-    ws = torch.empty(ctx.conv_ws_bytes(max(Co, Ci), max(Co, Ci), k) // 4 + 64, device="cuda")
-    sk = int(force.split(",")[3])
-    ctx.set_tiling("igemm", force)
-    try:
-        ctx.conv3d_fwd(dev(x), dev(w), y)
-        ctx.conv3d_dgrad(_padded_dy(dy, k), dev(w), dx)
-        assert relerr(y, y_ref) < TOL
-        assert relerr(dx, O.conv3d_dgrad(dy, w, x.shape)) < TOL
-        ctx.conv3d_pack(dev(w), 0, ws)
-        if sk == 1:
-            ya = torch.full(y_ref.shape, float("nan"), device="cuda")
-            ctx.conv3d_fwd_packed_act(dev(x), ws, Co, k, dev(b), 'relu', ya)
-            pre = y_ref + b.reshape(1, -1, 1, 1, 1)
-            assert relerr(ya, np.maximum(pre, 0)) < TOL
-            neg = torch.signbit(ya).cpu().numpy()
-            assert neg[pre < -1e-6].all() and not neg[pre > 1e-6].any()
-        else:
-            yp = torch.full((8,) + y_ref.shape, float("nan"), device="cuda")
-            n = ctx.conv3d_fwd_packed_parts(dev(x), ws, Co, k, yp)
-            assert 1 <= n <= sk
-            assert relerr(yp[:n].sum(0), y_ref) < TOL
-    finally:
-        ctx.set_tiling("igemm", None)
-
-
 @pytest.mark.parametrize("force", [None, "2,1,8,1", "2,1,8,4", "3,2,8,6", "2,4,16,3", "1,2,4,8",
                                    "4,5,1,8,1,1,4,1", "4,5,1,8,4,1,4,1", "4,4,2,8,2,2,2,2"])
 @pytest.mark.parametrize("k,do", [((4, 3, 3), 3), ((3, 2, 4), 1), ((2, 1, 5), 6)])
