@@ -18,11 +18,14 @@
 //   tile    = NP = 16 * WN consecutive positions of one sample (the tensors are dense in
 //             (z, y, x), so a position is one flat index), all channels; 4 waves = WM x WN:
 //             wave (wm, wn) owns 16 positions and MTW = ceil(13 / WM) of the 13 blocks of
-//             16 channel rows (C1, C2 <= 208).  WM = 1 / 2 / 4 by the host: few positions
-//             (neuro3d: 2,205) -> split the rows, so that 138 work-groups exist instead of 35.
+//             16 channel rows (C1, C2 <= 208).  (WM, chunk rows) by the host (tail_cfg): WM = 2
+//             with 16-row weight chunks where there are >= 256 tiles of 32 positions (76 KB of
+//             LDS: two work-groups per CU); few positions (neuro3d: 2,205) -> WM = 4, so that
+//             138 work-groups exist instead of 35.
 //   phase A : pre[co][p] = sum_ci Wf[ci][co] x[ci][p]   fp32 MFMA 16x16x4; B from the x tile
 //             in LDS, A from the forward packed image ([k][m], m contiguous: the image
-//             conv_igemm.hip keeps), staged in chunks of 40 k-rows by LDS-DMA, double buffered.
+//             conv_igemm.hip keeps), staged in chunks of 16 or 40 k-rows by LDS-DMA, double
+//             buffered; operand reads one k-step ahead (inline asm, counted lgkmcnt).
 //   epilogue: h = relu(pre + b1) written over the x tile ([channel][position]); a negative
 //             pre-activation keeps its sign in the zero (-0.0): relu'(0) = 0.5 (Theano) is told
 //             from 0 by it, as in the GEMM epilogues of igemm_core.hpp.
@@ -34,7 +37,10 @@
 //             (bias gradient) and dWh[c][row] = sum_p dlogits[c][p] h[row][p] in registers ->
 //             ONE partial-sum slot per work-group (no same-address atomics, DESIGN.md lesson 6).
 //   phase C : dx[ci][p] = sum_co Wd[co][ci] dpre[co][p]  (B = the dpre tile, A = the data
-//             gradient's packed image), tile -> LDS -> 4 NP-byte row segments to memory.
+//             gradient's packed image), tile -> LDS -> rows of NP positions to memory --
+//             optionally THROUGH the activation backward of the layer that produced x (gm: dx *=
+//             act'(.), its bias gradient = the row sums, written into the interior of that
+//             layer's zero-padded gradient buffer).
 //   A small second kernel adds the slots up (into the zeroed gradient arena) and writes the
 //   loss: it is launched from the BACKWARD half of the plan, behind the arena's zero fill.
 #include "common.hpp"
