@@ -296,3 +296,32 @@ def test_tiling_candidate_lists():
     for key, val in shipped.items():
         kind = key.split("|")[0].replace("_bf16", "")
         assert val == "" or re.fullmatch(forms[kind], val), (key, val)
+
+
+def test_per_kernel_regression_gate_on_the_committed_profiles():
+    """tools/kstats_diff.py: run on round 3's own profiles it names the
+    kernels that regressed between r03_a and r03_c -- the first-layer backward (+16 us, run-time
+    debug branches) among them -- and it passes a profile against itself; adopt_profile.py
+    imports the same function."""
+    import io
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import kstats_diff
+    prof = os.path.join(root, "profiles")
+    a = os.path.join(prof, "r03_a_bench_lite183_kernel_stats.csv")
+    c = os.path.join(prof, "r03_c_bench_lite183_kernel_stats.csv")
+    out = io.StringIO()
+    bad = kstats_diff.diff(c, a, out=out)
+    assert "firstm_bwd_kernel<4, 4, 2, 2, 5>" in bad and "SUM" in bad
+    assert "REGRESSION" in out.getvalue()
+    assert kstats_diff.diff(c, c, out=io.StringIO()) == []
+    # the profile of record exists for both nets of the driver's line and names real files
+    import json
+    cur = json.load(open(os.path.join(prof, "CURRENT.json")))
+    for wl in ("lite183", "full185"):
+        assert os.path.exists(kstats_diff.record_path(wl)), wl
+        base = os.path.join(prof, "%s_bench_%s" % (cur[wl]["tag"], wl))
+        for suf in ("_pmc_mfma.csv", "_pmc_traffic.csv", ".json"):
+            assert os.path.exists(base + suf), base + suf
