@@ -325,3 +325,35 @@ def test_per_kernel_regression_gate_on_the_committed_profiles():
         base = os.path.join(prof, "%s_bench_%s" % (cur[wl]["tag"], wl))
         for suf in ("_pmc_mfma.csv", "_pmc_traffic.csv", ".json"):
             assert os.path.exists(base + suf), base + suf
+
+
+def test_build_check_enforces_the_register_budget(tmp_path):
+    """csrc/check_scratch.py + reg_budget.txt: a kernel that uses scratch, or falls below the
+    occupancy its launch geometry assumes, fails the BUILD (round 3 shipped a first-layer
+    backward at occupancy 2 under a 3-per-CU persistent grid)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "elektronn2_amd", "csrc")
+
+    def log(name, vgprs, scratch, occ):
+        return ("x.hip:1:1: remark: Function Name: %s [-Rpass-analysis=kernel-resource-usage]\n"
+                "x.hip:1:1: remark:     VGPRs: %d [-Rpass-analysis=kernel-resource-usage]\n"
+                "x.hip:1:1: remark:     ScratchSize [bytes/lane]: %d [-Rpass-analysis=kernel-resource-usage]\n"
+                "x.hip:1:1: remark:     Occupancy [waves/SIMD]: %d [-Rpass-analysis=kernel-resource-usage]\n"
+                % (name, vgprs, scratch, occ))
+    fm = "_ZN12_GLOBAL__N_117firstm_bwd_kernelILi4ELi4ELi2ELi2ELi5EEEvNS_6FirstMEPf"
+    ig = "_Z12igemm_kernelILi7ELi2ELi3ELi1ELb0EEv6IgemmP"
+    cases = [(log(fm, 103, 0, 3) + log(ig, 125, 0, 4), 0),
+             (log(fm, 128, 0, 2), 1),                     # round 3's regression
+             (log(fm, 110, 0, 3), 1),                     # above the VGPR budget
+             (log(ig, 125, 8, 4), 1),                     # scratch in a hand-scheduled GEMM
+             (log(ig, 150, 0, 3), 1)]                     # no second co-resident work-group
+    for i, (text, want) in enumerate(cases):
+        f = tmp_path / ("k%d.log" % i)
+        f.write_text(text)
+        r = subprocess.run([sys.executable, os.path.join(csrc, "check_scratch.py"), str(f),
+                            "igemm4_kernel|wgrad_direct_kernel|igemm_kernel|pw_gemm_kernel",
+                            os.path.join(csrc, "reg_budget.txt")], capture_output=True, text=True)
+        assert (r.returncode != 0) == bool(want), (i, r.stderr)
