@@ -254,6 +254,7 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
     return sorted(set(cands) | set(pointwise_wgrad_candidates(cout, cin, k, out_sp, n_cu)))
 
 
+PW_WGRAD_KS_TILES = [(13, 2), (10, 2), (7, 2), (7, 4), (4, 4)]
 PW_WGRAD_TILES = [(2, 2), (4, 2), (2, 4), (4, 4), (4, 3), (3, 4), (7, 2), (2, 7), (7, 4), (4, 7)]
 
 
@@ -275,6 +276,18 @@ def pointwise_wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
         for fill in (0.5, 1, 2, 4):
             s = max(1, min(steps, int(n_cu * fill) // tiles))
             out.append("%d,%d,7,0,%d" % (mt, nt, s))
+    # "MT,NT,8,0,S": ONE 16 MT x 16 NT tile per work-group, its four waves split the positions
+    units = max(1, (out_sp[0] * out_sp[1] * out_sp[2]) // 32)
+    scored = []
+    for mt, nt in PW_WGRAD_KS_TILES:
+        nm, nn = -(-cout // (16 * mt)), -(-cin // (16 * nt))
+        eff = (cout * cin) / float(nm * 16 * mt * nn * 16 * nt)
+        scored.append((-eff, -mt * nt, mt, nt, nm * nn))
+    scored.sort()
+    for _, _, mt, nt, tiles in scored[:3]:
+        for fill in (0.5, 0.75, 1, 2):
+            s = max(1, min(-(-units // 4), int(n_cu * fill) // tiles))
+            out.append("%d,%d,8,0,%d" % (mt, nt, s))
     return sorted(set(out))
 
 

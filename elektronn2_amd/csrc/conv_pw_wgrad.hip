@@ -24,6 +24,7 @@
 // Requires dense channel planes (row stride = W, plane stride = H * W) for x and dy.
 #include "common.hpp"
 #include <algorithm>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -36,6 +37,7 @@ struct PgP {
   int R;                                           // UpConv: row m = co * R + r
   int nMT, nNT, S;
   int stepsPerSample, steps, per;                  // 16-position steps: per sample, total, per split
+  int rem;                                         // (position-split waves) K % 32
 };
 
 // lane's float4 of a 16-position step: positions k0 + 4q .. + 3 of one channel row; past the end
@@ -145,6 +147,172 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(PgP p) {
   }
 }
 
+// ---- the same GEMM with the four waves of a work-group splitting the POSITIONS ---------------
+// ("MT,NT,8,0,S").  The tiles above give every wave its own output blocks, so a work-group's
+// tile is 32 MT x 32 NT outputs: 200 channels fill 224 x 256 at best (1.43 x the MFMAs), and
+// the small tiles that would fit ask L2 for ~20 TB/s.  Here ONE wave holds the whole
+// 16 MT x 16 NT tile (13 x 2 blocks = 208 x 32 for 200 channels: 1.16 x), the four waves take
+// every fourth 32-position unit of the work-group's range, their partial tiles are summed
+// through LDS and flushed once.  Operand registers: A is single-buffered -- block mb's two
+// float4 of the NEXT unit are requested right after block mb's MFMAs of this unit, so every
+// load has a whole unit (13 x 2 x 8 MFMAs = 2.8 us) to arrive -- B double-buffered.
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
+  extern __shared__ float red[];
+  constexpr int RW = 16 * NT + 4;                    // padded row of a wave's partial tile
+  constexpr int RS = 16 * MT * RW;
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // work-groups b, b + 8, b + 16 ... share an XCD: the tiles of one position range are
+  // consecutive THERE, so an operand row comes out of HBM once per range, not once per tile
+  int L = blockIdx.x;
+  if ((gridDim.x & 7) == 0) L = (L & 7) * (gridDim.x >> 3) + (L >> 3);
+  const int nt = L % p.nNT; L /= p.nNT;
+  const int mt = L % p.nMT;
+  const int sp = L / p.nMT;
+  if (sp >= p.S) return;                             // (grid padded to a multiple of 8)
+  const int m0 = mt * 16 * MT, n0 = nt * 16 * NT;
+  const int u0 = sp * p.per + wave, u1 = min(sp * p.per + p.per, p.steps);
+  const int cnt = u0 < u1 ? (u1 - u0 + 3) >> 2 : 0;
+
+  unsigned aoff[MT], boff[NT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) aoff[mb] = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC;
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) boff[nb] = (unsigned)min(n0 + 16 * nb + l15, p.Ncol - 1) * (unsigned)p.bsC;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // unit i of this wave: sample and first position (units are WHOLE: the K % 32 positions at
+  // the end of a sample are a masked step of their own below, outside the pipelined loop)
+  auto where = [&](int i, const float*& ap, const float*& bp, int& k) {
+    const int u = u0 + 4 * i;
+    const int n = u / p.stepsPerSample;
+    ap = p.a + (long)n * p.asN;
+    bp = p.b + (long)n * p.bsN;
+    k = (u - n * p.stepsPerSample) * 32 + 4 * q;
+  };
+  auto load2 = [&](f32x4 (&d)[2], const float* base, unsigned off, int k) {
+    const float* r = base + off + k;
+    __builtin_memcpy(&d[0], r, 16);                  // (4-byte aligned only: rows need not be 16-byte aligned)
+    __builtin_memcpy(&d[1], r + 16, 16);
+  };
+  auto mfmas = [&](int mb, const f32x4 (&Am)[2], const f32x4 (&Bc)[NT][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb)
+          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Am[h][j], Bc[nb][h][j], acc[mb][nb], 0, 0, 0);
+  };
+
+  f32x4 A[MT][2], B0[NT][2], B1[NT][2];
+  auto step = [&](auto next, int i, f32x4 (&Bc)[NT][2], f32x4 (&Bn)[NT][2]) {
+    constexpr bool NEXT = decltype(next)::value;
+    const float *ap = nullptr, *bp = nullptr;
+    int k = 0;
+    if (NEXT) {
+      where(i + 1, ap, bp, k);
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) load2(Bn[nb], bp, boff[nb], k);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+      mfmas(mb, A[mb], Bc);
+      if (NEXT) load2(A[mb], ap, aoff[mb], k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (cnt > 0) {
+    const float *ap, *bp;
+    int k;
+    where(0, ap, bp, k);
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) load2(B0[nb], bp, boff[nb], k);
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) load2(A[mb], ap, aoff[mb], k);
+    int i = 0;
+    for (; i + 2 < cnt; i += 2) {
+      step(std::true_type{}, i, B0, B1);
+      step(std::true_type{}, i + 1, B1, B0);
+    }
+    if (i + 2 == cnt) {
+      step(std::true_type{}, i, B0, B1);
+      step(std::false_type{}, i + 1, B1, B0);
+    } else {
+      step(std::false_type{}, i, B0, B1);
+    }
+  }
+  // the K % 32 last positions of sample n: split sp = n % S, wave (n / S) % 4 of every tile
+  if (p.rem > 0) {
+    for (int n = sp; n < p.N; n += p.S) {
+      if (((n / p.S) & 3) != wave) continue;
+      const float* ap = p.a + (long)n * p.asN;
+      const float* bp = p.b + (long)n * p.bsN;
+      const int k = p.K - p.rem + 4 * q;
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) {
+        B0[nb][0] = pg_load(bp + boff[nb], k, p.K);
+        B0[nb][1] = pg_load(bp + boff[nb], k + 16, p.K);
+      }
+#pragma unroll 1
+      for (int mb = 0; mb < MT; ++mb) {              // (not unrolled: acc[mb] through the switch below)
+        f32x4 Am[2];
+        const unsigned ao = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC;
+        Am[0] = pg_load(ap + ao, k, p.K);
+        Am[1] = pg_load(ap + ao, k + 16, p.K);
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm)
+          if (mm == mb) mfmas(mm, Am, B0);
+      }
+    }
+  }
+
+  // ---- the four partial tiles through LDS: D row = 4 q + r, col = l15 ------------------------
+  float* mine = red + wave * RS;
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(16 * mb + 4 * q + r) * RW + 16 * nb + l15] = acc[mb][nb][r];
+  __syncthreads();
+  const bool single = p.S == 1;
+#pragma unroll 2
+  for (int e = tid; e < 16 * MT * 16 * NT; e += 256) {
+    const int ml = e / (16 * NT), nl = e - ml * (16 * NT);
+    const int m = m0 + ml, n = n0 + nl;
+    const float* s = red + ml * RW + nl;
+    const float v = (s[0] + s[RS]) + (s[2 * RS] + s[3 * RS]);
+    if (m >= p.M || n >= p.Ncol) continue;
+    float* dst;
+    if (p.R > 1) { const int co = m / p.R; dst = p.c + (long)co * p.Ncol * p.R + (m - co * p.R) + (long)n * p.R; }
+    else dst = p.c + (long)m * p.Ncol + n;
+    if (single) *dst += v;                           // (dw was zeroed or holds what to add to)
+    else unsafeAtomicAdd(dst, v);
+  }
+}
+
+template <int MT, int NT>
+int launch_ks(e2_ctx* ctx, const PgP& p, long grid) {
+  const int lds = 4 * 16 * MT * (16 * NT + 4) * (int)sizeof(float);
+  static bool raised = false;                        // (one device per process: plan.py get_ctx)
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_ks_kernel<MT, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
+    raised = true;
+  }
+  hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int MT, int NT>
 int launch(e2_ctx* ctx, const PgP& p, long grid) {
   hipLaunchKernelGGL((pw_wgrad_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
@@ -170,6 +338,7 @@ int e2i_pw_wgrad(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   E2_REQUIRE(a.Cout % p.R == 0, "pointwise wgrad: %d rows for %d sub-positions", a.Cout, p.R);
   p.nMT = e2_cdiv(a.Cout, 32 * MT);
   p.nNT = e2_cdiv(a.Cin, 32 * NT);
+  p.rem = 0;
   p.stepsPerSample = (int)((K + 15) / 16);
   const long steps = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(steps < (1L << 30), "pointwise wgrad: too many positions");
@@ -185,5 +354,46 @@ int e2i_pw_wgrad(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   E2_L(2, 2) E2_L(4, 2) E2_L(2, 4) E2_L(4, 4) E2_L(4, 3) E2_L(3, 4) E2_L(7, 2) E2_L(2, 7) E2_L(7, 4) E2_L(4, 7)
 #undef E2_L
   e2_set_error("pointwise wgrad: no instance MT=%d NT=%d", MT, NT);
+  return 2;
+}
+
+// "MT,NT,8,0,S": the waves of a work-group split the positions (pw_wgrad_ks_kernel)
+int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
+  E2_REQUIRE(a.kd == 1 && a.kh == 1 && a.kw == 1, "pointwise wgrad: kernel %dx%dx%d is not 1x1x1", a.kd, a.kh, a.kw);
+  E2_REQUIRE(a.xsY == a.Wo && a.xsZ == (int64_t)a.Ho * a.Wo && a.dsY == a.Wo && a.dsZ == (int64_t)a.Ho * a.Wo,
+             "pointwise wgrad: x and dy need dense channel planes (row stride = W, plane stride = H * W)");
+  E2_REQUIRE(!ctx->mfma_bf16, "pointwise wgrad: an f32 kernel, not offered in bf16 mode");
+  PgP p;
+  p.a = a.dy; p.b = a.x; p.c = a.dw;
+  p.asN = a.dsN; p.asC = a.dsC; p.bsN = a.xsN; p.bsC = a.xsC;
+  p.N = a.N; p.M = a.Cout; p.Ncol = a.Cin;
+  const long K = (long)a.Do * a.Ho * a.Wo;
+  E2_REQUIRE(K >= 4 && K < (1L << 30), "pointwise wgrad: sample of %ld positions", K);
+  // 32-bit element offsets of a row inside its sample (+ the 32 positions of a unit)
+  E2_REQUIRE((long)a.Cout * a.dsC + 64 < (1L << 31) && (long)a.Cin * a.xsC + 64 < (1L << 31) && a.dsC >= 0 && a.xsC >= 0,
+             "pointwise wgrad: sample too large for 32-bit row offsets");
+  p.K = (int)K;
+  p.R = a.upR > 1 ? a.upR : 1;
+  E2_REQUIRE(a.Cout % p.R == 0, "pointwise wgrad: %d rows for %d sub-positions", a.Cout, p.R);
+  p.nMT = e2_cdiv(a.Cout, 16 * MT);
+  p.nNT = e2_cdiv(a.Cin, 16 * NT);
+  p.stepsPerSample = (int)(K / 32);                  // (here: WHOLE 32-position units)
+  p.rem = (int)(K % 32);
+  const long units = (long)a.N * p.stepsPerSample;
+  E2_REQUIRE(units < (1L << 29), "pointwise wgrad: too many positions");
+  p.steps = (int)units;
+  S = (int)std::max<long>(1, std::min<long>(S, std::max<long>(1, (units + 3) / 4)));
+  p.per = (int)std::max<long>(1, (units + S - 1) / S);
+  p.per = (p.per + 3) & ~3;                          // whole rounds of the four waves
+  p.S = (int)std::max<long>(1, (units + p.per - 1) / p.per);
+  long grid = (long)p.nMT * p.nNT * p.S;
+  grid = (grid + 7) & ~7L;                           // XCD-grouped order (the pad returns at once)
+  E2_REQUIRE(grid < (1L << 31), "pointwise wgrad: grid too large");
+  if (!a.accumulate)
+    if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * a.Cin, 0.f)) return rc;
+#define E2_L(M, N_) if (MT == M && NT == N_) return launch_ks<M, N_>(ctx, p, grid);
+  E2_L(13, 2) E2_L(7, 2) E2_L(7, 4) E2_L(4, 4) E2_L(10, 2)
+#undef E2_L
+  e2_set_error("pointwise wgrad (position-split waves): no instance MT=%d NT=%d", MT, NT);
   return 2;
 }

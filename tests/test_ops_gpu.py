@@ -531,15 +531,19 @@ def test_conv3d_wgrad_pad_forced_tilings(ctx, force, k):
 
 
 @pytest.mark.parametrize("force", ["2,2,7,0,1", "2,2,7,0,5", "4,2,7,0,3", "2,4,7,0,64", "4,4,7,0,2", "4,3,7,0,7",
-                                   "3,4,7,0,1", "7,2,7,0,4", "2,7,7,0,9", "7,4,7,0,3", "4,7,7,0,100000"])
+                                   "3,4,7,0,1", "7,2,7,0,4", "2,7,7,0,9", "7,4,7,0,3", "4,7,7,0,100000",
+                                   "13,2,8,0,1", "13,2,8,0,5", "13,2,8,0,100000", "7,2,8,0,3", "7,4,8,0,2",
+                                   "4,4,8,0,7", "10,2,8,0,4"])
 @pytest.mark.parametrize("Ci,Co,N,sp", [(70, 100, 2, (3, 7, 13)), (200, 200, 1, (2, 9, 37)), (33, 250, 1, (1, 5, 70)),
-                                        (40, 37, 3, (1, 1, 5))])
+                                        (40, 37, 3, (1, 1, 5)), (200, 200, 2, (2, 8, 40)), (60, 208, 5, (1, 3, 23))])
 def test_conv3d_pointwise_wgrad_gemm(ctx, force, Ci, Co, N, sp):
-    """csrc/conv_pw_wgrad.hip ("MT,NT,7,0,S"): the 1x1x1 weight gradient as a GEMM whose two
+    """csrc/conv_pw_wgrad.hip ("MT,NT,7,0,S", and "MT,NT,8,0,S": the four waves of a work-group
+    split the positions of ONE tile): the 1x1x1 weight gradient as a GEMM whose two
     operands are K-contiguous (positions): channel counts that are not multiples of the
-    tiles, position counts that are not multiples of 16 (a masked last step per sample) or
-    4, batches, one split (plain stores) to more splits than steps, overwrite and accumulate;
-    channel rows that are NOT 16-byte aligned (odd plane sizes)."""
+    tiles, position counts that are not multiples of 16 / 32 (a masked last step per sample) or
+    4, fewer than 32 positions, whole multiples of 32, batches (more samples than splits), one
+    split (plain stores) to more splits than steps, overwrite and accumulate; channel rows that
+    are NOT 16-byte aligned (odd plane sizes)."""
     rng = np.random.RandomState(Ci + Co)
     k = (1, 1, 1)
     x = rng.rand(N, Ci, *sp).astype(np.float32)
@@ -577,7 +581,7 @@ def test_conv3d_pointwise_wgrad_gemm(ctx, force, Ci, Co, N, sp):
         ctx.set_tiling("wgrad", None)
 
 
-@pytest.mark.parametrize("force", ["2,2,7,0,3", "4,4,7,0,1", "7,2,7,0,6"])
+@pytest.mark.parametrize("force", ["2,2,7,0,3", "4,4,7,0,1", "7,2,7,0,6", "13,2,8,0,3", "7,2,8,0,2", "4,4,8,0,1"])
 def test_upconv3d_pointwise_wgrad_gemm(ctx, force):
     """UpConv's weight gradient through the same GEMM: rows m = co * R + r land in
     dw[co][ci][r]"""

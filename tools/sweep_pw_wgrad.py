@@ -24,8 +24,9 @@ for c in autotune.wgrad_candidates(cout, cin, (1, 1, 1), (D, H, W)):
         continue
     res.append((t * 1e3, c))
 ctx.set_tiling("wgrad", None)
-for kind, sel in (("direct / staged", [r for r in res if r[1].split(",")[2] != "7"]),
-                  ("K-contiguous GEMM", [r for r in res if r[1].split(",")[2] == "7"])):
+for kind, sel in (("direct / staged", [r for r in res if r[1].split(",")[2] not in "78"]),
+                  ("K-contiguous GEMM", [r for r in res if r[1].split(",")[2] == "7"]),
+                  ("K-contiguous GEMM, waves split the positions", [r for r in res if r[1].split(",")[2] == "8"])):
     sel.sort()
     print("wgrad 1x1x1 %s %s: %.2f GF, ideal %.1f us (incl. the zero fill of dw)" % (sys.argv[1:6], kind, gf, gf / 157.3 * 1e3))
     for t, c in sel[:top]:
