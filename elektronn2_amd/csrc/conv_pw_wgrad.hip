@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(PgP p) {
 // every fourth 32-position unit of the work-group's range, their partial tiles are summed
 // through LDS and flushed once.  Operand registers: A is single-buffered -- block mb's two
 // float4 of the NEXT unit are requested right after block mb's MFMAs of this unit, so every
-// load has a whole unit (13 x 2 x 8 MFMAs = 2.8 us) to arrive -- B double-buffered.
+// load has a whole unit (13 x 2 x 8 MFMAs = 2.8 us) to arrive -- B double-buffered.  Units are
+// WHOLE; the K % 32 last positions of the samples go to one extra work-group per tile.
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   extern __shared__ float red[];
@@ -170,16 +171,60 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   const int nt = L % p.nNT; L /= p.nNT;
   const int mt = L % p.nMT;
   const int sp = L / p.nMT;
-  if (sp >= p.S) return;                             // (grid padded to a multiple of 8)
   const int m0 = mt * 16 * MT, n0 = nt * 16 * NT;
+  const bool single = p.S == 1 && p.rem == 0;
+  auto dst_of = [&](int m, int n) -> float* {
+    if (p.R > 1) { const int co = m / p.R; return p.c + (long)co * p.Ncol * p.R + (m - co * p.R) + (long)n * p.R; }
+    return p.c + (long)m * p.Ncol + n;
+  };
+
+  if (sp >= p.S) {
+    // ---- the K % 32 last positions of every sample: ONE more work-group per tile, masked
+    // loads, wave w takes the row blocks w, w + 4, ... and adds them straight from registers
+    if (sp > p.S || p.rem == 0) return;              // (grid padded to a multiple of 8)
+    const int k = p.K - p.rem + 4 * q;
+#pragma unroll 1
+    for (int mb = wave; mb < MT; mb += 4) {
+      f32x4 c[NT];
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) c[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const long ao = (long)min(m0 + 16 * mb + l15, p.M - 1) * p.asC;
+#pragma unroll 1
+      for (int n = 0; n < p.N; ++n) {
+        const float* ar = p.a + (long)n * p.asN + ao;
+        const f32x4 a0 = pg_load(ar, k, p.K), a1 = pg_load(ar, k + 16, p.K);
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+          const float* br = p.b + (long)n * p.bsN + (long)min(n0 + 16 * nb + l15, p.Ncol - 1) * p.bsC;
+          const f32x4 b0 = pg_load(br, k, p.K), b1 = pg_load(br, k + 16, p.K);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], c[nb], 0, 0, 0);
+            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], c[nb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + 16 * mb + 4 * q + r, n = n0 + 16 * nb + l15;
+          if (m < p.M && n < p.Ncol) unsafeAtomicAdd(dst_of(m, n), c[nb][r]);
+        }
+    }
+    return;
+  }
+
   const int u0 = sp * p.per + wave, u1 = min(sp * p.per + p.per, p.steps);
   const int cnt = u0 < u1 ? (u1 - u0 + 3) >> 2 : 0;
 
+  // BYTE offsets of the lane's rows inside a sample (32 bits: checked by the host), so that a
+  // load is "scalar sample base + vector offset"
   unsigned aoff[MT], boff[NT];
 #pragma unroll
-  for (int mb = 0; mb < MT; ++mb) aoff[mb] = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC;
+  for (int mb = 0; mb < MT; ++mb) aoff[mb] = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC * 4u + 16u * q;
 #pragma unroll
-  for (int nb = 0; nb < NT; ++nb) boff[nb] = (unsigned)min(n0 + 16 * nb + l15, p.Ncol - 1) * (unsigned)p.bsC;
+  for (int nb = 0; nb < NT; ++nb) boff[nb] = (unsigned)min(n0 + 16 * nb + l15, p.Ncol - 1) * (unsigned)p.bsC * 4u + 16u * q;
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -187,89 +232,50 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // unit i of this wave: sample and first position (units are WHOLE: the K % 32 positions at
-  // the end of a sample are a masked step of their own below, outside the pipelined loop)
-  auto where = [&](int i, const float*& ap, const float*& bp, int& k) {
+  // unit i of this wave (WHOLE 32-position units only): sample bases and byte offset of the unit
+  auto where = [&](int i, const char*& ap, const char*& bp, unsigned& kb) {
     const int u = u0 + 4 * i;
     const int n = u / p.stepsPerSample;
-    ap = p.a + (long)n * p.asN;
-    bp = p.b + (long)n * p.bsN;
-    k = (u - n * p.stepsPerSample) * 32 + 4 * q;
+    ap = reinterpret_cast<const char*>(p.a + (long)n * p.asN);
+    bp = reinterpret_cast<const char*>(p.b + (long)n * p.bsN);
+    kb = (unsigned)(u - n * p.stepsPerSample) * 128u;
   };
-  auto load2 = [&](f32x4 (&d)[2], const float* base, unsigned off, int k) {
-    const float* r = base + off + k;
-    __builtin_memcpy(&d[0], r, 16);                  // (4-byte aligned only: rows need not be 16-byte aligned)
-    __builtin_memcpy(&d[1], r + 16, 16);
-  };
-  auto mfmas = [&](int mb, const f32x4 (&Am)[2], const f32x4 (&Bc)[NT][2]) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb)
-          acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Am[h][j], Bc[nb][h][j], acc[mb][nb], 0, 0, 0);
+  auto load2 = [&](f32x4 (&d)[2], const char* base, unsigned off) {
+    const char* r = base + off;                      // (4-byte aligned only: rows need not be 16-byte aligned)
+    __builtin_memcpy(&d[0], r, 16);
+    __builtin_memcpy(&d[1], r + 64, 16);
   };
 
-  f32x4 A[MT][2], B0[NT][2], B1[NT][2];
-  auto step = [&](auto next, int i, f32x4 (&Bc)[NT][2], f32x4 (&Bn)[NT][2]) {
-    constexpr bool NEXT = decltype(next)::value;
-    const float *ap = nullptr, *bp = nullptr;
-    int k = 0;
-    if (NEXT) {
-      where(i + 1, ap, bp, k);
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) load2(Bn[nb], bp, boff[nb], k);
-    }
-#pragma unroll
-    for (int mb = 0; mb < MT; ++mb) {
-      mfmas(mb, A[mb], Bc);
-      if (NEXT) load2(A[mb], ap, aoff[mb], k);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
   if (cnt > 0) {
-    const float *ap, *bp;
-    int k;
-    where(0, ap, bp, k);
+    f32x4 A[MT][2], Bc[NT][2], Bn[NT][2];
+    const char *ap, *bp;
+    unsigned kb;
+    where(0, ap, bp, kb);
 #pragma unroll
-    for (int nb = 0; nb < NT; ++nb) load2(B0[nb], bp, boff[nb], k);
+    for (int nb = 0; nb < NT; ++nb) load2(Bc[nb], bp, boff[nb] + kb);
 #pragma unroll
-    for (int mb = 0; mb < MT; ++mb) load2(A[mb], ap, aoff[mb], k);
-    int i = 0;
-    for (; i + 2 < cnt; i += 2) {
-      step(std::true_type{}, i, B0, B1);
-      step(std::true_type{}, i + 1, B1, B0);
-    }
-    if (i + 2 == cnt) {
-      step(std::true_type{}, i, B0, B1);
-      step(std::false_type{}, i + 1, B1, B0);
-    } else {
-      step(std::false_type{}, i, B0, B1);
-    }
-  }
-  // the K % 32 last positions of sample n: split sp = n % S, wave (n / S) % 4 of every tile
-  if (p.rem > 0) {
-    for (int n = sp; n < p.N; n += p.S) {
-      if (((n / p.S) & 3) != wave) continue;
-      const float* ap = p.a + (long)n * p.asN;
-      const float* bp = p.b + (long)n * p.bsN;
-      const int k = p.K - p.rem + 4 * q;
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) {
-        B0[nb][0] = pg_load(bp + boff[nb], k, p.K);
-        B0[nb][1] = pg_load(bp + boff[nb], k + 16, p.K);
-      }
+    for (int mb = 0; mb < MT; ++mb) load2(A[mb], ap, aoff[mb] + kb);
+    // ONE loop body (accumulators stay where they are): the last trip requests its own unit
+    // again -- L1 / L2 hits, nothing waits for them
 #pragma unroll 1
-      for (int mb = 0; mb < MT; ++mb) {              // (not unrolled: acc[mb] through the switch below)
-        f32x4 Am[2];
-        const unsigned ao = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC;
-        Am[0] = pg_load(ap + ao, k, p.K);
-        Am[1] = pg_load(ap + ao, k + 16, p.K);
+    for (int i = 0; i < cnt; ++i) {
+      where(min(i + 1, cnt - 1), ap, bp, kb);
 #pragma unroll
-        for (int mm = 0; mm < MT; ++mm)
-          if (mm == mb) mfmas(mm, Am, B0);
+      for (int nb = 0; nb < NT; ++nb) load2(Bn[nb], bp, boff[nb] + kb);
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[mb][h][j], Bc[nb][h][j], acc[mb][nb], 0, 0, 0);
+        load2(A[mb], ap, aoff[mb] + kb);
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) { Bc[nb][0] = Bn[nb][0]; Bc[nb][1] = Bn[nb][1]; }
     }
   }
 
@@ -282,7 +288,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(16 * mb + 4 * q + r) * RW + 16 * nb + l15] = acc[mb][nb][r];
   __syncthreads();
-  const bool single = p.S == 1;
 #pragma unroll 2
   for (int e = tid; e < 16 * MT * 16 * NT; e += 256) {
     const int ml = e / (16 * NT), nl = e - ml * (16 * NT);
@@ -290,9 +295,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     const float* s = red + ml * RW + nl;
     const float v = (s[0] + s[RS]) + (s[2 * RS] + s[3 * RS]);
     if (m >= p.M || n >= p.Ncol) continue;
-    float* dst;
-    if (p.R > 1) { const int co = m / p.R; dst = p.c + (long)co * p.Ncol * p.R + (m - co * p.R) + (long)n * p.R; }
-    else dst = p.c + (long)m * p.Ncol + n;
+    float* dst = dst_of(m, n);
     if (single) *dst += v;                           // (dw was zeroed or holds what to add to)
     else unsafeAtomicAdd(dst, v);
   }
@@ -370,8 +373,8 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   const long K = (long)a.Do * a.Ho * a.Wo;
   E2_REQUIRE(K >= 4 && K < (1L << 30), "pointwise wgrad: sample of %ld positions", K);
   // 32-bit element offsets of a row inside its sample (+ the 32 positions of a unit)
-  E2_REQUIRE((long)a.Cout * a.dsC + 64 < (1L << 31) && (long)a.Cin * a.xsC + 64 < (1L << 31) && a.dsC >= 0 && a.xsC >= 0,
-             "pointwise wgrad: sample too large for 32-bit row offsets");
+  E2_REQUIRE(((long)a.Cout * a.dsC + K) * 4 < (1L << 32) && ((long)a.Cin * a.xsC + K) * 4 < (1L << 32) && a.dsC >= 0 && a.xsC >= 0,
+             "pointwise wgrad: sample too large for 32-bit byte offsets");
   p.K = (int)K;
   p.R = a.upR > 1 ? a.upR : 1;
   E2_REQUIRE(a.Cout % p.R == 0, "pointwise wgrad: %d rows for %d sub-positions", a.Cout, p.R);
@@ -386,7 +389,7 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.per = (int)std::max<long>(1, (units + S - 1) / S);
   p.per = (p.per + 3) & ~3;                          // whole rounds of the four waves
   p.S = (int)std::max<long>(1, (units + p.per - 1) / p.per);
-  long grid = (long)p.nMT * p.nNT * p.S;
+  long grid = (long)p.nMT * p.nNT * (p.S + (p.rem > 0 ? 1 : 0));   // (+ the work-groups of the K % 32 tails)
   grid = (grid + 7) & ~7L;                           // XCD-grouped order (the pad returns at once)
   E2_REQUIRE(grid < (1L << 31), "pointwise wgrad: grid too large");
   if (!a.accumulate)
