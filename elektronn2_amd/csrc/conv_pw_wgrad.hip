@@ -25,8 +25,16 @@
 #include "common.hpp"
 #include <algorithm>
 #include <type_traits>
+#include <vector>
+#include <cstdio>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef E2_DEBUG_ENV
+#define KS_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[8L * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KS_STAMP(i) do {} while (0)
+#endif
 
 namespace {
 
@@ -38,6 +46,7 @@ struct PgP {
   int nMT, nNT, S;
   int stepsPerSample, steps, per;                  // 16-position steps: per sample, total, per split
   int rem;                                         // (position-split waves) K % 32
+  unsigned long long* stamps;                      // debug build (E2_PWKS_STAMPS): 8 s_memtime stamps per work-group
 };
 
 // lane's float4 of a 16-position step: positions k0 + 4q .. + 3 of one channel row; past the end
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 
   const int u0 = sp * p.per + wave, u1 = min(sp * p.per + p.per, p.steps);
   const int cnt = u0 < u1 ? (u1 - u0 + 3) >> 2 : 0;
+  KS_STAMP(0);
 
   // BYTE offsets of the lane's rows inside a sample (32 bits: checked by the host), so that a
   // load is "scalar sample base + vector offset"
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     for (int nb = 0; nb < NT; ++nb) load2(Bc[nb], bp, boff[nb] + kb);
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) load2(A[mb], ap, aoff[mb] + kb);
+    KS_STAMP(1);
     // ONE loop body (accumulators stay where they are): the last trip requests its own unit
     // again -- L1 / L2 hits, nothing waits for them
 #pragma unroll 1
@@ -276,8 +287,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
       }
 #pragma unroll
       for (int nb = 0; nb < NT; ++nb) { Bc[nb][0] = Bn[nb][0]; Bc[nb][1] = Bn[nb][1]; }
+#ifdef E2_DEBUG_ENV
+      if (i == 0) KS_STAMP(2);
+#endif
     }
   }
+  KS_STAMP(3);
 
   // ---- the four partial tiles through LDS: D row = 4 q + r, col = l15 ------------------------
   float* mine = red + wave * RS;
@@ -288,6 +303,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) mine[(16 * mb + 4 * q + r) * RW + 16 * nb + l15] = acc[mb][nb][r];
   __syncthreads();
+  KS_STAMP(4);
 #pragma unroll 2
   for (int e = tid; e < 16 * MT * 16 * NT; e += 256) {
     const int ml = e / (16 * NT), nl = e - ml * (16 * NT);
@@ -299,6 +315,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     if (single) *dst += v;                           // (dw was zeroed or holds what to add to)
     else unsafeAtomicAdd(dst, v);
   }
+  KS_STAMP(5);
+#ifdef E2_DEBUG_ENV
+  if (p.stamps) { __builtin_amdgcn_s_waitcnt(0); KS_STAMP(6); }
+#endif
 }
 
 template <int MT, int NT>
@@ -311,8 +331,39 @@ int launch_ks(e2_ctx* ctx, const PgP& p, long grid) {
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     raised = true;
   }
+#ifdef E2_DEBUG_ENV
+  // in-kernel timeline (debug build): mean s_memtime ticks between the stamps over the work-groups
+  PgP ps = p;
+  const bool stamps = e2_dbg_env("E2_PWKS_STAMPS") != nullptr && !ctx->capturing;
+  if (stamps) {
+    E2_CHECK_HIP(hipMalloc(&ps.stamps, sizeof(unsigned long long) * 8 * grid));
+    E2_CHECK_HIP(hipMemsetAsync(ps.stamps, 0, sizeof(unsigned long long) * 8 * grid, ctx->stream));
+  }
+  hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, ps);
+  E2_CHECK_HIP(hipGetLastError());
+  if (stamps) {
+    E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> h(8 * grid);
+    E2_CHECK_HIP(hipMemcpy(h.data(), ps.stamps, sizeof(unsigned long long) * 8 * grid, hipMemcpyDeviceToHost));
+    static const char* names[6] = {"prologue issue", "first unit", "other units", "LDS + barrier", "flush issue", "flush done"};
+    double sum[6] = {0};
+    unsigned long long t0 = ~0ull, t1 = 0, s1 = 0;
+    long nb = 0;
+    for (long b = 0; b < grid; ++b) {
+      if (!h[8 * b + 6]) continue;                   // (pad / tail work-groups)
+      ++nb;
+      for (int i = 0; i < 6; ++i) sum[i] += (double)(h[8 * b + i + 1] - h[8 * b + i]);
+      t0 = std::min(t0, h[8 * b]); t1 = std::max(t1, h[8 * b + 6]); s1 = std::max(s1, h[8 * b]);
+    }
+    fprintf(stderr, "[e2] pw_wgrad_ks<%d,%d> grid %ld (%ld main), S %d, per %d: first start -> last end %llu ticks, last start %llu\n",
+            MT, NT, grid, nb, p.S, p.per, t1 - t0, s1 - t0);
+    for (int i = 0; i < 6; ++i) fprintf(stderr, "   %-14s %9.0f ticks\n", names[i], sum[i] / std::max(1L, nb));
+    (void)hipFree(ps.stamps);
+  }
+#else
   hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
+#endif
   return 0;
 }
 
@@ -341,7 +392,7 @@ int e2i_pw_wgrad(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   E2_REQUIRE(a.Cout % p.R == 0, "pointwise wgrad: %d rows for %d sub-positions", a.Cout, p.R);
   p.nMT = e2_cdiv(a.Cout, 32 * MT);
   p.nNT = e2_cdiv(a.Cin, 32 * NT);
-  p.rem = 0;
+  p.rem = 0; p.stamps = nullptr;
   p.stepsPerSample = (int)((K + 15) / 16);
   const long steps = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(steps < (1L << 30), "pointwise wgrad: too many positions");
@@ -381,7 +432,7 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.nMT = e2_cdiv(a.Cout, 16 * MT);
   p.nNT = e2_cdiv(a.Cin, 16 * NT);
   p.stepsPerSample = (int)(K / 32);                  // (here: WHOLE 32-position units)
-  p.rem = (int)(K % 32);
+  p.rem = (int)(K % 32); p.stamps = nullptr;
   const long units = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(units < (1L << 29), "pointwise wgrad: too many positions");
   p.steps = (int)units;
