@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(PgP p) {
 // through LDS and flushed once.  Operand registers: A is single-buffered -- block mb's two
 // float4 of the NEXT unit are requested right after block mb's MFMAs of this unit, so every
 // load has a whole unit (13 x 2 x 8 MFMAs = 2.8 us) to arrive -- B double-buffered.  Units are
-// WHOLE; the K % 32 last positions of the samples go to one extra work-group per tile.
+// WHOLE; the K % 32 last positions of the samples are a masked step of the last range's work-groups.
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   extern __shared__ float red[];
@@ -187,43 +187,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     return p.c + (long)m * p.Ncol + n;
   };
 
-  if (sp >= p.S) {
-    // ---- the K % 32 last positions of every sample: ONE more work-group per tile, masked
-    // loads, wave w takes the row blocks w, w + 4, ... and adds them straight from registers
-    if (sp > p.S || p.rem == 0) return;              // (grid padded to a multiple of 8)
-    const int k = p.K - p.rem + 4 * q;
-#pragma unroll 1
-    for (int mb = wave; mb < MT; mb += 4) {
-      f32x4 c[NT];
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) c[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const long ao = (long)min(m0 + 16 * mb + l15, p.M - 1) * p.asC;
-#pragma unroll 1
-      for (int n = 0; n < p.N; ++n) {
-        const float* ar = p.a + (long)n * p.asN + ao;
-        const f32x4 a0 = pg_load(ar, k, p.K), a1 = pg_load(ar, k + 16, p.K);
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-          const float* br = p.b + (long)n * p.bsN + (long)min(n0 + 16 * nb + l15, p.Ncol - 1) * p.bsC;
-          const f32x4 b0 = pg_load(br, k, p.K), b1 = pg_load(br, k + 16, p.K);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], c[nb], 0, 0, 0);
-            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], c[nb], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + 16 * mb + 4 * q + r, n = n0 + 16 * nb + l15;
-          if (m < p.M && n < p.Ncol) unsafeAtomicAdd(dst_of(m, n), c[nb][r]);
-        }
-    }
-    return;
-  }
-
+  if (sp >= p.S) return;                             // (grid padded to a multiple of 8)
   const int u0 = sp * p.per + wave, u1 = min(sp * p.per + p.per, p.steps);
   const int cnt = u0 < u1 ? (u1 - u0 + 3) >> 2 : 0;
   KS_STAMP(0);
@@ -319,6 +283,41 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 #ifdef E2_DEBUG_ENV
   if (p.stamps) { __builtin_amdgcn_s_waitcnt(0); KS_STAMP(6); }
 #endif
+  // ---- the K % 32 last positions of every sample: masked loads, by the work-groups of the LAST
+  // position range (the shortest one: per is rounded up); wave w takes the row blocks w, w + 4,
+  // ... and adds them straight from its registers
+  if (sp == p.S - 1 && p.rem > 0) {
+    const int k = p.K - p.rem + 4 * q;
+#pragma unroll 1
+    for (int mb = wave; mb < MT; mb += 4) {
+      f32x4 c[NT];
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) c[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const long ao = (long)min(m0 + 16 * mb + l15, p.M - 1) * p.asC;
+#pragma unroll 1
+      for (int n = 0; n < p.N; ++n) {
+        const float* ar = p.a + (long)n * p.asN + ao;
+        const f32x4 a0 = pg_load(ar, k, p.K), a1 = pg_load(ar, k + 16, p.K);
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) {
+          const float* br = p.b + (long)n * p.bsN + (long)min(n0 + 16 * nb + l15, p.Ncol - 1) * p.bsC;
+          const f32x4 b0 = pg_load(br, k, p.K), b1 = pg_load(br, k + 16, p.K);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], c[nb], 0, 0, 0);
+            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], c[nb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + 16 * mb + 4 * q + r, n = n0 + 16 * nb + l15;
+          if (m < p.M && n < p.Ncol) unsafeAtomicAdd(dst_of(m, n), c[nb][r]);
+        }
+    }
+  }
 }
 
 template <int MT, int NT>
@@ -440,7 +439,7 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.per = (int)std::max<long>(1, (units + S - 1) / S);
   p.per = (p.per + 3) & ~3;                          // whole rounds of the four waves
   p.S = (int)std::max<long>(1, (units + p.per - 1) / p.per);
-  long grid = (long)p.nMT * p.nNT * (p.S + (p.rem > 0 ? 1 : 0));   // (+ the work-groups of the K % 32 tails)
+  long grid = (long)p.nMT * p.nNT * p.S;
   grid = (grid + 7) & ~7L;                           // XCD-grouped order (the pad returns at once)
   E2_REQUIRE(grid < (1L << 31), "pointwise wgrad: grid too large");
   if (!a.accumulate)

@@ -11,8 +11,12 @@ import torch
 from elektronn2_amd import backend, autotune
 
 ctx = backend.Context(0)
-forced = sys.argv[1:]
-for name, sp in (("lite183", (10, 37, 37)), ("full185", (5, 21, 21))):
+forced = [a for a in sys.argv[1:] if not a.startswith("sp=")]
+shapes = [("lite183", (10, 37, 37)), ("full185", (5, 21, 21))]
+for a in sys.argv[1:]:
+    if a.startswith("sp="):                      # e.g. sp=8,40,43: rows of 13760 positions (64-byte aligned)
+        shapes = [(a, tuple(int(v) for v in a[3:].split(",")))]
+for name, sp in shapes:
     cin = cout = 200
     n = cout * sp[0] * sp[1] * sp[2]
     x = torch.rand(1, cin, *sp, device="cuda")
