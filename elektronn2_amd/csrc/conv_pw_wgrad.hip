@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   const int mt = L % p.nMT;
   const int sp = L / p.nMT;
   const int m0 = mt * 16 * MT, n0 = nt * 16 * NT;
-  const bool single = p.S == 1 && p.rem == 0;
+  const bool single = p.S == 1;
   auto dst_of = [&](int m, int n) -> float* {
     if (p.R > 1) { const int co = m / p.R; return p.c + (long)co * p.Ncol * p.R + (m - co * p.R) + (long)n * p.R; }
     return p.c + (long)m * p.Ncol + n;
@@ -257,6 +257,40 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     }
   }
   KS_STAMP(3);
+  // ---- the K % 32 last positions of every sample: one masked step of the work-groups of the LAST
+  // position range (the shortest one: per is rounded up).  Wave w takes the row blocks w, w + 4,
+  // ...; every load is a clamped dword + select (no branches: all of them are in flight at once)
+  if (sp == p.S - 1 && p.rem > 0) {
+    constexpr int MBW = (MT + 3) / 4;
+    const int k = p.K - p.rem + 4 * q;
+#pragma unroll 1
+    for (int n = 0; n < p.N; ++n) {
+      float av[MBW][8], bv[NT][8];
+      auto mload = [&](float (&d)[8], const float* row) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int pos = k + (e >> 2) * 16 + (e & 3);
+          const float v = row[min(pos, p.K - 1)];
+          d[e] = pos < p.K ? v : 0.f;
+        }
+      };
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb)
+        mload(bv[nb], p.b + (long)n * p.bsN + (long)min(n0 + 16 * nb + l15, p.Ncol - 1) * p.bsC);
+#pragma unroll
+      for (int i = 0; i < MBW; ++i)
+        mload(av[i], p.a + (long)n * p.asN + (long)min(m0 + 16 * min(wave + 4 * i, MT - 1) + l15, p.M - 1) * p.asC);
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb)
+        if ((mb & 3) == wave) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int nb = 0; nb < NT; ++nb)
+              acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mb >> 2][e], bv[nb][e], acc[mb][nb], 0, 0, 0);
+        }
+    }
+  }
 
   // ---- the four partial tiles through LDS: D row = 4 q + r, col = l15 ------------------------
   float* mine = red + wave * RS;
@@ -283,41 +317,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 #ifdef E2_DEBUG_ENV
   if (p.stamps) { __builtin_amdgcn_s_waitcnt(0); KS_STAMP(6); }
 #endif
-  // ---- the K % 32 last positions of every sample: masked loads, by the work-groups of the LAST
-  // position range (the shortest one: per is rounded up); wave w takes the row blocks w, w + 4,
-  // ... and adds them straight from its registers
-  if (sp == p.S - 1 && p.rem > 0) {
-    const int k = p.K - p.rem + 4 * q;
-#pragma unroll 1
-    for (int mb = wave; mb < MT; mb += 4) {
-      f32x4 c[NT];
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb) c[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const long ao = (long)min(m0 + 16 * mb + l15, p.M - 1) * p.asC;
-#pragma unroll 1
-      for (int n = 0; n < p.N; ++n) {
-        const float* ar = p.a + (long)n * p.asN + ao;
-        const f32x4 a0 = pg_load(ar, k, p.K), a1 = pg_load(ar, k + 16, p.K);
-#pragma unroll
-        for (int nb = 0; nb < NT; ++nb) {
-          const float* br = p.b + (long)n * p.bsN + (long)min(n0 + 16 * nb + l15, p.Ncol - 1) * p.bsC;
-          const f32x4 b0 = pg_load(br, k, p.K), b1 = pg_load(br, k + 16, p.K);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], c[nb], 0, 0, 0);
-            c[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], c[nb], 0, 0, 0);
-          }
-        }
-      }
-#pragma unroll
-      for (int nb = 0; nb < NT; ++nb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + 16 * mb + 4 * q + r, n = n0 + 16 * nb + l15;
-          if (m < p.M && n < p.Ncol) unsafeAtomicAdd(dst_of(m, n), c[nb][r]);
-        }
-    }
-  }
 }
 
 template <int MT, int NT>
