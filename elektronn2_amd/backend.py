@@ -37,6 +37,33 @@ class Tensor5(C.Structure):
                 ("sh", C.c_int64)]
 
 
+class Bf16Dst(C.Structure):
+    """e2_bf16_dst (include/e2hip.h): where a producer kernel puts the bf16 copies of its output"""
+    _fields_ = [("cl", C.c_void_p), ("cl_kg", C.c_int32), ("cl_d", C.c_int32), ("cl_h", C.c_int32),
+                ("cl_w", C.c_int32), ("cl_oz", C.c_int32), ("cl_oy", C.c_int32), ("cl_ox", C.c_int32),
+                ("pl", C.c_void_p), ("pl_plane", C.c_int64), ("pl_pitch", C.c_int32)]
+
+
+def bf16_dst(cl=None, cl_dims=None, cl_off=(0, 0, 0), pl=None, pl_plane=0, pl_pitch=0):
+    """cl: uint8 device tensor holding [n][d][kg][h][w][8] bf16 (cl_dims = (kg, d, h, w)); pl: uint8
+    device tensor holding [n][c][d][pl_plane] bf16"""
+    d = Bf16Dst()
+    d.cl = cl.data_ptr() if cl is not None else None
+    if cl is not None:
+        d.cl_kg, d.cl_d, d.cl_h, d.cl_w = (int(v) for v in cl_dims)
+        d.cl_oz, d.cl_oy, d.cl_ox = (int(v) for v in cl_off)
+    d.pl = pl.data_ptr() if pl is not None else None
+    d.pl_plane, d.pl_pitch = int(pl_plane), int(pl_pitch)
+    return d
+
+
+def t5_shape(shape):
+    """a Tensor5 that carries extents only (null pointer): the shape argument of the entry points
+    whose operand was made ahead of the call"""
+    n, c, d, h, w = (int(v) for v in shape)
+    return Tensor5(None, n, c, d, h, w, c * d * h * w, d * h * w, h * w, w)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise E2Error(
@@ -129,6 +156,17 @@ def _load():
         "e2_conv3d_bf16_xkeep_bytes": (sz, [i, i, i, i, i, i, i]),
         "e2_conv3d_fwd_bf16_keep": (C.c_int, [vp, P5, fp, i, i, i, i, fp, i, P5, vp, sz, vp, sz]),
         "e2_conv3d_wgrad_bf16_xcl": (C.c_int, [vp, P5, vp, i, P5, fp, i, i, i, i, vp, sz]),
+        "e2_pool_bias_act_bwd_bf16": (C.c_int, [vp, P5, C.c_int64, i, P5, fp, i, i, i, i, P5, fp, C.POINTER(Bf16Dst)]),
+        "e2_pool_bias_act_fwd_bf16": (C.c_int, [vp, P5, C.c_int64, i, fp, i, i, i, i, P5, C.POINTER(Bf16Dst)]),
+        "e2_conv3d_bf16_wb_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
+        "e2_bf16_wjob_bytes": (sz, []),
+        "e2_bf16_wjob_fill": (C.c_int, [vp, fp, i, i, i, i, i, i, i, i, i, i, vp, sz]),
+        "e2_conv3d_bf16_pack_w_multi": (C.c_int, [vp, vp, i]),
+        "e2_conv3d_fwd_bf16_ex": (C.c_int, [vp, P5, fp, i, i, i, i, fp, i, P5, vp, sz, vp, sz, i, vp, vp, i]),
+        "e2_conv3d_dgrad_bf16_ex": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz, vp, vp]),
+        "e2_conv3d_wgrad_bf16_geometry": (C.c_int, [i, i, i, i, i, i, i, i, i, C.POINTER(C.c_int64),
+                                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+        "e2_conv3d_wgrad_bf16_ex": (C.c_int, [vp, P5, vp, i, P5, vp, fp, fp, i, i, i, i, vp, sz]),
         "e2_dense_fwd": (C.c_int, [vp, fp, fp, fp, i, i, i]),
         "e2_dense_dgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
         "e2_dense_wgrad": (C.c_int, [vp, fp, fp, fp, i, i, i, i]),
@@ -640,6 +678,107 @@ class Context:
 
     def bf16_memory_wgrad(self):
         return getattr(self, '_tiling', {}).get('wgrad', '').startswith('32,')
+
+    # ---- the producers' epilogues: operands made ahead of the GEMM launches ------------------
+    @staticmethod
+    def bf16_tile(tiling):
+        """(MB, NB) of a "32,MB,NB[,...]" tiling string, else None"""
+        v = (tiling or '').split(',')
+        if len(v) >= 3 and v[0] == '32':
+            return int(v[1]), int(v[2])
+        return None
+
+    @staticmethod
+    def conv_bf16_wb_bytes(rows, kk, k, in_w, out_w, tile):
+        return int(_lib.e2_conv3d_bf16_wb_bytes(int(rows), int(kk), k[0], k[1], k[2], int(in_w),
+                                                int(out_w), tile[0], tile[1]))
+
+    def make_bf16_wjobs(self, jobs):
+        """jobs: list of (w5 tensor (nf, nin, kd, kh, kw), mode, in_w, out_w, (MB, NB), wb uint8
+        tensor).  Returns (device records, count) for conv3d_bf16_pack_w_multi."""
+        rec = int(_lib.e2_bf16_wjob_bytes())
+        buf = (C.c_char * (rec * len(jobs)))()
+        for n, (w, mode, in_w, out_w, tile, wb) in enumerate(jobs):
+            nf, nin, kd, kh, kw = w.shape
+            _chk(_lib.e2_bf16_wjob_fill(C.byref(buf, n * rec), _fp(w), nf, nin, kd, kh, kw, int(mode),
+                                        int(in_w), int(out_w), tile[0], tile[1],
+                                        C.c_void_p(wb.data_ptr()), wb.numel()), "e2_bf16_wjob_fill")
+        host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+        return host.to(self.device), len(jobs)
+
+    def conv3d_bf16_pack_w_multi(self, jobs_dev, njobs):
+        _chk(_lib.e2_conv3d_bf16_pack_w_multi(self.h, C.c_void_p(jobs_dev.data_ptr()), njobs),
+             "e2_conv3d_bf16_pack_w_multi")
+
+    def conv3d_fwd_bf16_ex(self, x, w, y, bias=None, act='lin', ws=None, xkeep=None, x_ready=False,
+                           wb=None, next_xb=None, next_kg=0):
+        """conv3d_fwd_bf16 with ready-made operands (include/e2hip.h): x_ready: xkeep holds this
+        step's copy of x; wb: the packed filter rows; next_xb: receives the channels-last bf16
+        copy of y for the next layer"""
+        cout, cin, kd, kh, kw = w.shape
+        if ws is None and not (x_ready and wb is not None):
+            ws = self.workspace("conv_bf16", self.conv_bf16_ws_bytes(x.shape, cout, (kd, kh, kw)))
+        _chk(_lib.e2_conv3d_fwd_bf16_ex(
+            self.h, C.byref(t5(x)), _fp(w), cout, kd, kh, kw, _fp(bias), ACT[act], C.byref(t5(y)),
+            C.c_void_p(ws.data_ptr()) if ws is not None else None,
+            ws.numel() * ws.element_size() if ws is not None else 0,
+            C.c_void_p(xkeep.data_ptr()) if xkeep is not None else None,
+            xkeep.numel() * xkeep.element_size() if xkeep is not None else 0, int(bool(x_ready)),
+            C.c_void_p(wb.data_ptr()) if wb is not None else None,
+            C.c_void_p(next_xb.data_ptr()) if next_xb is not None else None, int(next_kg)),
+            "e2_conv3d_fwd_bf16_ex")
+
+    def conv3d_dgrad_bf16_ex(self, dy_pad, w, dx, ws=None, dy_cl=None, wb=None):
+        cout, cin, kd, kh, kw = w.shape
+        if ws is None and not (dy_cl is not None and wb is not None):
+            ws = self.workspace("conv_bf16", self.conv_bf16_ws_bytes(dx.shape, cout, (kd, kh, kw)))
+        _chk(_lib.e2_conv3d_dgrad_bf16_ex(
+            self.h, C.byref(t5(dy_pad)), _fp(w), cin, kd, kh, kw, C.byref(t5(dx)),
+            C.c_void_p(ws.data_ptr()) if ws is not None else None,
+            ws.numel() * ws.element_size() if ws is not None else 0,
+            C.c_void_p(dy_cl.data_ptr()) if dy_cl is not None else None,
+            C.c_void_p(wb.data_ptr()) if wb is not None else None), "e2_conv3d_dgrad_bf16_ex")
+
+    @staticmethod
+    def wgrad_bf16_geometry(x_shape, cout, k):
+        """(elements per dy plane, bytes of the dy planes, bytes of the f32 sums) of
+        conv3d_wgrad_bf16_ex's ready-made operands"""
+        n, cin, d, h, w = (int(v) for v in x_shape)
+        pd, db, sb = C.c_int64(), C.c_size_t(), C.c_size_t()
+        _chk(_lib.e2_conv3d_wgrad_bf16_geometry(n, cin, d, h, w, int(cout), k[0], k[1], k[2],
+                                                C.byref(pd), C.byref(db), C.byref(sb)),
+             "e2_conv3d_wgrad_bf16_geometry")
+        return int(pd.value), int(db.value), int(sb.value)
+
+    def conv3d_wgrad_bf16_ex(self, x, dy, dw, accumulate=False, ws=None, xcl=None, dyc=None, sums=None):
+        """conv3d_wgrad_bf16 with ready-made operands: xcl (the forward's kept copy of x), dyc
+        (the bf16 planes of dy written by its producer), sums (a zeroed f32 buffer of the
+        caller's, left zero)"""
+        cout, cin, kd, kh, kw = dw.shape
+        if ws is None and not (xcl is not None and dyc is not None and sums is not None):
+            ws = self.workspace("wgrad_bf16", self.wgrad_bf16_ws_bytes(x.shape, cout, (kd, kh, kw)))
+        _chk(_lib.e2_conv3d_wgrad_bf16_ex(
+            self.h, C.byref(t5(x)), C.c_void_p(xcl.data_ptr()) if xcl is not None else None,
+            (cin + 15) // 16 * 2, C.byref(t5(dy)),
+            C.c_void_p(dyc.data_ptr()) if dyc is not None else None, _fp(sums), _fp(dw),
+            kd, kh, kw, int(accumulate),
+            C.c_void_p(ws.data_ptr()) if ws is not None else None,
+            ws.numel() * ws.element_size() if ws is not None else 0), "e2_conv3d_wgrad_bf16_ex")
+
+    def pool_bias_act_bwd_bf16(self, dout, src, bias, pool, act, dy, dbias, dst, parts=1, part_stride=0):
+        """pool_bias_act_bwd (bias given: src = conv output) / bias_act_bwd_out (bias None: src =
+        activated output) writing dy (f32, or None) and the bf16 copies named by dst (bf16_dst)"""
+        dyv = t5(dy) if dy is not None else Tensor5(None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+        _chk(_lib.e2_pool_bias_act_bwd_bf16(self.h, C.byref(t5(dout)), int(part_stride), int(parts),
+                                            C.byref(t5(src)), _fp(bias), pool[0], pool[1], pool[2],
+                                            ACT[act], C.byref(dyv), _fp(dbias), C.byref(dst)),
+             "e2_pool_bias_act_bwd_bf16")
+
+    def pool_bias_act_fwd_bf16(self, y, bias, pool, act, out, dst, parts=1, part_stride=0):
+        _chk(_lib.e2_pool_bias_act_fwd_bf16(self.h, C.byref(t5(y)), int(part_stride), int(parts),
+                                            _fp(bias), pool[0], pool[1], pool[2], ACT[act],
+                                            C.byref(t5(out)), C.byref(dst)),
+             "e2_pool_bias_act_fwd_bf16")
 
     # ---- config 1 (mnist): Perceptron dot product, batch normalisation ------------------
     def dense_fwd(self, x, w, y):

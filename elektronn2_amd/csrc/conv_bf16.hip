@@ -27,6 +27,7 @@
 #include <algorithm>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* gbl_vp;
@@ -60,6 +61,10 @@ struct CbP {
   // steps of a chunk -- (tap, pair of its channel groups) -- are padded to FL / LL (multiples
   // of the ring depth) with zero filter rows
   int KGC, nck, kgsLast, FL, LL;
+  // the epilogue's second output (forward with fused bias + act): the channels-last bf16 copy
+  // of `out` that the NEXT layer's kernels read, [N][Do][nxKG][Ho * Wo][8] -- or nullptr
+  __bf16* nxb;
+  int nxKG;
 };
 
 // ---- f32 (strided NCDHW view) -> Xb[n][z][kg][y][x][8] --------------------------------
@@ -139,6 +144,13 @@ __device__ __forceinline__ void pack_w_bf16_part(const PwP& q, int blk, int nblk
 __global__ __launch_bounds__(256) void prep_bf16_kernel(CvP c, PwP q, int cblocks) {
   if ((int)blockIdx.x < cblocks) cvt_bf16_part(c, blockIdx.x, cblocks);
   else pack_w_bf16_part(q, blockIdx.x - cblocks, gridDim.x - cblocks);
+}
+
+// the filter rows of MANY launches in one (the plan packs every layer's images at the start of
+// the step: e2_conv3d_bf16_pack_w_multi); blockIdx.y = job
+__global__ __launch_bounds__(256) void pack_w_bf16_multi_kernel(const PwP* __restrict__ jobs) {
+  const PwP q = jobs[blockIdx.y];
+  pack_w_bf16_part(q, blockIdx.x, gridDim.x);
 }
 
 // ---- the GEMM -----------------------------------------------------------------------
@@ -330,14 +342,34 @@ __global__ __launch_bounds__(256) void conv_bf16_kernel(CbP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = m0 + mb * 32 + 8 * (i >> 2) + 4 * kh8 + (i & 3);
-        if (co >= p.Cout) continue;
         float v = acc[mb][nb][i];
-        if (p.bias) {
-          v += p.bias[co];
-          if (p.act == E2_ACT_RELU) v = (v > 0.f) ? v : ((v == 0.f) ? 0.f : -0.f);
+        if (co < p.Cout) {
+          if (p.bias) {
+            v += p.bias[co];
+            if (p.act == E2_ACT_RELU) v = (v > 0.f) ? v : ((v == 0.f) ? 0.f : -0.f);
+          }
+          ob[(long)co * p.osC] = v;
+        } else {
+          v = 0.f;                                  // (padding channels of the next layer's copy)
         }
-        ob[(long)co * p.osC] = v;
+        acc[mb][nb][i] = v;
       }
+    if (p.nxb) {
+      // lanes (c32, kh8 = 0 / 1) hold channels 8g + 0..3 / 8g + 4..7 of position q: the two
+      // 8-byte halves of one pixel piece
+      __bf16* nb0 = p.nxb + ((((long)n * p.Do + z) * p.nxKG) * p.Q + q) * 8 + 4 * kh8;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int kg = ((m0 + mb * 32) >> 3) + g;
+          if (kg >= p.nxKG) continue;
+          bf16x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = (__bf16)acc[mb][nb][4 * g + e];
+          *reinterpret_cast<bf16x4*>(nb0 + (long)kg * p.Q * 8) = h;
+        }
+    }
   }
 }
 
@@ -369,54 +401,95 @@ static int span_pixels(int BN, int Wo, int Win, int kh, int kw) {
   return (BN - 1) + rows * (Win - Wo) + (kh - 1) * Win + kw;
 }
 
+// the geometry of one launch: a function of the GEMM's shape and tile only (the plan packs the
+// filter rows ahead of the launch with the same numbers, e2_bf16_wjob_fill)
+struct CbGeo {
+  int Cp, KG, ocP, T2, Lpad, KGC, nck, kgsLast, FL, LL, DL;
+  size_t bufBytes, ldsb, wb_bytes;
+  bool ok;
+};
+static CbGeo cb_geo(int rows, int kk, int kd, int kh, int kw, int in_w, int out_w, int MB, int NB) {
+  CbGeo g;
+  g.ok = false;
+  g.Cp = pad16(kk); g.KG = g.Cp / 8;
+  g.ocP = (rows + 32 * MB - 1) / (32 * MB) * (32 * MB);          // whole wave tiles
+  g.T2 = kh * kw;
+  g.Lpad = (span_pixels(64 * NB, out_w, in_w, kh, kw) + 3) / 4 * 4;
+  // channel groups per LDS chunk: two buffers within ~72 KB, so that two work-groups share
+  // a CU; an even count, as equal as possible over the chunks
+  g.KGC = (int)std::min<long>(g.KG, (36 * 1024) / ((long)g.Lpad * 16) / 2 * 2);
+  if (g.KGC < 2) return g;
+  g.nck = (g.KG + g.KGC - 1) / g.KGC;
+  g.KGC = ((g.KG / 2 + g.nck - 1) / g.nck) * 2;                  // balance the chunks
+  g.nck = (g.KG + g.KGC - 1) / g.KGC;
+  g.kgsLast = g.KG - (g.nck - 1) * g.KGC;
+  g.FL = (g.T2 * (g.KGC / 2) + kPD - 1) / kPD * kPD;
+  g.LL = (g.T2 * (g.kgsLast / 2) + kPD - 1) / kPD * kPD;
+  g.DL = (g.nck - 1) * g.FL + g.LL;
+  g.bufBytes = (size_t)g.KGC * g.Lpad * 16;
+  g.ldsb = (kd * g.nck > 1 ? 2 : 1) * g.bufBytes;
+  g.wb_bytes = ((size_t)kd * g.DL + kPD) * 2 * g.ocP * 8 * 2;
+  g.ok = true;
+  return g;
+}
+
+// what a caller may hand over ready-made (all optional)
+struct CbExt {
+  const void* xb = nullptr;      // the channels-last bf16 copy of `in` (its producer wrote it)
+  const void* wb = nullptr;      // the filter rows (e2_conv3d_bf16_pack_w_multi, same tile)
+  void* nxb = nullptr;           // forward: receives the channels-last bf16 copy of `out`
+  int nxKG = 0;
+};
+
 // in: input view (forward: x; data gradient: the zero-padded dy); rows = output channels of
 // the GEMM (forward: n_f; data gradient: n_in), kk = its reduction channels
 static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, int nin, int kd,
                      int kh, int kw, int mode, const float* bias, int act, const e2_tensor5* out,
                      void* ws, size_t ws_bytes, int MB, int NB, void* xkeep = nullptr,
-                     size_t xkeep_bytes = 0) {
+                     size_t xkeep_bytes = 0, const CbExt& ext = CbExt()) {
   const int rows = mode ? nin : nf, kk = mode ? nf : nin;
   E2_REQUIRE(in->c == kk && out->c == rows, "conv_bf16: channel mismatch");
   E2_REQUIRE(out->n == in->n && out->d == in->d - kd + 1 && out->h == in->h - kh + 1 &&
                  out->w == in->w - kw + 1, "conv_bf16: out shape does not match in - k + 1");
-  const int Cp = pad16(kk), KG = Cp / 8;
-  const int ocP = (rows + 32 * MB - 1) / (32 * MB) * (32 * MB);   // whole wave tiles
-  const int T2 = kh * kw;
-  const int Lpad = (span_pixels(64 * NB, out->w, in->w, kh, kw) + 3) / 4 * 4;
-  // channel groups per LDS chunk: two buffers within ~72 KB, so that two work-groups share
-  // a CU; an even count, as equal as possible over the chunks
-  int KGC = (int)std::min<long>(KG, (36 * 1024) / ((long)Lpad * 16) / 2 * 2);
-  E2_REQUIRE(KGC >= 2, "conv_bf16: the window of one channel-group pair (%d pixels) does not fit LDS", Lpad);
-  int nck = (KG + KGC - 1) / KGC;
-  KGC = ((KG / 2 + nck - 1) / nck) * 2;         // balance the chunks
-  nck = (KG + KGC - 1) / KGC;
-  const int kgsLast = KG - (nck - 1) * KGC;
-  const int FL = (T2 * (KGC / 2) + kPD - 1) / kPD * kPD;
-  const int LL = (T2 * (kgsLast / 2) + kPD - 1) / kPD * kPD;
-  const int DL = (nck - 1) * FL + LL;
-  const size_t bufBytes = (size_t)KGC * Lpad * 16;
-  const size_t ldsb = (kd * nck > 1 ? 2 : 1) * bufBytes;
+  const CbGeo g = cb_geo(rows, kk, kd, kh, kw, in->w, out->w, MB, NB);
+  E2_REQUIRE(g.ok, "conv_bf16: the window of one channel-group pair (%d pixels) does not fit LDS", g.Lpad);
+  const int Cp = g.Cp, KG = g.KG, ocP = g.ocP, T2 = g.T2, Lpad = g.Lpad, KGC = g.KGC, nck = g.nck;
+  const int kgsLast = g.kgsLast, FL = g.FL, LL = g.LL, DL = g.DL;
+  const size_t ldsb = g.ldsb;
   E2_REQUIRE(ldsb <= 160 * 1024, "conv_bf16: LDS window of %zu B", ldsb);
   const size_t xb_bytes = (size_t)in->n * in->d * in->h * in->w * Cp * 2;
-  const size_t wb_bytes = ((size_t)kd * DL + kPD) * 2 * ocP * 8 * 2;
-  const size_t need = ((xb_bytes + 255) / 256) * 256 + wb_bytes + 256;
-  E2_REQUIRE(ws && ws_bytes >= need, "conv_bf16: workspace of %zu bytes needed, %zu given", need, ws_bytes);
-  E2_REQUIRE(((uintptr_t)ws & 15) == 0, "conv_bf16: workspace must be 16-byte aligned");
+  const size_t wb_bytes = g.wb_bytes;
+  const bool need_x = !ext.xb, need_w = !ext.wb;
+  const size_t need = ((need_x && !xkeep) ? ((xb_bytes + 255) / 256) * 256 : 0) + (need_w ? wb_bytes + 256 : 0);
+  E2_REQUIRE(need == 0 || (ws && ws_bytes >= need), "conv_bf16: workspace of %zu bytes needed, %zu given", need, ws_bytes);
+  E2_REQUIRE(need == 0 || ((uintptr_t)ws & 15) == 0, "conv_bf16: workspace must be 16-byte aligned");
+  E2_REQUIRE(((uintptr_t)ext.xb & 15) == 0 && ((uintptr_t)ext.wb & 15) == 0 && ((uintptr_t)ext.nxb & 15) == 0,
+             "conv_bf16: ready-made operands must be 16-byte aligned");
   E2_REQUIRE((long)ocP * 32 < (1L << 31), "conv_bf16: too many channels");
   E2_REQUIRE(!xkeep || (xkeep_bytes >= xb_bytes && ((uintptr_t)xkeep & 15) == 0),
              "conv_bf16: the kept input copy needs %zu bytes, 16-byte aligned (%zu given)", xb_bytes, xkeep_bytes);
+  E2_REQUIRE(!ext.nxb || (mode == 0 && ext.nxKG * 8 >= rows && ext.nxKG * 8 <= ocP),
+             "conv_bf16: the next layer's copy holds %d channel groups for %d channels (%d rows computed)",
+             ext.nxKG, rows, ocP);
   // (xkeep: the channels-last bf16 copy of the input goes to the caller's buffer instead of
   // the workspace -- the layer's weight gradient reads it again, e2_conv3d_wgrad_bf16_xcl)
-  __bf16* xb = xkeep ? reinterpret_cast<__bf16*>(xkeep) : reinterpret_cast<__bf16*>(ws);
-  __bf16* wb = reinterpret_cast<__bf16*>((char*)ws + ((xb_bytes + 255) / 256) * 256);
-  CvP c{in->ptr, in->sn, in->sc, in->sd, in->sh, in->n, in->c, in->d, in->h, in->w, KG, xb};
-  const long ctot = (long)in->n * in->d * in->h * KG * in->w;
-  const long wtot = ((long)kd * DL + kPD) * 2 * ocP * 8;
-  const int cblocks = (int)std::min<long>((ctot + 255) / 256, 8192);
-  const int wblocks = (int)std::min<long>((wtot + 255) / 256, 2048);
-  PwP q{w, wb, nf, nin, kd, T2, ocP, mode, KGC, nck, kgsLast, FL, LL};
-  hipLaunchKernelGGL(prep_bf16_kernel, dim3((unsigned)(cblocks + wblocks)), dim3(256), 0, ctx->stream,
-                     c, q, cblocks);
+  const __bf16* xb;
+  char* wsp = reinterpret_cast<char*>(ws);
+  if (ext.xb) xb = reinterpret_cast<const __bf16*>(ext.xb);
+  else if (xkeep) xb = reinterpret_cast<const __bf16*>(xkeep);
+  else { xb = reinterpret_cast<const __bf16*>(wsp); wsp += ((xb_bytes + 255) / 256) * 256; }
+  const __bf16* wb = ext.wb ? reinterpret_cast<const __bf16*>(ext.wb) : reinterpret_cast<const __bf16*>(wsp);
+  if (need_x || need_w) {
+    CvP c{in->ptr, in->sn, in->sc, in->sd, in->sh, in->n, in->c, in->d, in->h, in->w, KG, const_cast<__bf16*>(xb)};
+    const long ctot = (long)in->n * in->d * in->h * KG * in->w;
+    const long wtot = ((long)kd * DL + kPD) * 2 * ocP * 8;
+    const int cblocks = need_x ? (int)std::min<long>((ctot + 255) / 256, 8192) : 0;
+    const int wblocks = need_w ? (int)std::min<long>((wtot + 255) / 256, 2048) : 0;
+    PwP q{w, const_cast<__bf16*>(wb), nf, nin, kd, T2, ocP, mode, KGC, nck, kgsLast, FL, LL};
+    E2_REQUIRE(!need_w || w, "conv_bf16: null weights");
+    hipLaunchKernelGGL(prep_bf16_kernel, dim3((unsigned)(cblocks + wblocks)), dim3(256), 0, ctx->stream,
+                       c, q, cblocks);
+  }
   CbP p;
   p.xb = xb; p.wb = wb; p.out = out->ptr;
   p.osN = out->sn; p.osC = out->sc; p.osZ = out->sd; p.osY = out->sh;
@@ -428,6 +501,7 @@ static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, 
   p.nPT = (p.Q + 64 * NB - 1) / (64 * NB);
   p.nMT = (ocP + 64 * MB - 1) / (64 * MB);
   p.Lpad = Lpad; p.KGC = KGC; p.nck = nck; p.kgsLast = kgsLast; p.FL = FL; p.LL = LL;
+  p.nxb = reinterpret_cast<__bf16*>(ext.nxb); p.nxKG = ext.nxKG;
   const long units = (long)p.N * p.Do * p.nPT;
   const long grid = (units + 7) / 8 * 8 * p.nMT;
   E2_REQUIRE(grid < (1L << 31), "conv_bf16: grid too large");
@@ -509,4 +583,70 @@ extern "C" int e2_conv3d_dgrad_bf16(e2_ctx* ctx, const e2_tensor5* dy_pad, const
   int MB, NB;
   tile_from_ctx(ctx, &MB, &NB);
   return conv_bf16(ctx, dy_pad, w, dy_pad->c, cin, kd, kh, kw, 1, nullptr, 0, dx, ws, ws_bytes, MB, NB);
+}
+
+// ---- operands made ahead of the launch (the producers' epilogues) ----------
+extern "C" size_t e2_conv3d_bf16_wb_bytes(int rows, int kk, int kd, int kh, int kw, int in_w,
+                                          int out_w, int mb, int nb) {
+  const CbGeo g = cb_geo(rows, kk, kd, kh, kw, in_w, out_w, mb, nb);
+  return g.ok ? g.wb_bytes + 256 : 0;
+}
+
+extern "C" size_t e2_bf16_wjob_bytes(void) { return sizeof(PwP); }
+
+extern "C" int e2_bf16_wjob_fill(void* rec, const float* w, int nf, int nin, int kd, int kh, int kw,
+                                 int mode, int in_w, int out_w, int mb, int nb, void* wb,
+                                 size_t wb_bytes) {
+  E2_REQUIRE(rec && w && wb && ((uintptr_t)wb & 15) == 0, "bf16_wjob_fill: null / unaligned argument");
+  const int rows = mode ? nin : nf, kk = mode ? nf : nin;
+  const CbGeo g = cb_geo(rows, kk, kd, kh, kw, in_w, out_w, mb, nb);
+  E2_REQUIRE(g.ok && wb_bytes >= g.wb_bytes, "bf16_wjob_fill: %zu bytes given, %zu needed", wb_bytes, g.wb_bytes);
+  PwP q{w, reinterpret_cast<__bf16*>(wb), nf, nin, kd, g.T2, g.ocP, mode, g.KGC, g.nck, g.kgsLast, g.FL, g.LL};
+  *reinterpret_cast<PwP*>(rec) = q;
+  return 0;
+}
+
+extern "C" int e2_conv3d_bf16_pack_w_multi(e2_ctx* ctx, const void* jobs_dev, int njobs) {
+  E2_REQUIRE(ctx && jobs_dev && njobs > 0, "conv3d_bf16_pack_w_multi: bad argument");
+  hipLaunchKernelGGL(pack_w_bf16_multi_kernel, dim3(256, (unsigned)njobs), dim3(256), 0, ctx->stream,
+                     reinterpret_cast<const PwP*>(jobs_dev));
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// forward / data gradient with any of {input copy, filter rows} ready-made, and (forward) the
+// next layer's input copy as a second output; the tile must be the one the filter rows were
+// packed for (the forced "32,MB,NB")
+extern "C" int e2_conv3d_fwd_bf16_ex(e2_ctx* ctx, const e2_tensor5* x, const float* w, int cout,
+                                     int kd, int kh, int kw, const float* bias, int act,
+                                     const e2_tensor5* out, void* ws, size_t ws_bytes,
+                                     void* xkeep, size_t xkeep_bytes, int x_ready, const void* wb,
+                                     void* next_xb, int next_kg) {
+  E2_REQUIRE(ctx && (w || wb), "conv3d_fwd_bf16_ex: null argument");
+  E2_REQUIRE(x && x->n > 0 && x->c > 0 && x->d > 0 && x->h > 0 && x->w > 0 && (x->ptr || x_ready),
+             "conv3d_fwd_bf16_ex: bad x");
+  if (int rc = view_ok(out, "conv3d_fwd_bf16_ex out")) return rc;
+  E2_REQUIRE(!bias || act == E2_ACT_LIN || act == E2_ACT_RELU, "conv3d_fwd_bf16_ex: bad act %d", act);
+  E2_REQUIRE(!x_ready || xkeep, "conv3d_fwd_bf16_ex: x_ready names the copy in xkeep");
+  int MB, NB;
+  tile_from_ctx(ctx, &MB, &NB);
+  CbExt e;
+  e.xb = x_ready ? xkeep : nullptr; e.wb = wb; e.nxb = next_xb; e.nxKG = next_kg;
+  return conv_bf16(ctx, x, w, cout, x->c, kd, kh, kw, 0, bias, act, out, ws, ws_bytes, MB, NB,
+                   xkeep, xkeep_bytes, e);
+}
+
+extern "C" int e2_conv3d_dgrad_bf16_ex(e2_ctx* ctx, const e2_tensor5* dy_pad, const float* w, int cin,
+                                       int kd, int kh, int kw, const e2_tensor5* dx, void* ws,
+                                       size_t ws_bytes, const void* dy_cl, const void* wb) {
+  E2_REQUIRE(ctx && (w || wb), "conv3d_dgrad_bf16_ex: null argument");
+  E2_REQUIRE(dy_pad && dy_pad->n > 0 && dy_pad->c > 0 && dy_pad->d > 0 && dy_pad->h > 0 && dy_pad->w > 0 &&
+                 (dy_pad->ptr || dy_cl), "conv3d_dgrad_bf16_ex: bad dy_pad");
+  if (int rc = view_ok(dx, "conv3d_dgrad_bf16_ex dx")) return rc;
+  int MB, NB;
+  tile_from_ctx(ctx, &MB, &NB);
+  CbExt e;
+  e.xb = dy_cl; e.wb = wb;
+  return conv_bf16(ctx, dy_pad, w, dy_pad->c, cin, kd, kh, kw, 1, nullptr, 0, dx, ws, ws_bytes, MB, NB,
+                   nullptr, 0, e);
 }

@@ -334,14 +334,15 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
 }
 
 // dw[oc][ic][tap] (+)= dwt[oc][tap][ic], through an LDS tile so that both sides are coalesced
-__global__ __launch_bounds__(256) void wgrad_bf16_out_kernel(const float* __restrict__ dwt, float* __restrict__ dw,
-                                                             int Cin, int CinP, int T, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_bf16_out_kernel(float* __restrict__ dwt, float* __restrict__ dw,
+                                                             int Cin, int CinP, int T, int accumulate, int rezero) {
   extern __shared__ float tile[];                // [T][33]
   const int oc = blockIdx.y, ic0 = blockIdx.x * 32;
   const int nic = min(32, Cin - ic0);
   for (int i = threadIdx.x; i < T * 32; i += 256) {
     const int t = i >> 5, c = i & 31;
     tile[t * 33 + c] = dwt[((long)oc * T + t) * CinP + ic0 + c];
+    if (rezero) dwt[((long)oc * T + t) * CinP + ic0 + c] = 0.f;   // (a caller-owned sum buffer stays zero between calls)
   }
   __syncthreads();
   float* o = dw + ((long)oc * Cin + ic0) * T;
@@ -401,26 +402,36 @@ extern "C" size_t e2_conv3d_wgrad_bf16_workspace_bytes(int n, int cin, int d, in
 // xcl_ext != nullptr: the channels-last bf16 copy of x already exists (written by the layer's
 // forward pass, e2_conv3d_fwd_bf16_keep: the same layout with kgs_ext channel groups per
 // plane and zero pixels behind the last plane) -- x is used for its shape only
+// dyc_ext != nullptr: the channel-major bf16 planes of dy already exist (written by the kernel that
+// produced dy, e2_pool_bias_act_bwd_bf16: [n][oc][z][planeD] at the input's row pitch, zeros in
+// the gaps and 2 KB behind the end) -- dy is used for its shape only.  dwt_ext: the f32 sums
+// live in the caller's buffer (e2_conv3d_wgrad_bf16_sums_bytes), ZERO on entry and zero again on
+// return.  With all three the conversion pass disappears and ws may be NULL.
 static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int kgs_ext,
                       const e2_tensor5* dy, float* dw, int kd, int kh, int kw, int accumulate,
-                      void* ws, size_t ws_bytes) {
+                      void* ws, size_t ws_bytes, const void* dyc_ext = nullptr, float* dwt_ext = nullptr) {
   E2_REQUIRE(ctx && dw, "conv3d_wgrad_bf16: null argument");
   if (xcl_ext) {
     E2_REQUIRE(x && x->n > 0 && x->c > 0 && x->d > 0 && x->h > 0 && x->w > 0, "conv3d_wgrad_bf16_xcl: bad x shape");
     E2_REQUIRE(kgs_ext >= (x->c + 7) / 8 && ((uintptr_t)xcl_ext & 15) == 0,
                "conv3d_wgrad_bf16_xcl: %d channel groups per plane for %d channels", kgs_ext, x->c);
   } else if (int rc = view_ok(x, "conv3d_wgrad_bf16 x")) return rc;
-  if (int rc = view_ok(dy, "conv3d_wgrad_bf16 dy")) return rc;
+  if (dyc_ext) {
+    E2_REQUIRE(dy && dy->n > 0 && dy->c > 0 && dy->d > 0 && dy->h > 0 && dy->w > 0 && ((uintptr_t)dyc_ext & 15) == 0,
+               "conv3d_wgrad_bf16: bad dy shape / unaligned planes");
+  } else if (int rc = view_ok(dy, "conv3d_wgrad_bf16 dy")) return rc;
   E2_REQUIRE(dy->n == x->n && dy->d == x->d - kd + 1 && dy->h == x->h - kh + 1 &&
                  dy->w == x->w - kw + 1,
              "conv3d_wgrad_bf16: dy spatial (%d,%d,%d) != x (%d,%d,%d) - k + 1", dy->d, dy->h,
              dy->w, x->d, x->h, x->w);
   const int Cin = x->c, Cout = dy->c, T = kd * kh * kw;
   const Geo g = geo(x->n, Cin, x->d, x->h, x->w, Cout, kd, kh, kw);
-  const size_t need = g.xbytes + g.dbytes + g.tbytes;
-  E2_REQUIRE(ws && ws_bytes >= need, "conv3d_wgrad_bf16: workspace of %zu bytes needed, %zu given",
+  const bool all_ext = xcl_ext && dyc_ext && dwt_ext;
+  const size_t need = all_ext ? 0 : g.xbytes + g.dbytes + g.tbytes;
+  E2_REQUIRE(all_ext || (ws && ws_bytes >= need), "conv3d_wgrad_bf16: workspace of %zu bytes needed, %zu given",
              need, ws_bytes);
-  E2_REQUIRE(((uintptr_t)ws & 15) == 0, "conv3d_wgrad_bf16: workspace must be 16-byte aligned");
+  E2_REQUIRE(all_ext || ((uintptr_t)ws & 15) == 0, "conv3d_wgrad_bf16: workspace must be 16-byte aligned");
+  E2_REQUIRE(((uintptr_t)dwt_ext & 15) == 0, "conv3d_wgrad_bf16: the sum buffer must be 16-byte aligned");
   int MB = 2, NB = 0, S = 0, rows = Cin <= 64 ? 1 : 0;
   {
     int v[5];
@@ -431,8 +442,9 @@ static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int
   E2_REQUIRE((MB == 1 || MB == 2) && NB >= 1 && NB <= 4, "conv3d_wgrad_bf16: MB 1..2, NB 1..4");
   __bf16* xcl = xcl_ext ? const_cast<__bf16*>(reinterpret_cast<const __bf16*>(xcl_ext))
                         : reinterpret_cast<__bf16*>(ws);
-  __bf16* dyc = reinterpret_cast<__bf16*>((char*)ws + g.xbytes);
-  float* dwt = reinterpret_cast<float*>((char*)ws + g.xbytes + g.dbytes);
+  __bf16* dyc = dyc_ext ? const_cast<__bf16*>(reinterpret_cast<const __bf16*>(dyc_ext))
+                        : reinterpret_cast<__bf16*>((char*)ws + g.xbytes);
+  float* dwt = dwt_ext ? dwt_ext : reinterpret_cast<float*>((char*)ws + g.xbytes + g.dbytes);
   WcP c;
   c.x = x->ptr; c.xsN = x->sn; c.xsC = x->sc; c.xsZ = x->sd; c.xsY = x->sh;
   c.dy = dy->ptr; c.dsN = dy->sn; c.dsC = dy->sc; c.dsZ = dy->sd; c.dsY = dy->sh;
@@ -442,12 +454,15 @@ static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int
   c.xcl = xcl; c.dyc = dyc; c.dwt = dwt; c.nT4 = (long)(g.tbytes / 16);
   c.cx = (int)((g.planePix + 255) / 256);
   c.cd = (g.planeD + 2047) / 2048;
-  const long nbx = xcl_ext ? 0 : (long)x->n * x->d * g.KG * c.cx, nbd = (long)x->n * Cout * dy->d * c.cd;
-  const long nbs = xcl_ext ? 0 : (g.xSlack + 255) / 256, nbt = (c.nT4 + 255) / 256;
+  const long nbx = xcl_ext ? 0 : (long)x->n * x->d * g.KG * c.cx;
+  const long nbd = dyc_ext ? 0 : (long)x->n * Cout * dy->d * c.cd;
+  const long nbs = xcl_ext ? 0 : (g.xSlack + 255) / 256, nbt = dwt_ext ? 0 : (c.nT4 + 255) / 256;
   E2_REQUIRE(g.planePix < (1L << 30) && nbx + nbd + nbs + nbt < (1L << 31), "conv3d_wgrad_bf16: volume too large");
   c.nbx = (int)nbx; c.nbd = (int)nbd; c.nbs = (int)nbs;
-  hipLaunchKernelGGL(wgrad_bf16_cvt_kernel, dim3((unsigned)(nbx + nbd + nbs + nbt)), dim3(256), 0, ctx->stream, c);
-  E2_CHECK_HIP(hipGetLastError());
+  if (nbx + nbd + nbs + nbt > 0) {
+    hipLaunchKernelGGL(wgrad_bf16_cvt_kernel, dim3((unsigned)(nbx + nbd + nbs + nbt)), dim3(256), 0, ctx->stream, c);
+    E2_CHECK_HIP(hipGetLastError());
+  }
   WbP p;
   p.xcl = xcl; p.dyc = dyc; p.dwt = dwt; p.CinP = g.CinP;
   p.N = x->n; p.Cin = Cin; p.Cout = Cout; p.Din = x->d; p.Do = dy->d; p.KG = g.KG;
@@ -486,7 +501,7 @@ static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int
 #undef E2_L
   if (rc) return rc;
   hipLaunchKernelGGL(wgrad_bf16_out_kernel, dim3((unsigned)(g.CinP / 32), (unsigned)Cout), dim3(256),
-                     (size_t)T * 33 * 4, ctx->stream, dwt, dw, Cin, g.CinP, T, accumulate);
+                     (size_t)T * 33 * 4, ctx->stream, dwt, dw, Cin, g.CinP, T, accumulate, dwt_ext ? 1 : 0);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -502,4 +517,22 @@ extern "C" int e2_conv3d_wgrad_bf16_xcl(e2_ctx* ctx, const e2_tensor5* x_shape, 
                                         int kh, int kw, int accumulate, void* ws, size_t ws_bytes) {
   E2_REQUIRE(xcl, "conv3d_wgrad_bf16_xcl: null copy");
   return wgrad_bf16(ctx, x_shape, xcl, kg_per_plane, dy, dw, kd, kh, kw, accumulate, ws, ws_bytes);
+}
+
+/* geometry of the ready-made operands of e2_conv3d_wgrad_bf16_ex */
+extern "C" int e2_conv3d_wgrad_bf16_geometry(int n, int cin, int d, int h, int w, int cout, int kd,
+                                             int kh, int kw, int64_t* plane_d, size_t* dyc_bytes,
+                                             size_t* sums_bytes) {
+  const Geo g = geo(n, cin, d, h, w, cout, kd, kh, kw);
+  if (plane_d) *plane_d = g.planeD;
+  if (dyc_bytes) *dyc_bytes = g.dbytes;
+  if (sums_bytes) *sums_bytes = (g.tbytes + 255) / 256 * 256;
+  return 0;
+}
+
+extern "C" int e2_conv3d_wgrad_bf16_ex(e2_ctx* ctx, const e2_tensor5* x_shape, const void* xcl,
+                                       int kg_per_plane, const e2_tensor5* dy, const void* dyc,
+                                       float* sums, float* dw, int kd, int kh, int kw,
+                                       int accumulate, void* ws, size_t ws_bytes) {
+  return wgrad_bf16(ctx, x_shape, xcl, kg_per_plane, dy, dw, kd, kh, kw, accumulate, ws, ws_bytes, dyc, sums);
 }

@@ -522,6 +522,79 @@ int e2_conv3d_wgrad_bf16_xcl(e2_ctx*, const e2_tensor5* x_shape, const void* xcl
                              int kg_per_plane, const e2_tensor5* dy, float* dw, int kd, int kh,
                              int kw, int accumulate, void* ws, size_t ws_bytes);
 
+/* ---- the producers' epilogues ---------------------------------------------
+ * No conversion pass at all: the bf16 operand images of a GEMM are written by the kernel that
+ * produces the tensor, the filter rows of every layer by ONE launch at the start of the step,
+ * and the GEMM entry points take them ready-made.  Reference seam unchanged: the tensors are
+ * those of neural.py:662-712 (conv -> pool -> bias -> activation) and of T.grad of that chain
+ * (model.py:182); only WHERE their bf16 copies are made moves.
+ *
+ * e2_bf16_dst: where a producer puts the bf16 copies of the tensor it writes.
+ *   cl  channels-last image [n][cl_d][cl_kg][cl_h][cl_w][8] (16-byte pixel pieces of 8 channels,
+ *       cl_kg * 8 >= channels; the layout conv_bf16 / wgrad_bf16 read); element (z, y, x) of the
+ *       tensor lands at (z + cl_oz, y + cl_oy, x + cl_ox) -- the interior of a zero-padded
+ *       gradient image.  Everything the producer does not write (border, padding channel
+ *       groups, slack) must be zero from a one-time fill.
+ *   pl  channel-major planes [n][c][d][pl_plane] with row pitch pl_pitch (the dy operand of
+ *       e2_conv3d_wgrad_bf16_ex: pl_pitch = the layer INPUT's row length, pl_plane from
+ *       e2_conv3d_wgrad_bf16_geometry); gaps stay zero from a one-time fill.
+ * Either may be NULL. */
+typedef struct e2_bf16_dst {
+  void* cl;
+  int cl_kg, cl_d, cl_h, cl_w;
+  int cl_oz, cl_oy, cl_ox;
+  void* pl;
+  int64_t pl_plane;
+  int pl_pitch;
+} e2_bf16_dst;
+/* e2_pool_bias_act_bwd (bias != NULL: src = the conv output y, slope from max + bias) and
+ * e2_bias_act_bwd_out (bias == NULL, window (1,1,1): src = the activated output, slope from its
+ * signed zeros) with dout as `parts` partial sums part_stride apart; writes dy (f32; dy == NULL
+ * or dy->ptr == NULL: not written), dbias += row sums (NULL: skipped) and the bf16 copies named
+ * by dst.  relu / lin; windows (1,1,1), (1,2,2), (2,1,1), (2,2,2). */
+int e2_pool_bias_act_bwd_bf16(e2_ctx*, const e2_tensor5* dout, int64_t part_stride, int parts,
+                              const e2_tensor5* src, const float* bias, int pz, int py, int px,
+                              int act, const e2_tensor5* dy, float* dbias, const e2_bf16_dst* dst);
+/* e2_pool_bias_act_fwd_parts writing out (f32; out->ptr == NULL: not written) and the
+ * channels-last bf16 copy of out (dst->cl: the NEXT conv layer's kept input copy). */
+int e2_pool_bias_act_fwd_bf16(e2_ctx*, const e2_tensor5* y, int64_t part_stride, int parts,
+                              const float* bias, int pz, int py, int px, int act,
+                              const e2_tensor5* out, const e2_bf16_dst* dst);
+/* The filter rows of a launch, packed ahead of it for the tile "32,mb,nb" (mode 0: forward
+ * image of w (nf, nin, kd, kh, kw), rows = nf; mode 1: data-gradient image, rows = nin); in_w /
+ * out_w: the row lengths of the GEMM's input and output (forward: x and y; data gradient: the
+ * padded dy and dx).  Jobs are plain records (e2_bf16_wjob_bytes each) filled on the host,
+ * copied to the device by the caller and run by ONE launch. */
+size_t e2_conv3d_bf16_wb_bytes(int rows, int kk, int kd, int kh, int kw, int in_w, int out_w,
+                               int mb, int nb);
+size_t e2_bf16_wjob_bytes(void);
+int e2_bf16_wjob_fill(void* rec, const float* w, int nf, int nin, int kd, int kh, int kw, int mode,
+                      int in_w, int out_w, int mb, int nb, void* wb, size_t wb_bytes);
+int e2_conv3d_bf16_pack_w_multi(e2_ctx*, const void* jobs_dev, int njobs);
+/* e2_conv3d_fwd_bf16_keep / e2_conv3d_dgrad_bf16 with ready-made operands: x_ready != 0: xkeep
+ * already holds this step's copy of x (x->ptr may be NULL); wb != NULL: the packed filter rows
+ * (w may be NULL; the forced tile must be the one they were packed for); next_xb != NULL
+ * (forward): the channels-last bf16 copy of out, [n][d][next_kg][h * w][8] with next_kg =
+ * ceil(cout / 16) * 2, is written by the epilogue (padding channels as zeros).  dy_cl: the
+ * channels-last image of the padded gradient (dy_pad gives the shape).  With every operand
+ * ready ws may be NULL. */
+int e2_conv3d_fwd_bf16_ex(e2_ctx*, const e2_tensor5* x, const float* w, int cout, int kd, int kh,
+                          int kw, const float* bias, int act, const e2_tensor5* out, void* ws,
+                          size_t ws_bytes, void* xkeep, size_t xkeep_bytes, int x_ready,
+                          const void* wb, void* next_xb, int next_kg);
+int e2_conv3d_dgrad_bf16_ex(e2_ctx*, const e2_tensor5* dy_pad, const float* w, int cin, int kd,
+                            int kh, int kw, const e2_tensor5* dx, void* ws, size_t ws_bytes,
+                            const void* dy_cl, const void* wb);
+/* e2_conv3d_wgrad_bf16_xcl with dy as ready-made planes (dyc: e2_bf16_dst.pl of the kernel that
+ * produced dy; dy gives the shape) and the f32 sums in a buffer of the caller's (sums:
+ * sums_bytes of e2_conv3d_wgrad_bf16_geometry, zero-filled ONCE -- the call leaves it zero);
+ * xcl, dyc, sums may each be NULL (then made / held in ws as before). */
+int e2_conv3d_wgrad_bf16_geometry(int n, int cin, int d, int h, int w, int cout, int kd, int kh,
+                                  int kw, int64_t* plane_d, size_t* dyc_bytes, size_t* sums_bytes);
+int e2_conv3d_wgrad_bf16_ex(e2_ctx*, const e2_tensor5* x_shape, const void* xcl, int kg_per_plane,
+                            const e2_tensor5* dy, const void* dyc, float* sums, float* dw, int kd,
+                            int kh, int kw, int accumulate, void* ws, size_t ws_bytes);
+
 /* ---- BASELINE config 1 (examples/mnist.py:29-56): Perceptron and batch normalisation ----
  * Correctness-first kernels for the reference's CPU-runnable plumbing case.
  *

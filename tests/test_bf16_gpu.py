@@ -266,3 +266,206 @@ def test_wgrad_with_bf16_operands_in_memory(ctx, case, tile):
         assert relerr(dw, ref) < TOL
     finally:
         ctx.set_tiling("wgrad", None)
+
+
+# ---- the producers' epilogues (csrc/bf16_prod.hip, e2_*_bf16_ex): SURVEY.md 8f-3 --------------
+def _cl_image(t, dims=None, off=(0, 0, 0)):
+    """the channels-last bf16 image [n][d][kg][h][w][8] of an f32 tensor (n, c, d, h, w), torch's
+    round-to-nearest-even; kg = ceil(c / 16) * 2"""
+    n, c, d, h, w = t.shape
+    kg = (c + 15) // 16 * 2
+    D, H, W = dims or (d, h, w)
+    tp = torch.zeros((n, kg * 8, d, h, w), device=t.device)
+    tp[:, :c] = t
+    img = torch.zeros((n, D, kg, H, W, 8), dtype=torch.bfloat16, device=t.device)
+    img[:, off[0]:off[0] + d, :, off[1]:off[1] + h, off[2]:off[2] + w, :] = \
+        tp.view(n, kg, 8, d, h, w).permute(0, 3, 1, 4, 5, 2).to(torch.bfloat16)
+    return img
+
+
+def _same_bits(buf, img):
+    got = buf.view(torch.int16)[:img.numel()].view(img.shape)
+    return bool((got == img.view(torch.int16)).all())
+
+
+@pytest.mark.parametrize("pool,mode", [((1, 1, 1), 'out'), ((1, 1, 1), 'y'), ((1, 2, 2), 'y'),
+                                       ((2, 1, 1), 'y'), ((2, 2, 2), 'y')])
+@pytest.mark.parametrize("C,sp,parts", [(20, (3, 9, 13), 1), (150, (2, 8, 41), 3), (7, (4, 5, 6), 1)])
+def test_backward_producer_writes_the_bf16_gradient_images(ctx, pool, mode, C, sp, parts):
+    """e2_pool_bias_act_bwd_bf16 = e2_pool_bias_act_bwd / e2_bias_act_bwd_out (same f32 dy, bit for
+    bit; same dbias) + the channels-last image of the ZERO-PADDED gradient (what the data
+    gradient's conversion pass made of it) + the channel-major planes at the input's row pitch
+    (what the weight gradient's made): both bit-identical to torch's bf16 rounding of dy."""
+    from elektronn2_amd import backend
+    rng = np.random.RandomState(C + sp[2])
+    N = 2
+    k = (1, 3, 4)                                        # the layer's kernel: pad and pitch
+    pad = [kk - 1 for kk in k]
+    osp = tuple(sp[i] // pool[i] for i in range(3))
+    src = dev(rng.randn(N, C, *sp) * (rng.rand(N, C, *sp) > 0.2))      # exact zeros too
+    bias = dev(rng.randn(C) * 0.1)
+    douts = dev(rng.randn(parts, N, C, *osp))
+    dout = douts.sum(0) if parts > 1 else douts[0]
+    act = 'relu'
+    pshape = (N, C) + tuple(sp[i] + 2 * pad[i] for i in range(3))
+    # reference: the f32 kernels into the interior of a padded buffer
+    ref_pad = torch.zeros(pshape, device="cuda")
+    ref_dy = ref_pad[:, :, pad[0]:pad[0] + sp[0], pad[1]:pad[1] + sp[1], pad[2]:pad[2] + sp[2]]
+    ref_db = torch.zeros(C, device="cuda")
+    if mode == 'out':
+        out = torch.where(src > 0, src, torch.where(src == 0, torch.zeros_like(src), -torch.zeros_like(src)))
+        ctx.bias_act_bwd_out(dout, out, act, ref_dy, ref_db)
+        srcT, b = out, None
+    else:
+        ctx.pool_bias_act_bwd(dout, src, bias, pool, act, ref_dy, ref_db)
+        srcT, b = src, bias
+    # the producer form
+    kg = (C + 15) // 16 * 2
+    win = sp[2] + pad[2]                                   # the layer input's row length
+    plane = ((sp[1] * win + 63) // 64) * 64
+    cl = torch.zeros(N * pshape[2] * kg * pshape[3] * pshape[4] * 16 + 256, dtype=torch.uint8, device="cuda")
+    pl = torch.zeros(N * C * sp[0] * plane * 2 + 2048, dtype=torch.uint8, device="cuda")
+    dst = backend.bf16_dst(cl=cl, cl_dims=(kg, pshape[2], pshape[3], pshape[4]), cl_off=pad,
+                           pl=pl, pl_plane=plane, pl_pitch=win)
+    got_pad = torch.zeros(pshape, device="cuda")
+    got_dy = got_pad[:, :, pad[0]:pad[0] + sp[0], pad[1]:pad[1] + sp[1], pad[2]:pad[2] + sp[2]]
+    db = torch.zeros(C, device="cuda")
+    ctx.pool_bias_act_bwd_bf16(douts[0], srcT, b, pool, act, got_dy, db, dst, parts=parts,
+                               part_stride=douts[0].numel())
+    assert torch.equal(got_pad.view(torch.int32), ref_pad.view(torch.int32))
+    assert relerr(db, ref_db.cpu().numpy()) < 1e-5
+    assert _same_bits(cl, _cl_image(ref_pad))
+    planes = torch.zeros((N, C, sp[0], plane), device="cuda")
+    rows = torch.zeros((N, C, sp[0], sp[1], win), device="cuda")
+    rows[..., :sp[2]] = ref_dy
+    planes[..., :sp[1] * win] = rows.reshape(N, C, sp[0], sp[1] * win)
+    assert _same_bits(pl, planes.to(torch.bfloat16))
+    # bf16 copies only (no f32 gradient): same images
+    cl2, pl2 = torch.zeros_like(cl), torch.zeros_like(pl)
+    dst2 = backend.bf16_dst(cl=cl2, cl_dims=(kg, pshape[2], pshape[3], pshape[4]), cl_off=pad,
+                            pl=pl2, pl_plane=plane, pl_pitch=win)
+    ctx.pool_bias_act_bwd_bf16(douts[0], srcT, b, pool, act, None, None, dst2, parts=parts,
+                               part_stride=douts[0].numel())
+    assert torch.equal(cl2, cl) and torch.equal(pl2, pl)
+
+
+@pytest.mark.parametrize("pool", [(1, 1, 1), (1, 2, 2), (2, 1, 1), (2, 2, 2)])
+@pytest.mark.parametrize("C,sp,parts", [(40, (4, 9, 13), 1), (150, (2, 8, 41), 2), (7, (4, 5, 6), 1)])
+def test_forward_producer_writes_the_next_layers_input_image(ctx, pool, C, sp, parts):
+    """e2_pool_bias_act_fwd_bf16 = e2_pool_bias_act_fwd (same f32 output incl. the signed zeros of
+    relu) + the channels-last bf16 copy the next conv's kernels read"""
+    from elektronn2_amd import backend
+    rng = np.random.RandomState(C)
+    N = 2
+    osp = tuple(sp[i] // pool[i] for i in range(3))
+    ys = dev(rng.randn(parts, N, C, *sp) * (rng.rand(parts, N, C, *sp) > 0.1))
+    y = ys.sum(0) if parts > 1 else ys[0]
+    bias = dev(rng.randn(C) * 0.1)
+    ref = torch.full((N, C) + osp, float("nan"), device="cuda")
+    ctx.pool_bias_act_fwd(y, bias, pool, 'relu', ref)
+    kg = (C + 15) // 16 * 2
+    cl = torch.zeros(N * osp[0] * kg * osp[1] * osp[2] * 16 + 512, dtype=torch.uint8, device="cuda")
+    dst = backend.bf16_dst(cl=cl, cl_dims=(kg,) + osp)
+    out = torch.full((N, C) + osp, float("nan"), device="cuda")
+    ctx.pool_bias_act_fwd_bf16(ys[0], bias, pool, 'relu', out, dst, parts=parts, part_stride=ys[0].numel())
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert _same_bits(cl, _cl_image(ref))
+
+
+@pytest.mark.parametrize("tile", ["32,1,2", "32,2,1", "32,2,2", "32,4,1"])
+@pytest.mark.parametrize("case", [(20, 40, (3, 3, 3), (2, 5, 14, 19)), (150, 200, (1, 3, 3), (1, 2, 11, 12)),
+                                  (40, 150, (2, 4, 4), (1, 3, 12, 13)), (33, 17, (1, 5, 2), (1, 1, 9, 70))])
+def test_conv_bf16_with_ready_made_operands(ctx, case, tile):
+    """e2_conv3d_fwd_bf16_ex / e2_conv3d_dgrad_bf16_ex: filter rows packed ahead by the multi-job
+    launch, the input image ready in the kept buffer / written by the gradient's producer, the next
+    layer's image written by the forward's epilogue -- every result bit-identical to the call that
+    converts by itself."""
+    from elektronn2_amd import backend
+    Ci, Co, k, (N, D, H, W) = case
+    rng = np.random.RandomState(Ci + Co)
+    x = dev(rng.rand(N, Ci, D, H, W))
+    w = dev(rng.randn(Co, Ci, *k) / np.sqrt(Ci * np.prod(k)))
+    b = dev(rng.randn(Co) * 0.1)
+    osp = (D - k[0] + 1, H - k[1] + 1, W - k[2] + 1)
+    mbnb = backend.Context.bf16_tile(tile)
+    ctx.set_tiling("igemm", tile)
+    try:
+        ref = torch.full((N, Co) + osp, float("nan"), device="cuda")
+        keep = torch.zeros(ctx.conv_bf16_xkeep_bytes(x.shape, k), dtype=torch.uint8, device="cuda")
+        ctx.conv3d_fwd_bf16(x, w, ref, bias=b, act='relu', xkeep=keep)
+        # filter rows of both directions in ONE launch
+        pshape = (N, Co) + tuple(osp[i] + 2 * (k[i] - 1) for i in range(3))
+        wbf = torch.empty(ctx.conv_bf16_wb_bytes(Co, Ci, k, W, osp[2], mbnb), dtype=torch.uint8, device="cuda")
+        wbd = torch.empty(ctx.conv_bf16_wb_bytes(Ci, Co, k, pshape[4], W, mbnb), dtype=torch.uint8, device="cuda")
+        jobs = ctx.make_bf16_wjobs([(w, 0, W, osp[2], mbnb, wbf), (w, 1, pshape[4], W, mbnb, wbd)])
+        ctx.conv3d_bf16_pack_w_multi(*jobs)
+        # forward: x ready in the kept buffer, rows ready, next layer's image out
+        kgn = (Co + 15) // 16 * 2
+        nxt = torch.zeros(N * osp[0] * kgn * osp[1] * osp[2] * 16 + 512, dtype=torch.uint8, device="cuda")
+        y = torch.full((N, Co) + osp, float("nan"), device="cuda")
+        ctx.conv3d_fwd_bf16_ex(x, w, y, bias=b, act='relu', xkeep=keep, x_ready=True, wb=wbf,
+                               next_xb=nxt, next_kg=kgn)
+        assert torch.equal(y.view(torch.int32), ref.view(torch.int32))
+        assert _same_bits(nxt, _cl_image(ref))
+        # only the rows ready (x converted by the call, into the workspace)
+        y.fill_(float("nan"))
+        ctx.conv3d_fwd_bf16_ex(x, w, y, bias=b, act='relu', wb=wbf)
+        assert torch.equal(y.view(torch.int32), ref.view(torch.int32))
+        # data gradient: the padded gradient's image written by its producer
+        dy = dev(rng.randn(N, Co, *osp))
+        dyp = torch.zeros(pshape, device="cuda")
+        dyp[:, :, k[0] - 1:k[0] - 1 + osp[0], k[1] - 1:k[1] - 1 + osp[1], k[2] - 1:k[2] - 1 + osp[2]] = dy
+        dref = torch.full(x.shape, float("nan"), device="cuda")
+        try:
+            ctx.conv3d_dgrad_bf16(dyp, w, dref)
+        except Exception as err:
+            assert "does not fit LDS" in str(err)
+            return
+        img = _cl_image(dyp)
+        dx = torch.full(x.shape, float("nan"), device="cuda")
+        ctx.conv3d_dgrad_bf16_ex(dyp, w, dx, dy_cl=img.view(torch.uint8).reshape(-1), wb=wbd)
+        assert torch.equal(dx.view(torch.int32), dref.view(torch.int32))
+    finally:
+        ctx.set_tiling("igemm", None)
+
+
+@pytest.mark.parametrize("tile", [None, "32,1,2,0,3", "32,2,2,0,7", "32,2,3,1,4"])
+@pytest.mark.parametrize("case", [(20, 40, (3, 3, 3), (2, 5, 14, 19)), (150, 200, (1, 3, 3), (1, 2, 11, 12)),
+                                  (40, 150, (2, 4, 4), (1, 3, 12, 13))])
+def test_wgrad_bf16_with_ready_made_operands(ctx, case, tile):
+    """e2_conv3d_wgrad_bf16_ex: x from the forward's kept copy, dy as the planes its producer
+    wrote, the f32 sums in a caller-owned buffer that the call leaves zero: no conversion pass;
+    twice in a row (the sums really are zero again), overwrite and accumulate."""
+    from elektronn2_amd import backend
+    Ci, Co, k, (N, D, H, W) = case
+    rng = np.random.RandomState(Ci + Co)
+    x = rng.rand(N, Ci, D, H, W).astype(np.float32)
+    osp = (D - k[0] + 1, H - k[1] + 1, W - k[2] + 1)
+    dy = rng.randn(N, Co, *osp).astype(np.float32)
+    ref = O.conv3d_wgrad(bf16_round(dy), bf16_round(x), (Co, Ci) + k)
+    xd, dyd = dev(x), dev(dy)
+    keep = torch.zeros(ctx.conv_bf16_xkeep_bytes(x.shape, k), dtype=torch.uint8, device="cuda")
+    keep[:_cl_image(xd).numel() * 2] = _cl_image(xd).view(torch.uint8).reshape(-1)
+    plane, dbytes, sbytes = ctx.wgrad_bf16_geometry(x.shape, Co, k)
+    planes = torch.zeros((N, Co, osp[0], plane), device="cuda")
+    rows = torch.zeros((N, Co, osp[0], osp[1], W), device="cuda")
+    rows[..., :osp[2]] = dyd
+    planes[..., :osp[1] * W] = rows.reshape(N, Co, osp[0], osp[1] * W)
+    dyc = torch.zeros(dbytes, dtype=torch.uint8, device="cuda")
+    dyc[:planes.numel() * 2] = planes.to(torch.bfloat16).view(torch.uint8).reshape(-1)
+    sums = torch.zeros(sbytes // 4, device="cuda")
+    ctx.set_tiling("wgrad", tile)
+    try:
+        dw = torch.full((Co, Ci) + k, float("nan"), device="cuda")
+        shape_only = torch.empty((N, Co) + osp, device="cuda")      # (extents; the values are not read)
+        ctx.conv3d_wgrad_bf16_ex(xd, shape_only, dw, xcl=keep, dyc=dyc, sums=sums)
+        assert relerr(dw, ref) < TOL
+        assert float(sums.abs().max()) == 0.0
+        ctx.conv3d_wgrad_bf16_ex(xd, shape_only, dw, accumulate=True, xcl=keep, dyc=dyc, sums=sums)
+        assert relerr(dw, 2 * ref) < TOL
+        # dy ready, x converted by the call
+        dw.fill_(float("nan"))
+        ctx.conv3d_wgrad_bf16_ex(xd, shape_only, dw, dyc=dyc, sums=sums)
+        assert relerr(dw, ref) < TOL
+    finally:
+        ctx.set_tiling("wgrad", None)
