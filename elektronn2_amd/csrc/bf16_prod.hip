@@ -31,6 +31,7 @@ struct BwP {
   float* dy;         long dsN, dsC, dsZ, dsY;             // f32 gradient (optional)
   float* dbias;
   int N, C, Do, Ho, Wo;                                    // pooled dims (= dims of dout)
+  int D;                                                   // planes of src / dy
   int act, out_mode;
   int VW;                                                  // thread columns per pooled row
   BfDst d;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void bwd_bf16_kernel(BwP p) {
     gs[j] = s;
     // the window's gradient values; f32 + plane stores here, pixel pieces collected
     float* dp = p.dy ? p.dy + (long)n * p.dsN + (long)c * p.dsC + (long)(zo * PZ) * p.dsZ + (long)(yo * PY) * p.dsY + xo * PX : nullptr;
-    __bf16* pp = p.d.pl ? p.d.pl + (((long)n * p.C + c) * (p.Do * PZ) + zo * PZ) * p.d.plPlane +
+    __bf16* pp = p.d.pl ? p.d.pl + (((long)n * p.C + c) * p.D + zo * PZ) * p.d.plPlane +
                               (long)(yo * PY) * p.d.plPitch + xo * PX : nullptr;
 #pragma unroll
     for (int a = 0; a < PZ; ++a)
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
         float v = m[o] + bv;
-        if (p.act == E2_ACT_RELU) v = (v > 0.f) ? v : ((v == 0.f) ? 0.f : -0.f);
+        if (p.act == E2_ACT_RELU) v = fmaxf(v, 0.f);        // (as pool_fwd_fixed_kernel: the backward reads y, not out)
         m[o] = (o < nvo) ? v : 0.f;
         if (op && o < nvo) op[o] = v;
       }
@@ -268,7 +269,7 @@ extern "C" int e2_pool_bias_act_bwd_bf16(e2_ctx* ctx, const e2_tensor5* dout, in
   p.N = dout->n; p.C = dout->c; p.Do = dout->d; p.Ho = dout->h; p.Wo = dout->w;
   p.act = act; p.out_mode = out_mode ? 1 : 0;
   if (int rc = check_dst(dst, &p.d, src->n, src->c, src->d, src->h, src->w, "pool_bias_act_bwd_bf16")) return rc;
-  E2_REQUIRE(!p.d.pl || src->d == dout->d * pz, "pool_bias_act_bwd_bf16: planes need d divisible by the window");
+  p.D = src->d;
   const int NO = 2 / px;
   E2_REQUIRE(px == 1 || px == 2, "pool_bias_act_bwd_bf16: x windows of 1 or 2");
   p.VW = (p.Wo + NO - 1) / NO;
