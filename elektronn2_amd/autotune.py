@@ -303,6 +303,16 @@ def force(kind, cfg):
         _forced.pop(kind, None)
 
 
+def known(ctx, kind, sig):
+    """the tiling tuned_call would run (kind, sig) with WITHOUT tuning: the pinned one, the
+    table's entry, or None when the problem has not been tuned yet"""
+    if kind in _forced:
+        return _forced[kind]
+    suffix = "_bf16" if getattr(ctx, "mfma_dtype", "f32") == "bf16" else ""
+    key = "%s%s|%s" % (kind, suffix, ",".join(str(int(v)) for v in sig))
+    return _load().get(key)
+
+
 def _time(ctx, fn, iters=4):
     fn()
     e0, e1 = ctx.event(), ctx.event()

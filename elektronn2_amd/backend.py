@@ -679,6 +679,10 @@ class Context:
     def bf16_memory_wgrad(self):
         return getattr(self, '_tiling', {}).get('wgrad', '').startswith('32,')
 
+    def current_tiling(self, kind):
+        """the tiling string in force for kind ('igemm' | 'wgrad'), '' when none is pinned"""
+        return getattr(self, '_tiling', {}).get(kind, '')
+
     # ---- the producers' epilogues: operands made ahead of the GEMM launches ------------------
     @staticmethod
     def bf16_tile(tiling):

@@ -26,6 +26,7 @@ import numpy as np
 
 from .graphutils import floatX, TaggedShape
 from .. import autotune
+from . import bf16_ahead
 from .node_basic import Node, Concat, Add, Sym
 from .variables import VariableWeight, ConstantParam, VariableParam
 
@@ -522,6 +523,49 @@ class Conv(NeuralLayer):
                 plan.scratch[self, 'wp_d'] = plan.zeros_flat(nb // 4 + 64)
                 plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_d'], 1))
 
+    # ---- the tuning keys of the node's three GEMM launches --------------------------------
+    def _sig_fwd(self, plan):
+        x = plan.out[self.parent]
+        cin = self.parent.shape['f']
+        if self._fused_act(plan):
+            return (2, self.n_f, cin) + tuple(self._k3) + tuple(plan.out[self].shape[2:]) + (x.stride(3),)
+        return (0, self.n_f, cin) + tuple(self._k3) + tuple(plan.scratch[self, 'y'].shape[2:]) + (x.stride(3),)
+
+    def _sig_dgrad(self, plan):
+        dst = plan.grad[self.parent]
+        return (1, self.parent.shape['f'], self.n_f) + tuple(self._k3) + tuple(dst.shape[2:]) + \
+            (plan.scratch[self, 'dy_pad'].stride(3),)
+
+    def _sig_wgrad(self, plan):
+        x, dy = plan.out[self.parent], plan.scratch[self, 'dy']
+        return (self.n_f, self.parent.shape['f']) + tuple(self._k3) + tuple(dy.shape[2:]) + \
+            (x.stride(3), dy.stride(3))
+
+    def _need_f32_dy(self, plan):
+        """a launch is about to read the f32 gradient of the pre-activation: it must exist"""
+        b = plan.bf16a.get((self, 'dy'))
+        if b is not None and not b['want_f32'] and plan._dy_ready.get(self):
+            raise RuntimeError("bf16 mode: the tiling of a gradient launch of %s changed after its "
+                               "operands were planned as bf16 images only (re-build the plan)" % self.name)
+
+    def _bf16_fwd(self, plan, x, out, bias=None, act='lin'):
+        """the forward launch as the kernel with bf16 operands in memory: with the operands made
+        ahead (bf16_ahead.py) when this launch's tile is the one they were made for"""
+        ctx = plan.ctx
+        a = plan.bf16a.get((self, 'fwd'))
+        w5 = self._w5(plan.param(self.w))
+        if a is None or a['tile'] != ctx.current_tiling('igemm'):
+            ctx.conv3d_fwd_bf16(x, w5, out, bias=bias, act=act, ws=plan.bf16_ws(self),
+                                xkeep=plan.bf16_xkeep(self))
+            return
+        nx = bf16_ahead.next_image(plan, self) if bias is not None else None
+        ctx.conv3d_fwd_bf16_ex(x, w5, out, bias=bias, act=act, ws=plan.bf16_ws(self),
+                               xkeep=plan.bf16_xkeep(self), x_ready=plan._xb_ready.get(self, False),
+                               wb=a['wb'] if plan._wb_ready else None,
+                               next_xb=nx[0] if nx else None, next_kg=nx[1] if nx else 0)
+        if nx:
+            plan._xb_ready[nx[2]] = True
+
     def _plan_fwd(self, plan):
         ctx = plan.ctx
         if self._fused_head(plan) is not None:
@@ -542,9 +586,7 @@ class Conv(NeuralLayer):
                 (x.stride(3),)
             def fwd_act():
                 if ctx.bf16_memory_form():
-                    ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), out,
-                                        bias=plan.param(self.b), act=self.activation_func,
-                                        ws=plan.bf16_ws(self), xkeep=plan.bf16_xkeep(self))
+                    self._bf16_fwd(plan, x, out, bias=plan.param(self.b), act=self.activation_func)
                     plan.bf16_xkeep_valid(self, True)
                 else:
                     plan.bf16_xkeep_valid(self, False)
@@ -564,8 +606,7 @@ class Conv(NeuralLayer):
         def fwd_plain():
             plan.bf16_xkeep_valid(self, ctx.bf16_memory_form())
             if ctx.bf16_memory_form():
-                ctx.conv3d_fwd_bf16(x, self._w5(plan.param(self.w)), y, ws=plan.bf16_ws(self),
-                                    xkeep=plan.bf16_xkeep(self))
+                self._bf16_fwd(plan, x, y)
                 got[0] = 1
             elif yp.shape[0] > 1:
                 got[0] = ctx.conv3d_fwd_packed_parts(x, wp, self.n_f, self._k3, yp)
@@ -602,7 +643,13 @@ class Conv(NeuralLayer):
                 ctx.pool_bias_act_fwd(src, plan.param(self.b), self._p3,
                                       self.activation_func, out[i * n_in:(i + 1) * n_in])
             return
-        if y_nparts > 1:                        # split-K partial sums: added up on the way
+        ndst = bf16_ahead.next_dst(plan, self)
+        if ndst is not None:
+            # bf16 mode: this pass also writes the next conv's channels-last input image
+            ctx.pool_bias_act_fwd_bf16(yp[0], plan.param(self.b), self._p3, self.activation_func,
+                                       plan.out[self], ndst, parts=y_nparts, part_stride=yp.stride(0))
+            plan._xb_ready[plan.bf16a[self, 'next']['consumer']] = True
+        elif y_nparts > 1:                      # split-K partial sums: added up on the way
             ctx.pool_bias_act_fwd_parts(yp, y_nparts, plan.param(self.b), self._p3,
                                         self.activation_func, plan.out[self])
         else:
@@ -643,6 +690,20 @@ class Conv(NeuralLayer):
         elif plan.scratch.get((self, 'dy_done')) or plan.scratch.get((self, 'dy_by_tail')):
             pass        # the consumer's data-gradient launch (below) or the tail launch
                         # (Conv._tail_gm) wrote dy and dbias
+        elif (self, 'dy') in plan.bf16a:
+            # bf16 mode: the pass that produces dy writes the operand images of this layer's two
+            # gradient GEMMs (and the f32 tensor only if a launch still reads it)
+            b = plan.bf16a[self, 'dy']
+            gn = plan.scratch.get((self, 'grad_nparts'), 1)
+            gp = plan.scratch.get((self, 'grad_parts'))
+            dout = gp[0] if (gn > 1 and gp is not None) else plan.grad[self]
+            fused = self._fused_act(plan)
+            ctx.pool_bias_act_bwd_bf16(dout, plan.out[self] if fused else plan.scratch[self, 'y'],
+                                       None if fused else plan.param(self.b), self._p3,
+                                       self.activation_func, dy if b['want_f32'] else None,
+                                       plan.pgrad(self.b), b['dst'], parts=gn,
+                                       part_stride=gp.stride(0) if (gn > 1 and gp is not None) else 0)
+            plan._dy_ready[self] = True
         elif self._fused_act(plan):
             gn = plan.scratch.get((self, 'grad_nparts'), 1)
             if gn > 1:
@@ -674,9 +735,17 @@ class Conv(NeuralLayer):
             if ctx.bf16_memory_wgrad():     # "32,MB,NB,0,S": bf16 operands in memory
                 # (the forward's channels-last bf16 copy of x, when this step's forward of
                 # the layer was the memory form: one conversion pass less)
-                ctx.conv3d_wgrad_bf16(x, dy, dw, accumulate=accumulate, ws=wws,
-                                      xcl=plan.bf16_xkeep(self, only_valid=True))
+                aw = plan.bf16a.get((self, 'wgrad'))
+                if aw is not None and plan._dy_ready.get(self) and aw['tile'] == ctx.current_tiling('wgrad'):
+                    ctx.conv3d_wgrad_bf16_ex(x, dy, dw, accumulate=accumulate, ws=wws,
+                                             xcl=plan.bf16_xkeep(self, only_valid=True),
+                                             dyc=aw['dyc'], sums=aw['sums'])
+                else:
+                    self._need_f32_dy(plan)
+                    ctx.conv3d_wgrad_bf16(x, dy, dw, accumulate=accumulate, ws=wws,
+                                          xcl=plan.bf16_xkeep(self, only_valid=True))
             else:
+                self._need_f32_dy(plan)
                 ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=accumulate)
         # the weight gradient is independent of the data-gradient chain below: side stream
         plan.on_side(lambda: plan.tuned(
@@ -722,12 +791,21 @@ class Conv(NeuralLayer):
                 (dyp.stride(3),)
             def dgrad():
                 if ctx.bf16_memory_form():
-                    ctx.conv3d_dgrad_bf16(dyp, self._w5(plan.param(self.w)), out,
-                                          ws=plan.bf16_ws(self))
+                    ad = plan.bf16a.get((self, 'dgrad'))
+                    if ad is not None and plan._dy_ready.get(self) and ad['tile'] == ctx.current_tiling('igemm'):
+                        ctx.conv3d_dgrad_bf16_ex(dyp, self._w5(plan.param(self.w)), out,
+                                                 ws=plan.bf16_ws(self), dy_cl=ad['cl'],
+                                                 wb=ad['wb'] if plan._wb_ready else None)
+                    else:
+                        self._need_f32_dy(plan)
+                        ctx.conv3d_dgrad_bf16(dyp, self._w5(plan.param(self.w)), out,
+                                              ws=plan.bf16_ws(self))
                     got[0] = 1
                 elif gparts is not None:
+                    self._need_f32_dy(plan)
                     got[0] = ctx.conv3d_dgrad_packed_parts(dyp, wp, cin, self._k3, gparts)
                 else:
+                    self._need_f32_dy(plan)
                     ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out)
             plan.tuned('igemm', sig,
                        autotune.igemm_candidates(cin, self.n_f, self._k3, out.shape[2:]) +

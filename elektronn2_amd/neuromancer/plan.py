@@ -370,6 +370,10 @@ class Plan(object):
         # bias-gradient atomics of split-K grids cost more (neuro3d@185 +0.7 ms) -- off
         self.fuse_actbwd = int(os.environ.get("E2_FUSE_ACTBWD", "0"))
         self.out, self.grad, self.scratch = {}, {}, {}
+        # bf16 mode: operands of the GEMM launches made ahead of them (bf16_ahead.py)
+        self.bf16a, self._bf16_wjobs = {}, None
+        self._xb_ready, self._dy_ready, self._wb_ready = {}, {}, False
+        self._bf16_ahead_on = os.environ.get("E2_BF16_AHEAD", "1") == "1"
         self._xkeep_valid = {}       # Conv node -> its kept bf16 input copy is this step's
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
@@ -423,6 +427,10 @@ class Plan(object):
     def _emit_forward(self):
         if self._pack_dev is not None:       # all packed weight images, one launch
             self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
+        self._xb_ready, self._dy_ready = {}, {}
+        self._wb_ready = self._bf16_wjobs is not None
+        if self._wb_ready:                   # bf16 mode: every layer's filter rows, one launch
+            self.ctx.conv3d_bf16_pack_w_multi(*self._bf16_wjobs)
         for n in self.nodes:
             n._plan_fwd(self)
         self.join_side()
@@ -603,6 +611,9 @@ class Plan(object):
             if self._upd_zeroes_g() and not self.model._g_clean:
                 ctx.fill(self.model.G, 0.0)            # (someone else wrote G: eager, outside the graphs)
             self.model._g_clean = False
+        if self._graphs is None:
+            from . import bf16_ahead
+            bf16_ahead.prepare(self)                   # (allocates: never during a capture)
         capture = self.use_graph and self._calls >= 1
         if capture and self._graphs is None:
             # the first captured call runs segment by segment: a host step between two

@@ -469,3 +469,49 @@ def test_wgrad_bf16_with_ready_made_operands(ctx, case, tile):
         assert relerr(dw, ref) < TOL
     finally:
         ctx.set_tiling("wgrad", None)
+
+
+def _lite_steps(n_steps, sp=(9, 71, 71), ahead=True, use_graph=True, net="neuro3d_lite"):
+    """n training steps of a small-input neuro3d_lite / neuro3d in bf16 mode with every conv launch
+    pinned to the kernels with bf16 operands in memory; returns (losses, parameters, launches)"""
+    from elektronn2_amd import nets, autotune, neuromancer as nm
+    nm.model_manager.reset()
+    os.environ["E2_BF16_AHEAD"] = "1" if ahead else "0"
+    spec = O.NEURO3D_LITE if net == "neuro3d_lite" else O.NEURO3D
+    params = O.init_net(spec, 1, seed=3)
+    rng = np.random.RandomState(5)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    m = getattr(nets, net)((None, 1) + sp, params=params)
+    m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+    autotune.force('igemm', "32,1,2")
+    autotune.force('wgrad', "32,1,2,0,0")
+    try:
+        opt = m.optimisers['Adam']
+        opt.step.compile()
+        opt.step.func.use_graph = use_graph
+        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(n_steps)]
+        plan = opt.step.func
+        kinds = sorted(set(k for (_, k) in plan.bf16a))
+        ps = [p.detach().cpu().numpy().copy() for p in m.device_params_list()] \
+            if hasattr(m, 'device_params_list') else [plan.model.P.detach().cpu().numpy().copy()]
+    finally:
+        autotune.force('igemm', None)
+        autotune.force('wgrad', None)
+        os.environ.pop("E2_BF16_AHEAD", None)
+    return losses, ps, kinds
+
+
+@pytest.mark.parametrize("net,sp", [("neuro3d_lite", (9, 71, 71)), ("neuro3d", (23, 121, 121))])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_step_with_operands_made_ahead_equals_the_converting_step(process_bf16, net, sp, use_graph):
+    """the same bf16 step with the GEMM operands written by their producers (bf16_ahead.py) and
+    with every launch converting for itself: the images are bit-identical, so losses and
+    parameters agree to the weight gradients' atomic summation order"""
+    l0, p0, k0 = _lite_steps(4, sp=sp, ahead=False, use_graph=use_graph, net=net)
+    l1, p1, k1 = _lite_steps(4, sp=sp, ahead=True, use_graph=use_graph, net=net)
+    assert k0 == [] and {'fwd', 'dgrad', 'wgrad', 'dy', 'next'} <= set(k1), (k0, k1)
+    assert np.isfinite(l1).all()
+    np.testing.assert_allclose(l1, l0, rtol=2e-5)
+    for a, b in zip(p1, p0):
+        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30) + 1e-7
