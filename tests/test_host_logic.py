@@ -275,11 +275,17 @@ def test_tiling_candidate_lists():
     # 1x1x1 / UpConv weight gradient as a GEMM with K-contiguous operands: "MT,NT,7,0,S"; the
     # tile list is the kernel's instance list (csrc/conv_pw_wgrad.hip)
     src = open(os.path.join(os.path.dirname(autotune.__file__), "csrc", "conv_pw_wgrad.hip")).read()
-    inst = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", src))
+    host7, host8 = src.split("int e2i_pw_wgrad_ks(")
+    inst = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", host7))
     assert inst == set(autotune.PW_WGRAD_TILES)
+    # ... and "MT,NT,8,0,S": one tile per work-group, its four waves split the positions
+    inst8 = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", host8))
+    assert inst8 == set(autotune.PW_WGRAD_KS_TILES)
     pg = autotune.pointwise_wgrad_candidates(2048, 256, (1, 1, 1), (18, 10, 10))
-    assert pg and all(re.fullmatch(r"\d+,\d+,7,0,\d+", c) for c in pg)
-    assert all((int(c.split(",")[0]), int(c.split(",")[1])) in inst for c in pg)
+    assert pg and all(re.fullmatch(r"\d+,\d+,[78],0,\d+", c) for c in pg)
+    ks = [c for c in autotune.pointwise_wgrad_candidates(200, 200, (1, 1, 1), (10, 37, 37)) if ",8,0," in c]
+    assert "7,2,8,0,18" in ks and "13,2,8,0,36" in ks       # (14 / 7 tiles x S = 252 work-groups)
+    assert all((int(c.split(",")[0]), int(c.split(",")[1])) in (inst8 if ",8,0," in c else inst) for c in pg)
     assert autotune.pointwise_wgrad_candidates(200, 200, (1, 3, 3), (10, 37, 37)) == []
     assert set(pg) <= set(autotune.wgrad_candidates(2048, 256, (1, 1, 1), (18, 10, 10)))
     # bf16 weight gradient: "32,MB,NB,R,S"; the row form (R = 1) for few input channels only,
