@@ -15,6 +15,7 @@
 #include <algorithm>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float pf2 __attribute__((ext_vector_type(2), aligned(4)));
 
 namespace {
@@ -51,12 +52,14 @@ __global__ __launch_bounds__(256) void bwd_bf16_kernel(BwP p) {
   constexpr int NO = 2 / PX;                               // pooled outputs per thread (along x)
   __shared__ float red[8][4];
   const int tid = threadIdx.x;
-  const int col = blockIdx.x * 256 + tid;                  // (pooled row, thread column)
+  const int col = blockIdx.x * 256 + tid;                  // (pooled plane, pooled row, thread column)
   const int kg = blockIdx.y;
-  const int zo = blockIdx.z % p.Do, n = blockIdx.z / p.Do;
-  const bool live = col < p.Ho * p.VW;
-  const int yo = live ? col / p.VW : 0;
-  const int xo = live ? (col - yo * p.VW) * NO : 0;
+  const int n = blockIdx.z;
+  const bool live = col < p.Do * p.Ho * p.VW;
+  const int zo = live ? col / (p.Ho * p.VW) : 0;
+  const int rc = col - zo * (p.Ho * p.VW);
+  const int yo = live ? rc / p.VW : 0;
+  const int xo = live ? (rc - yo * p.VW) * NO : 0;
   const int nvo = live ? min(NO, p.Wo - xo) : 0;           // valid pooled outputs
   float gs[8];
   bf16x8 piece[PZ][PY][2];
@@ -69,10 +72,16 @@ __global__ __launch_bounds__(256) void bwd_bf16_kernel(BwP p) {
     for (int o = 0; o < NO; ++o) { g[o] = 0.f; m[o] = -INFINITY; }
     if (cv) {
       const float* gp = p.dout + (long)n * p.gsN + (long)c * p.gsC + (long)zo * p.gsZ + (long)yo * p.gsY + xo;
-      for (int q = 0; q < p.parts; ++q)
+      // (split-K partial sums: every part requested before the first add)
+      float u[8][NO];
 #pragma unroll
-        for (int o = 0; o < NO; ++o)
-          if (o < nvo) g[o] += gp[q * p.gpart + o];
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) u[q][o] = (q < p.parts && o < nvo) ? gp[q * p.gpart + o] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) g[o] += u[q][o];
       const float* sp = p.src + (long)n * p.ssN + (long)c * p.ssC + (long)(zo * PZ) * p.ssZ +
                         (long)(yo * PY) * p.ssY + xo * PX;
 #pragma unroll
@@ -108,17 +117,32 @@ __global__ __launch_bounds__(256) void bwd_bf16_kernel(BwP p) {
 #pragma unroll
     for (int a = 0; a < PZ; ++a)
 #pragma unroll
-      for (int b = 0; b < PY; ++b)
+      for (int b = 0; b < PY; ++b) {
+        float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const bool ev = cv && (e / PX) < nvo;
-          const float v = (ev && w[a][b][e] == m[e / PX]) ? g[e / PX] : 0.f;
-          piece[a][b][e][j] = (__bf16)v;
-          if (ev) {
-            if (dp) dp[a * p.dsZ + b * p.dsY + e] = v;
-            if (pp) pp[a * p.d.plPlane + (long)b * p.d.plPitch + e] = (__bf16)v;
+          v[e] = (ev && w[a][b][e] == m[e / PX]) ? g[e / PX] : 0.f;
+          piece[a][b][e][j] = (__bf16)v[e];
+        }
+        if (!cv) continue;
+        const bool both = nvo * PX == 2;
+        if (dp) {
+          float* d = dp + a * p.dsZ + b * p.dsY;
+          if (both) { pf2 t = {v[0], v[1]}; *reinterpret_cast<pf2*>(d) = t; }
+          else d[0] = v[0];
+        }
+        if (pp) {
+          __bf16* d = pp + a * p.d.plPlane + (long)b * p.d.plPitch;
+          if (both && (((uintptr_t)d & 3) == 0)) {
+            bf16x2 t = {(__bf16)v[0], (__bf16)v[1]};
+            *reinterpret_cast<bf16x2*>(d) = t;
+          } else {
+            d[0] = (__bf16)v[0];
+            if (both) d[1] = (__bf16)v[1];
           }
         }
+      }
   }
   if (p.d.cl && nvo > 0) {
 #pragma unroll
@@ -163,10 +187,12 @@ template <int PZ, int PY, int PX>
 __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
   constexpr int NO = 2;                                    // pooled outputs per thread
   const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= p.Ho * p.VW) return;
+  if (col >= p.Do * p.Ho * p.VW) return;
   const int kg = blockIdx.y;
-  const int zo = blockIdx.z % p.Do, n = blockIdx.z / p.Do;
-  const int yo = col / p.VW, xo = (col - yo * p.VW) * NO;
+  const int n = blockIdx.z;
+  const int zo = col / (p.Ho * p.VW);
+  const int rc = col - zo * (p.Ho * p.VW);
+  const int yo = rc / p.VW, xo = (rc - yo * p.VW) * NO;
   const int nvo = min(NO, p.Wo - xo);
   bf16x8 piece[NO];
 #pragma unroll
@@ -188,7 +214,13 @@ __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
 #pragma unroll
               for (int e = 0; e < PX; ++e) {
                 float v = r[e];
-                for (int q = 1; q < p.parts; ++q) v += r[q * p.ypart + e];
+                if (p.parts > 1) {                 // (split-K partial sums: requested together)
+                  float u[7];
+#pragma unroll
+                  for (int q = 1; q < 8; ++q) u[q - 1] = q < p.parts ? r[q * p.ypart + e] : 0.f;
+#pragma unroll
+                  for (int q = 1; q < 8; ++q) v += u[q - 1];
+                }
                 m[o] = fmaxf(m[o], v);
               }
             }
@@ -273,8 +305,9 @@ extern "C" int e2_pool_bias_act_bwd_bf16(e2_ctx* ctx, const e2_tensor5* dout, in
   const int NO = 2 / px;
   E2_REQUIRE(px == 1 || px == 2, "pool_bias_act_bwd_bf16: x windows of 1 or 2");
   p.VW = (p.Wo + NO - 1) / NO;
-  const dim3 grid((unsigned)((p.Ho * p.VW + 255) / 256), (unsigned)((p.C + 7) / 8), (unsigned)(p.N * p.Do));
-  E2_REQUIRE((long)p.N * p.Do < 65536 && (p.C + 7) / 8 < 65536, "pool_bias_act_bwd_bf16: grid too large");
+  E2_REQUIRE((long)p.Do * p.Ho * p.VW < (1L << 30), "pool_bias_act_bwd_bf16: planes too large");
+  const dim3 grid((unsigned)((p.Do * p.Ho * p.VW + 255) / 256), (unsigned)((p.C + 7) / 8), (unsigned)p.N);
+  E2_REQUIRE(p.N < 65536 && (p.C + 7) / 8 < 65536, "pool_bias_act_bwd_bf16: grid too large");
 #define E2_L(Z, Y, X) if (pz == Z && py == Y && px == X) { \
     hipLaunchKernelGGL((bwd_bf16_kernel<Z, Y, X>), grid, dim3(256), 0, ctx->stream, p); \
     E2_CHECK_HIP(hipGetLastError()); return 0; }
@@ -301,8 +334,9 @@ extern "C" int e2_pool_bias_act_fwd_bf16(e2_ctx* ctx, const e2_tensor5* y, int64
   if (int rc = check_dst(dst, &p.d, out->n, out->c, out->d, out->h, out->w, "pool_bias_act_fwd_bf16")) return rc;
   E2_REQUIRE(!p.d.pl, "pool_bias_act_fwd_bf16: channels-last output only");
   p.VW = (p.Wo + 1) / 2;
-  const dim3 grid((unsigned)((p.Ho * p.VW + 255) / 256), (unsigned)(p.d.cl ? p.d.clKG : (p.C + 7) / 8), (unsigned)(p.N * p.Do));
-  E2_REQUIRE((long)p.N * p.Do < 65536 && grid.y < 65536, "pool_bias_act_fwd_bf16: grid too large");
+  E2_REQUIRE((long)p.Do * p.Ho * p.VW < (1L << 30), "pool_bias_act_fwd_bf16: planes too large");
+  const dim3 grid((unsigned)((p.Do * p.Ho * p.VW + 255) / 256), (unsigned)(p.d.cl ? p.d.clKG : (p.C + 7) / 8), (unsigned)p.N);
+  E2_REQUIRE(p.N < 65536 && grid.y < 65536, "pool_bias_act_fwd_bf16: grid too large");
 #define E2_L(Z, Y, X) if (pz == Z && py == Y && px == X) { \
     hipLaunchKernelGGL((fwd_bf16_kernel<Z, Y, X>), grid, dim3(256), 0, ctx->stream, p); \
     E2_CHECK_HIP(hipGetLastError()); return 0; }

@@ -428,7 +428,9 @@ class Plan(object):
         if self._pack_dev is not None:       # all packed weight images, one launch
             self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
         self._xb_ready, self._dy_ready = {}, {}
-        self._wb_ready = self._bf16_wjobs is not None
+        # (E2_BF16_WPACK=call: the filter rows are packed by each launch's own conversion pass,
+        # right in front of it, instead of all at the start of the step -- A/B switch)
+        self._wb_ready = self._bf16_wjobs is not None and os.environ.get("E2_BF16_WPACK", "step") == "step"
         if self._wb_ready:                   # bf16 mode: every layer's filter rows, one launch
             self.ctx.conv3d_bf16_pack_w_multi(*self._bf16_wjobs)
         for n in self.nodes:
