@@ -63,54 +63,61 @@ __global__ __launch_bounds__(256) void bwd_bf16_kernel(BwP p) {
   const int nvo = live ? min(NO, p.Wo - xo) : 0;           // valid pooled outputs
   float gs[8];
   bf16x8 piece[PZ][PY][2];
+  // phase 1: every load of the thread's 8 channels (the stores below may alias them for all the
+  // compiler knows: interleaved, each channel waited for the one before it)
+  float g[8][NO], w[8][PZ][PY][2], bv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = kg * 8 + j;
     const bool cv = c < p.C && nvo > 0;
-    float g[NO], w[PZ][PY][2], m[NO];
+    const float* gp = p.dout + (long)n * p.gsN + (long)min(c, p.C - 1) * p.gsC + (long)zo * p.gsZ + (long)yo * p.gsY + xo;
+    float u[8][NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) { g[o] = 0.f; m[o] = -INFINITY; }
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int o = 0; o < NO; ++o) u[q][o] = (cv && q < p.parts && o < nvo) ? gp[q * p.gpart + o] : 0.f;
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+      g[j][o] = ((u[0][o] + u[1][o]) + (u[2][o] + u[3][o])) + ((u[4][o] + u[5][o]) + (u[6][o] + u[7][o]));
+    const float* sp = p.src + (long)n * p.ssN + (long)min(c, p.C - 1) * p.ssC + (long)(zo * PZ) * p.ssZ +
+                      (long)(yo * PY) * p.ssY + xo * PX;
+#pragma unroll
+    for (int a = 0; a < PZ; ++a)
+#pragma unroll
+      for (int b = 0; b < PY; ++b) {
+        const float* r = sp + a * p.ssZ + b * p.ssY;
+        if (cv && nvo * PX == 2) { const pf2 v = *reinterpret_cast<const pf2*>(r); w[j][a][b][0] = v[0]; w[j][a][b][1] = v[1]; }
+        else if (cv) { w[j][a][b][0] = r[0]; w[j][a][b][1] = -INFINITY; }
+        else { w[j][a][b][0] = 0.f; w[j][a][b][1] = 0.f; }
+      }
+    bv[j] = (p.bias && c < p.C) ? p.bias[c] : 0.f;
+  }
+  // phase 2: slopes, row sums, stores
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = kg * 8 + j;
+    const bool cv = c < p.C && nvo > 0;
+    float m[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) m[o] = -INFINITY;
     if (cv) {
-      const float* gp = p.dout + (long)n * p.gsN + (long)c * p.gsC + (long)zo * p.gsZ + (long)yo * p.gsY + xo;
-      // (split-K partial sums: every part requested before the first add)
-      float u[8][NO];
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int o = 0; o < NO; ++o) u[q][o] = (q < p.parts && o < nvo) ? gp[q * p.gpart + o] : 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int o = 0; o < NO; ++o) g[o] += u[q][o];
-      const float* sp = p.src + (long)n * p.ssN + (long)c * p.ssC + (long)(zo * PZ) * p.ssZ +
-                        (long)(yo * PY) * p.ssY + xo * PX;
 #pragma unroll
       for (int a = 0; a < PZ; ++a)
 #pragma unroll
-        for (int b = 0; b < PY; ++b) {
-          const float* r = sp + a * p.ssZ + b * p.ssY;
-          if (nvo * PX == 2) { const pf2 v = *reinterpret_cast<const pf2*>(r); w[a][b][0] = v[0]; w[a][b][1] = v[1]; }
-          else { w[a][b][0] = r[0]; w[a][b][1] = -INFINITY; }
+        for (int b = 0; b < PY; ++b)
 #pragma unroll
-          for (int e = 0; e < 2; ++e) m[e / PX] = fmaxf(m[e / PX], w[a][b][e]);
-        }
-    } else {
-#pragma unroll
-      for (int a = 0; a < PZ; ++a)
-#pragma unroll
-        for (int b = 0; b < PY; ++b) w[a][b][0] = w[a][b][1] = 0.f;
+          for (int e = 0; e < 2; ++e) m[e / PX] = fmaxf(m[e / PX], w[j][a][b][e]);
     }
     float s = 0.f;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
       if (p.act == E2_ACT_RELU) {
-        if (p.out_mode) g[o] *= (m[o] > 0.f) ? 1.f : (__builtin_signbit(m[o]) ? 0.f : 0.5f);
-        else { const float pre = m[o] + p.bias[min(c, p.C - 1)]; g[o] *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f); }
+        if (p.out_mode) g[j][o] *= (m[o] > 0.f) ? 1.f : (__builtin_signbit(m[o]) ? 0.f : 0.5f);
+        else { const float pre = m[o] + bv[j]; g[j][o] *= (pre > 0.f) ? 1.f : ((pre == 0.f) ? 0.5f : 0.f); }
       }
-      if (o < nvo && cv) s += g[o];
+      if (o < nvo && cv) s += g[j][o];
     }
     gs[j] = s;
-    // the window's gradient values; f32 + plane stores here, pixel pieces collected
     float* dp = p.dy ? p.dy + (long)n * p.dsN + (long)c * p.dsC + (long)(zo * PZ) * p.dsZ + (long)(yo * PY) * p.dsY + xo * PX : nullptr;
     __bf16* pp = p.d.pl ? p.d.pl + (((long)n * p.C + c) * p.D + zo * PZ) * p.d.plPlane +
                               (long)(yo * PY) * p.d.plPitch + xo * PX : nullptr;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256) void bwd_bf16_kernel(BwP p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const bool ev = cv && (e / PX) < nvo;
-          v[e] = (ev && w[a][b][e] == m[e / PX]) ? g[e / PX] : 0.f;
+          v[e] = (ev && w[j][a][b][e] == m[e / PX]) ? g[j][e / PX] : 0.f;
           piece[a][b][e][j] = (__bf16)v[e];
         }
         if (!cv) continue;
@@ -195,12 +202,13 @@ __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
   const int yo = rc / p.VW, xo = (rc - yo * p.VW) * NO;
   const int nvo = min(NO, p.Wo - xo);
   bf16x8 piece[NO];
+  // phase 1: every load of the thread's 8 channels (all in flight together), phase 2: stores
+  float m[8][NO];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = kg * 8 + j;
-    float m[NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) m[o] = -INFINITY;
+    for (int o = 0; o < NO; ++o) m[j][o] = -INFINITY;
     if (c < p.C) {
       const float* sp = p.y + (long)n * p.ysN + (long)c * p.ysC + (long)(zo * PZ) * p.ysZ + (long)(yo * PY) * p.ysY + xo * PX;
 #pragma unroll
@@ -221,24 +229,31 @@ __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
 #pragma unroll
                   for (int q = 1; q < 8; ++q) v += u[q - 1];
                 }
-                m[o] = fmaxf(m[o], v);
+                m[j][o] = fmaxf(m[j][o], v);
               }
             }
       const float bv = p.bias ? p.bias[c] : 0.f;
-      float* op = p.out ? p.out + (long)n * p.osN + (long)c * p.osC + (long)zo * p.osZ + (long)yo * p.osY + xo : nullptr;
 #pragma unroll
       for (int o = 0; o < NO; ++o) {
-        float v = m[o] + bv;
+        float v = m[j][o] + bv;
         if (p.act == E2_ACT_RELU) v = fmaxf(v, 0.f);        // (as pool_fwd_fixed_kernel: the backward reads y, not out)
-        m[o] = (o < nvo) ? v : 0.f;
-        if (op && o < nvo) op[o] = v;
+        m[j][o] = (o < nvo) ? v : 0.f;
       }
     } else {
 #pragma unroll
-      for (int o = 0; o < NO; ++o) m[o] = 0.f;
+      for (int o = 0; o < NO; ++o) m[j][o] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = kg * 8 + j;
+    if (p.out && c < p.C) {
+      float* op = p.out + (long)n * p.osN + (long)c * p.osC + (long)zo * p.osZ + (long)yo * p.osY + xo;
+      if (nvo == 2) { pf2 t = {m[j][0], m[j][1]}; *reinterpret_cast<pf2*>(op) = t; }
+      else op[0] = m[j][0];
     }
 #pragma unroll
-    for (int o = 0; o < NO; ++o) piece[o][j] = (__bf16)m[o];
+    for (int o = 0; o < NO; ++o) piece[o][j] = (__bf16)m[j][o];
   }
   if (p.d.cl) {
 #pragma unroll
