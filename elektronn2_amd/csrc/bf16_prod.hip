@@ -193,6 +193,7 @@ struct FwP {
 template <int PZ, int PY, int PX>
 __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
   constexpr int NO = 2;                                    // pooled outputs per thread
+  typedef float pfN __attribute__((ext_vector_type(NO * PX), aligned(4)));
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= p.Do * p.Ho * p.VW) return;
   const int kg = blockIdx.y;
@@ -214,24 +215,32 @@ __global__ __launch_bounds__(256) void fwd_bf16_kernel(FwP p) {
 #pragma unroll
       for (int a = 0; a < PZ; ++a)
 #pragma unroll
-        for (int b = 0; b < PY; ++b)
+        for (int b = 0; b < PY; ++b) {
+          // the row piece of the thread's two windows: NO * PX consecutive floats, one access
+          const float* r = sp + a * p.ysZ + b * p.ysY;
+          float v[NO * PX];
+          if (nvo == NO) {
+            const pfN t = *reinterpret_cast<const pfN*>(r);
 #pragma unroll
-          for (int o = 0; o < NO; ++o)
-            if (o < nvo) {
-              const float* r = sp + a * p.ysZ + b * p.ysY + o * PX;
+            for (int e = 0; e < NO * PX; ++e) v[e] = t[e];
+            for (int q = 1; q < p.parts; ++q) {      // (split-K partial sums; 16-byte pieces)
+              const pfN u = *reinterpret_cast<const pfN*>(r + q * p.ypart);
 #pragma unroll
-              for (int e = 0; e < PX; ++e) {
-                float v = r[e];
-                if (p.parts > 1) {                 // (split-K partial sums: requested together)
-                  float u[7];
+              for (int e = 0; e < NO * PX; ++e) v[e] += u[e];
+            }
+          } else {
 #pragma unroll
-                  for (int q = 1; q < 8; ++q) u[q - 1] = q < p.parts ? r[q * p.ypart + e] : 0.f;
-#pragma unroll
-                  for (int q = 1; q < 8; ++q) v += u[q - 1];
-                }
-                m[j][o] = fmaxf(m[j][o], v);
+            for (int e = 0; e < NO * PX; ++e) {
+              v[e] = -INFINITY;
+              if (e < nvo * PX) {
+                v[e] = r[e];
+                for (int q = 1; q < p.parts; ++q) v[e] += r[q * p.ypart + e];
               }
             }
+          }
+#pragma unroll
+          for (int e = 0; e < NO * PX; ++e) m[j][e / PX] = fmaxf(m[j][e / PX], v[e]);
+        }
       const float bv = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
       for (int o = 0; o < NO; ++o) {

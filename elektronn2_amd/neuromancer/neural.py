@@ -559,6 +559,7 @@ class Conv(NeuralLayer):
                                 xkeep=plan.bf16_xkeep(self))
             return
         nx = bf16_ahead.next_image(plan, self) if bias is not None else None
+        plan.ensure_wb()
         ctx.conv3d_fwd_bf16_ex(x, w5, out, bias=bias, act=act, ws=plan.bf16_ws(self),
                                xkeep=plan.bf16_xkeep(self), x_ready=plan._xb_ready.get(self, False),
                                wb=a['wb'] if plan._wb_ready else None,
@@ -793,6 +794,7 @@ class Conv(NeuralLayer):
                 if ctx.bf16_memory_form():
                     ad = plan.bf16a.get((self, 'dgrad'))
                     if ad is not None and plan._dy_ready.get(self) and ad['tile'] == ctx.current_tiling('igemm'):
+                        plan.ensure_wb()
                         ctx.conv3d_dgrad_bf16_ex(dyp, self._w5(plan.param(self.w)), out,
                                                  ws=plan.bf16_ws(self), dy_cl=ad['cl'],
                                                  wb=ad['wb'] if plan._wb_ready else None)

@@ -428,14 +428,20 @@ class Plan(object):
         if self._pack_dev is not None:       # all packed weight images, one launch
             self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
         self._xb_ready, self._dy_ready = {}, {}
-        # (E2_BF16_WPACK=call: the filter rows are packed by each launch's own conversion pass,
-        # right in front of it, instead of all at the start of the step -- A/B switch)
-        self._wb_ready = self._bf16_wjobs is not None and os.environ.get("E2_BF16_WPACK", "step") == "step"
-        if self._wb_ready:                   # bf16 mode: every layer's filter rows, one launch
-            self.ctx.conv3d_bf16_pack_w_multi(*self._bf16_wjobs)
+        self._wb_ready = False               # bf16 mode: see ensure_wb
         for n in self.nodes:
             n._plan_fwd(self)
         self.join_side()
+
+    def ensure_wb(self):
+        """bf16 mode: every layer's packed filter rows by ONE launch per step, issued in front of
+        the first launch that reads them (behind the fused first layer, which does not).
+        E2_BF16_WPACK=call: each launch's own conversion pass packs its rows instead (A/B switch)"""
+        if not self._wb_ready and self._bf16_wjobs is not None and \
+                os.environ.get("E2_BF16_WPACK", "step") == "step":
+            self.ctx.conv3d_bf16_pack_w_multi(*self._bf16_wjobs)
+            self._wb_ready = True
+        return self._wb_ready
 
     def _bwd_nodes(self):
         return [n for n in reversed(self.nodes)
