@@ -158,6 +158,7 @@ def _load():
         "e2_conv3d_wgrad_bf16_xcl": (C.c_int, [vp, P5, vp, i, P5, fp, i, i, i, i, vp, sz]),
         "e2_pool_bias_act_bwd_bf16": (C.c_int, [vp, P5, C.c_int64, i, P5, fp, i, i, i, i, P5, fp, C.POINTER(Bf16Dst)]),
         "e2_pool_bias_act_fwd_bf16": (C.c_int, [vp, P5, C.c_int64, i, fp, i, i, i, i, P5, C.POINTER(Bf16Dst)]),
+        "e2_conv1_pool_act_fwd_bf16": (C.c_int, [vp, P5, fp, fp, i, i, i, i, i, i, P5, vp, i]),
         "e2_conv3d_bf16_wb_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
         "e2_bf16_wjob_bytes": (sz, []),
         "e2_bf16_wjob_fill": (C.c_int, [vp, fp, i, i, i, i, i, i, i, i, i, i, vp, sz]),
@@ -489,6 +490,13 @@ class Context:
         _chk(_lib.e2_conv1_pool_act_fwd(self.h, C.byref(t5(x)), _fp(w), _fp(bias), w.shape[0],
                                         w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
                                         C.byref(t5(out))), "e2_conv1_pool_act_fwd")
+
+    def conv1_pool_act_fwd_bf16(self, x, w, bias, pool, act, out, next_xb, next_kg):
+        """conv1_pool_act_fwd + the next conv layer's channels-last bf16 input image"""
+        _chk(_lib.e2_conv1_pool_act_fwd_bf16(self.h, C.byref(t5(x)), _fp(w), _fp(bias), w.shape[0],
+                                             w.shape[3], w.shape[4], pool[1], pool[2], ACT[act],
+                                             C.byref(t5(out)), C.c_void_p(next_xb.data_ptr()),
+                                             int(next_kg)), "e2_conv1_pool_act_fwd_bf16")
 
     @staticmethod
     def conv1_bwd_ws_bytes(dout_shape, k):

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void first_bwd_reduce_sm_kernel(const float* _
 int e2i_firstm_mg(int cout);
 size_t e2i_firstm_ws_floats(long nTiles, int cout, int T);
 int e2i_firstm_fwd(e2_ctx*, int v, const e2_tensor5* x, const float* w, const float* bias, int cout,
-                   int py, int px, int act, const e2_tensor5* out);
+                   int py, int px, int act, const e2_tensor5* out, void* next_xb, int next_kg);
 int e2i_firstm_bwd(e2_ctx*, int v, const e2_tensor5* x, const float* w, const float* bias,
                    const e2_tensor5* dout, int py, int px, int act, float* part, int* nslots);
 
@@ -269,17 +269,38 @@ static int first_fill(First& p, const e2_tensor5* x, const e2_tensor5* o, int co
   return 0;
 }
 
+static int conv1_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w, const float* bias, int cout,
+                     int kh, int kw, int py, int px, int act, const e2_tensor5* out, void* next_xb,
+                     int next_kg);
+
 extern "C" int e2_conv1_pool_act_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w,
                                      const float* bias, int cout, int kh, int kw, int py,
                                      int px, int act, const e2_tensor5* out) {
+  return conv1_fwd(ctx, x, w, bias, cout, kh, kw, py, px, act, out, nullptr, 0);
+}
+
+// ... and the channels-last bf16 copy of out for the next conv layer (bf16 mode, SURVEY.md 8f-3;
+// include/e2hip.h "the producers' epilogues"): matrix-core form only (cout <= 32)
+extern "C" int e2_conv1_pool_act_fwd_bf16(e2_ctx* ctx, const e2_tensor5* x, const float* w,
+                                          const float* bias, int cout, int kh, int kw, int py,
+                                          int px, int act, const e2_tensor5* out, void* next_xb,
+                                          int next_kg) {
+  E2_REQUIRE(next_xb, "conv1_pool_act_fwd_bf16: null copy");
+  return conv1_fwd(ctx, x, w, bias, cout, kh, kw, py, px, act, out, next_xb, next_kg);
+}
+
+static int conv1_fwd(e2_ctx* ctx, const e2_tensor5* x, const float* w, const float* bias, int cout,
+                     int kh, int kw, int py, int px, int act, const e2_tensor5* out, void* next_xb,
+                     int next_kg) {
   E2_REQUIRE(ctx && w && bias, "conv1_pool_act_fwd: null argument");
   const int v = first_supported(1, kh, kw, 1, py, px);
   E2_REQUIRE(v, "conv1_pool_act_fwd: unsupported kernel/pool %dx%d / %dx%d", kh, kw, py, px);
   First p{};
   if (int rc = first_fill(p, x, out, cout, kh, kw, py, px, "conv1_pool_act_fwd")) return rc;
   p.w = w; p.bias = bias; p.out = out->ptr; p.act = act;
-  if (e2i_firstm_mg(cout) && !e2_dbg_env("E2_FIRST_VALU"))
-    return e2i_firstm_fwd(ctx, v, x, w, bias, cout, py, px, act, out);
+  if (e2i_firstm_mg(cout) && (next_xb || !e2_dbg_env("E2_FIRST_VALU")))
+    return e2i_firstm_fwd(ctx, v, x, w, bias, cout, py, px, act, out, next_xb, next_kg);
+  E2_REQUIRE(!next_xb, "conv1_pool_act_fwd_bf16: %d output channels (matrix-core form: <= 32)", cout);
   const long nTiles = (long)p.N * p.D * p.tilesY * p.tilesX;
   const int grid = (int)std::min<long>(nTiles, ctx->num_cu * 8);
   if (v == 1)

@@ -46,6 +46,8 @@ __device__ __forceinline__ f32x4 fm_mfma(float a, float b, f32x4 c) {
 
 namespace {
 
+typedef __bf16 fm_bf16x8 __attribute__((ext_vector_type(8)));
+
 struct FirstM {
   const float* x;      // (n,1,d,h,w) view
   const float* w;      // [cout][1][1][kh][kw] dense
@@ -60,6 +62,10 @@ struct FirstM {
   int tilesX, tilesY, nTiles;
   int dbg;                       // timing ablations (debug build, E2_FM_DBG): 1 = no tile loads,
                                  // 2 = no conv MFMAs, 4 = no output stores / no dW MFMAs
+  // forward, bf16 mode: the channels-last bf16 copy of `out` that the next conv's kernels read,
+  // [N][D][nxKG][Ho * Wo][8] -- or nullptr (written by the producer)
+  __bf16* nxb;
+  int nxKG;
 };
 
 // The ablation switches exist in a `make DEBUG_ENV=1` build only.  As run-time branches on a
@@ -187,12 +193,29 @@ __global__ __launch_bounds__(256) void firstm_fwd_kernel(FirstM p) {
         if constexpr (PY == 2) m = fmaxf(m, acc[g][1][r]);
         if constexpr (PX == 2) m = fmaxf(m, __shfl_xor(m, 1, 64));
         const int ch = 4 * g + r;
+        float v = 0.f;
         if (ch < p.Cout) {
-          float v = m + bs[g][r];
+          v = m + bs[g][r];
           if (p.act == E2_ACT_RELU) v = fmaxf(v, 0.f);
           if (ok && !(FM_DBG(p, 4) && ch > 0)) ob[(long)ch * p.osC] = v;
         }
+        acc[g][0][r] = v;
       }
+    if (p.nxb && ok) {
+      // the lane holds every channel of its pooled position: whole 16-byte pixel pieces
+      __bf16* nb = p.nxb + ((((long)n * p.D + z) * p.nxKG) * ((long)p.Ho * p.Wo) + (long)prow * p.Wo + pcol) * 8;
+#pragma unroll
+      for (int kg = 0; kg < (MG + 1) / 2; ++kg) {
+        if (kg >= p.nxKG) continue;
+        fm_bf16x8 h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int g = 2 * kg + (e >> 2);
+          h[e] = (__bf16)(g < MG ? acc[g < MG ? g : 0][0][e & 3] : 0.f);
+        }
+        *reinterpret_cast<fm_bf16x8*>(nb + (long)kg * p.Ho * p.Wo * 8) = h;
+      }
+    }
   }
 }
 
@@ -388,11 +411,14 @@ static void fill(FirstM& p, const e2_tensor5* x, const e2_tensor5* o, int cout, 
   if (v == 3 && mg == 8) return FN<3, 3, 1, 1, 8>(__VA_ARGS__);
 
 int e2i_firstm_fwd(e2_ctx* ctx, int v, const e2_tensor5* x, const float* w, const float* bias,
-                   int cout, int py, int px, int act, const e2_tensor5* out) {
+                   int cout, int py, int px, int act, const e2_tensor5* out, void* next_xb, int next_kg) {
   const int mg = e2i_firstm_mg(cout);
   FirstM p{};
   fill(p, x, out, cout, py, px);
   p.w = w; p.bias = bias; p.out = out->ptr; p.act = act;
+  E2_REQUIRE(!next_xb || (next_kg * 8 >= cout && ((uintptr_t)next_xb & 15) == 0),
+             "conv1(mfma): the next layer's copy holds %d channel groups for %d channels", next_kg, cout);
+  p.nxb = reinterpret_cast<__bf16*>(next_xb); p.nxKG = next_kg;
   const int grid = e2i_firstm_grid(ctx, p.nTiles);
   E2_FM_DISPATCH(launch_fwd, ctx, p, grid)
   e2_set_error("conv1(mfma): no instance for variant %d, %d channels", v, cout);

@@ -126,12 +126,15 @@ def prepare(plan):
         from .neural import Conv
         if type(par) is not Conv or not hasattr(par, '_k3') or par.parent is None:
             continue
-        if par._fused_first(plan) or not eligible(plan, par):
-            continue                      # (the fused first layer keeps the conversion of its output)
+        if par._fused_first(plan):
+            if par.n_f > 32:              # (the matrix-core form of the fused first layer only)
+                continue
+        elif not eligible(plan, par):
+            continue
         if tuple(plan.out[par].shape) != tuple(plan.out_shape(par)) or (par, 'next') in a:
             continue                      # (a second consumer of the same tensor converts by itself)
         kgn = (par.n_f + 15) // 16 * 2
-        if par._fused_act(plan):
+        if not par._fused_first(plan) and par._fused_act(plan):
             # the parent's conv epilogue writes it -- when that launch is a memory form too
             pf = a.get((par, 'fwd'))
             if pf is None:

@@ -573,8 +573,14 @@ class Conv(NeuralLayer):
             return                            # done by the Softmax / NLL node
         x = plan.out[self.parent]
         if self._fused_first(plan):
-            ctx.conv1_pool_act_fwd(x, self._w5(plan.param(self.w)), plan.param(self.b), self._p3,
-                                   self.activation_func, plan.out[self])
+            nx = bf16_ahead.next_image(plan, self)
+            if nx is not None:            # bf16 mode: + the next conv's channels-last input image
+                ctx.conv1_pool_act_fwd_bf16(x, self._w5(plan.param(self.w)), plan.param(self.b),
+                                            self._p3, self.activation_func, plan.out[self], nx[0], nx[1])
+                plan._xb_ready[nx[2]] = True
+            else:
+                ctx.conv1_pool_act_fwd(x, self._w5(plan.param(self.w)), plan.param(self.b), self._p3,
+                                       self.activation_func, plan.out[self])
             return
         if self._tail(plan) is not None:
             return                            # done by the NLL node (csrc/tail.hip)

@@ -560,6 +560,10 @@ int e2_pool_bias_act_bwd_bf16(e2_ctx*, const e2_tensor5* dout, int64_t part_stri
 int e2_pool_bias_act_fwd_bf16(e2_ctx*, const e2_tensor5* y, int64_t part_stride, int parts,
                               const float* bias, int pz, int py, int px, int act,
                               const e2_tensor5* out, const e2_bf16_dst* dst);
+/* e2_conv1_pool_act_fwd writing also the channels-last bf16 copy of out (cout <= 32) */
+int e2_conv1_pool_act_fwd_bf16(e2_ctx*, const e2_tensor5* x, const float* w, const float* bias,
+                               int cout, int kh, int kw, int py, int px, int act,
+                               const e2_tensor5* out, void* next_xb, int next_kg);
 /* The filter rows of a launch, packed ahead of it for the tile "32,mb,nb" (mode 0: forward
  * image of w (nf, nin, kd, kh, kw), rows = nf; mode 1: data-gradient image, rows = nin); in_w /
  * out_w: the row lengths of the GEMM's input and output (forward: x and y; data gradient: the

@@ -515,3 +515,25 @@ def test_step_with_operands_made_ahead_equals_the_converting_step(process_bf16, 
     np.testing.assert_allclose(l1, l0, rtol=2e-5)
     for a, b in zip(p1, p0):
         assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30) + 1e-7
+
+
+@pytest.mark.parametrize("k,pool,cout,sp", [((1, 4, 4), (1, 2, 2), 20, (3, 35, 73)), ((1, 6, 6), (1, 2, 2), 20, (2, 37, 41)),
+                                            ((1, 3, 3), (1, 1, 1), 32, (2, 20, 70)), ((1, 4, 4), (1, 2, 2), 7, (1, 19, 23))])
+def test_first_layer_writes_the_next_layers_input_image(ctx, k, pool, cout, sp):
+    """e2_conv1_pool_act_fwd_bf16: the fused first layer (conv + pool + bias + relu on the matrix
+    cores) with the next conv's channels-last bf16 image as a second output: the f32 output is
+    bit-identical to e2_conv1_pool_act_fwd's, the image to torch's bf16 rounding of it"""
+    rng = np.random.RandomState(cout)
+    N = 2
+    x = dev(rng.rand(N, 1, *sp))
+    w = dev(rng.randn(cout, 1, *k) / 4)
+    b = dev(rng.randn(cout) * 0.1)
+    osp = (sp[0], (sp[1] - k[1] + 1) // pool[1], (sp[2] - k[2] + 1) // pool[2])
+    ref = torch.full((N, cout) + osp, float("nan"), device="cuda")
+    ctx.conv1_pool_act_fwd(x, w, b, pool, 'relu', ref)
+    kg = (cout + 15) // 16 * 2
+    nxt = torch.zeros(N * osp[0] * kg * osp[1] * osp[2] * 16 + 512, dtype=torch.uint8, device="cuda")
+    out = torch.full((N, cout) + osp, float("nan"), device="cuda")
+    ctx.conv1_pool_act_fwd_bf16(x, w, b, pool, 'relu', out, nxt, kg)
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert _same_bits(nxt, _cl_image(ref))
