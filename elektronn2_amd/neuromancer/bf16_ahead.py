@@ -25,6 +25,7 @@ from .. import autotune, backend
 
 import os
 _WGRAD_ONLY = os.environ.get("E2_BF16_AHEAD_WGRAD_ONLY", "0") == "1"
+_MIN_SHARE = float(os.environ.get("E2_BF16_AHEAD_MIN", "0.6"))
 
 
 def _known(plan, kind, sig):
@@ -57,6 +58,29 @@ def prepare(plan):
     if getattr(ctx, 'mfma_dtype', 'f32') != 'bf16' or not plan._bf16_ahead_on:
         return
     a = plan.bf16a
+    if not a:
+        # engage once every launch's tiling is known, and only where the kernels with bf16
+        # operands in memory carry most of the GEMM launches: neuro3d_lite@183 (11 of 13) gains
+        # 5 %, neuro3d@185 (11 of 25: its small late layers run the operand-rounding kernels on
+        # f32 tensors) loses 1-2 % to the extra stores of the producers (measured)
+        mem = tot = 0
+        for node in conv_nodes(plan):
+            if not eligible(plan, node) or plan.out[node.parent] is None:
+                continue
+            sigs = [('igemm', node._sig_fwd(plan))]
+            if plan.training and (node, 'dy') in plan.scratch and (node, 'dy_pad') in plan.scratch:
+                sigs.append(('wgrad', node._sig_wgrad(plan)))
+                if plan.needs_grad(node.parent):
+                    sigs.append(('igemm', node._sig_dgrad(plan)))
+            for kind, sig in sigs:
+                t = _known(plan, kind, sig)
+                if t is None:
+                    return                    # (not tuned yet: after the first eager step)
+                tot += 1
+                mem += t.startswith('32,')
+        if tot == 0 or mem < _MIN_SHARE * tot:
+            plan._bf16_ahead_on = False
+            return
     new_jobs = False
     for node in conv_nodes(plan):
         if not eligible(plan, node):
