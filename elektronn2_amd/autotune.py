@@ -251,7 +251,37 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
                             # the same launch in the XCD-grouped block order (balanced for any
                             # group count: csrc/conv_wgrad_direct.hip)
                             cands.append("%d,%d,%d,%d,%d" % (mt, nt, wk + 100, bp, q))
-    return sorted(set(cands) | set(pointwise_wgrad_candidates(cout, cin, k, out_sp, n_cu)))
+    return sorted(set(cands) | set(pointwise_wgrad_candidates(cout, cin, k, out_sp, n_cu))
+                  | set(position_split_wgrad_candidates(cout, cin, k, out_sp, n_cu)))
+
+
+WGRAD_KS_TILES = [(13, 2), (10, 2), (7, 2), (7, 4), (5, 4), (4, 4), (3, 4), (2, 4)]
+
+
+def position_split_wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
+    """"MT,NT,9,0,S": the weight gradient of a kernel WITH taps as the K-contiguous GEMM of
+    csrc/conv_pw_wgrad.hip -- one 16 MT x 16 NT tile of dW (cout x cin * taps) per work-group, its
+    four waves split the positions of the gradient planes; needs (kh - 1) input rows >= 31 zeros
+    behind a plane of the padded gradient (the library refuses otherwise: the tuner skips it)"""
+    T = k[0] * k[1] * k[2]
+    if T == 1 or cout < 24:
+        return []
+    pitch = out_sp[2] + k[2] - 1
+    if (k[1] - 1) * pitch + k[2] - 1 < 31:
+        return []
+    units = out_sp[0] * (-(-((out_sp[1] - 1) * pitch + out_sp[2]) // 32))
+    scored = []
+    for mt, nt in WGRAD_KS_TILES:
+        nm, nn = -(-cout // (16 * mt)), -(-(cin * T) // (16 * nt))
+        eff = (cout * cin * T) / float(nm * 16 * mt * nn * 16 * nt)
+        scored.append((-eff, -mt * nt, mt, nt, nm * nn))
+    scored.sort()
+    out = []
+    for _, _, mt, nt, tiles in scored[:3]:
+        for fill in (0.5, 1, 2):
+            s = max(1, min(-(-units // 4), int(n_cu * fill) // tiles))
+            out.append("%d,%d,9,0,%d" % (mt, nt, s))
+    return sorted(set(out))
 
 
 PW_WGRAD_KS_TILES = [(13, 2), (10, 2), (7, 2), (7, 4), (4, 4)]

@@ -151,6 +151,7 @@ int e2i_wgrad_direct_lpad(const WgradArgs& a, int BP);
 // conv_pw_wgrad.hip: 1x1x1 / UpConv weight gradient as a GEMM with K-contiguous operands
 int e2i_pw_wgrad(e2_ctx*, const WgradArgs& a, int MT, int NT, int S);
 int e2i_pw_wgrad_ks(e2_ctx*, const WgradArgs& a, int MT, int NT, int S);
+int e2i_wgrad_ks(e2_ctx*, const WgradArgs& a, int MT, int NT, int S);     // the same for kernels with taps
 size_t e2i_wgrad_direct_buf_floats(const WgradArgs& a, int NT, int BP, int WK);
 
 // view helpers (pointwise.hip)

@@ -46,6 +46,11 @@ struct PgP {
   int nMT, nNT, S;
   int stepsPerSample, steps, per;                  // 16-position steps: per sample, total, per split
   int rem;                                         // (position-split waves) K % 32
+  // (position-split waves, kernels with taps) a unit belongs to plane z of sample n; column j of
+  // the GEMM is (input channel j / T, tap j % T) and reads the channel's plane at the tap's shift
+  int T, kh, kw, flip, planes;                     // taps, kernel rows / cols, planes per sample
+  long asZ, bsZ, bsY;                              // plane strides of dy / x, row stride of x
+  long bLim;                                       // floats of one channel's volume in x (loads stay inside)
   unsigned long long* stamps;                      // debug build (E2_PWKS_STAMPS): 8 s_memtime stamps per work-group
 };
 
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(PgP p) {
 // float4 of the NEXT unit are requested right after block mb's MFMAs of this unit, so every
 // load has a whole unit (13 x 2 x 8 MFMAs = 2.8 us) to arrive -- B double-buffered.  Units are
 // WHOLE; the K % 32 last positions of the samples are a masked step of the last range's work-groups.
-template <int MT, int NT>
+template <int MT, int NT, bool TAPS>
 __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   extern __shared__ float red[];
   constexpr int RW = 16 * NT + 4;                    // padded row of a wave's partial tile
@@ -195,10 +200,26 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   // BYTE offsets of the lane's rows inside a sample (32 bits: checked by the host), so that a
   // load is "scalar sample base + vector offset"
   unsigned aoff[MT], boff[NT];
+  unsigned bend[NT];                                 // (TAPS) last byte offset a load of the row may start at
 #pragma unroll
   for (int mb = 0; mb < MT; ++mb) aoff[mb] = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC * 4u + 16u * q;
 #pragma unroll
-  for (int nb = 0; nb < NT; ++nb) boff[nb] = (unsigned)min(n0 + 16 * nb + l15, p.Ncol - 1) * (unsigned)p.bsC * 4u + 16u * q;
+  for (int nb = 0; nb < NT; ++nb) {
+    const int j = min(n0 + 16 * nb + l15, p.Ncol - 1);
+    if (TAPS) {
+      // column j = (input channel, tap as stored); the tap's shift inside the channel's volume
+      const int ci = j / p.T, ts = j - ci * p.T;
+      const int t = p.flip ? p.T - 1 - ts : ts;
+      const int tz = t / (p.kh * p.kw), r2 = t - tz * (p.kh * p.kw);
+      const int ty = r2 / p.kw, tx = r2 - ty * p.kw;
+      const unsigned row = (unsigned)ci * (unsigned)p.bsC * 4u;
+      boff[nb] = row + (unsigned)(tz * p.bsZ + ty * p.bsY + tx) * 4u + 16u * q;
+      bend[nb] = row + (unsigned)p.bLim * 4u - 80u;  // (a unit's two loads: 16 bytes at +0 and +64)
+    } else {
+      boff[nb] = (unsigned)j * (unsigned)p.bsC * 4u + 16u * q;
+      bend[nb] = 0;
+    }
+  }
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -207,12 +228,26 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // unit i of this wave (WHOLE 32-position units only): sample bases and byte offset of the unit
-  auto where = [&](int i, const char*& ap, const char*& bp, unsigned& kb) {
+  // (TAPS: units of a PLANE; zb = byte offset of the plane inside the sample's x, which the
+  // B loads add to their row offsets and clamp against the end of the channel's volume: a unit
+  // may run past the end of its plane -- dy holds zeros there, x must only stay readable)
+  auto where = [&](int i, const char*& ap, const char*& bp, unsigned& kb, unsigned& zb) {
     const int u = u0 + 4 * i;
-    const int n = u / p.stepsPerSample;
-    ap = reinterpret_cast<const char*>(p.a + (long)n * p.asN);
-    bp = reinterpret_cast<const char*>(p.b + (long)n * p.bsN);
-    kb = (unsigned)(u - n * p.stepsPerSample) * 128u;
+    const int pl = u / p.stepsPerSample;
+    kb = (unsigned)(u - pl * p.stepsPerSample) * 128u;
+    if (TAPS) {
+      const int n = pl / p.planes, z = pl - n * p.planes;
+      ap = reinterpret_cast<const char*>(p.a + (long)n * p.asN + (long)z * p.asZ);
+      bp = reinterpret_cast<const char*>(p.b + (long)n * p.bsN);
+      zb = (unsigned)(z * p.bsZ) * 4u;
+    } else {
+      ap = reinterpret_cast<const char*>(p.a + (long)pl * p.asN);
+      bp = reinterpret_cast<const char*>(p.b + (long)pl * p.bsN);
+      zb = 0;
+    }
+  };
+  auto bo = [&](int nb, unsigned kb, unsigned zb) -> unsigned {
+    return TAPS ? min(boff[nb] + zb + kb, bend[nb]) : boff[nb] + kb;
   };
   auto load2 = [&](f32x4 (&d)[2], const char* base, unsigned off) {
     const char* r = base + off;                      // (4-byte aligned only: rows need not be 16-byte aligned)
@@ -223,10 +258,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   if (cnt > 0) {
     f32x4 A[MT][2], Bc[NT][2], Bn[NT][2];
     const char *ap, *bp;
-    unsigned kb;
-    where(0, ap, bp, kb);
+    unsigned kb, zb;
+    where(0, ap, bp, kb, zb);
 #pragma unroll
-    for (int nb = 0; nb < NT; ++nb) load2(Bc[nb], bp, boff[nb] + kb);
+    for (int nb = 0; nb < NT; ++nb) load2(Bc[nb], bp, bo(nb, kb, zb));
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb) load2(A[mb], ap, aoff[mb] + kb);
     KS_STAMP(1);
@@ -234,9 +269,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     // again -- L1 / L2 hits, nothing waits for them
 #pragma unroll 1
     for (int i = 0; i < cnt; ++i) {
-      where(min(i + 1, cnt - 1), ap, bp, kb);
+      where(min(i + 1, cnt - 1), ap, bp, kb, zb);
 #pragma unroll
-      for (int nb = 0; nb < NT; ++nb) load2(Bn[nb], bp, boff[nb] + kb);
+      for (int nb = 0; nb < NT; ++nb) load2(Bn[nb], bp, bo(nb, kb, zb));
 #pragma unroll
       for (int mb = 0; mb < MT; ++mb) {
 #pragma unroll
@@ -260,7 +295,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   // ---- the K % 32 last positions of every sample: one masked step of the work-groups of the LAST
   // position range (the shortest one: per is rounded up).  Wave w takes the row blocks w, w + 4,
   // ...; every load is a clamped dword + select (no branches: all of them are in flight at once)
-  if (sp == p.S - 1 && p.rem > 0) {
+  if (!TAPS && sp == p.S - 1 && p.rem > 0) {
     constexpr int MBW = (MT + 3) / 4;
     const int k = p.K - p.rem + 4 * q;
 #pragma unroll 1
@@ -319,12 +354,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
 #endif
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool TAPS = false>
 int launch_ks(e2_ctx* ctx, const PgP& p, long grid) {
   const int lds = 4 * 16 * MT * (16 * NT + 4) * (int)sizeof(float);
   static bool raised = false;                        // (one device per process: plan.py get_ctx)
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_ks_kernel<MT, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_wgrad_ks_kernel<MT, NT, TAPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) { e2_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return 1; }
     raised = true;
@@ -337,7 +372,7 @@ int launch_ks(e2_ctx* ctx, const PgP& p, long grid) {
     E2_CHECK_HIP(hipMalloc(&ps.stamps, sizeof(unsigned long long) * 8 * grid));
     E2_CHECK_HIP(hipMemsetAsync(ps.stamps, 0, sizeof(unsigned long long) * 8 * grid, ctx->stream));
   }
-  hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, ps);
+  hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT, TAPS>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, ps);
   E2_CHECK_HIP(hipGetLastError());
   if (stamps) {
     E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -359,7 +394,7 @@ int launch_ks(e2_ctx* ctx, const PgP& p, long grid) {
     (void)hipFree(ps.stamps);
   }
 #else
-  hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
+  hipLaunchKernelGGL((pw_wgrad_ks_kernel<MT, NT, TAPS>), dim3((unsigned)grid), dim3(256), lds, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
 #endif
   return 0;
@@ -391,6 +426,7 @@ int e2i_pw_wgrad(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.nMT = e2_cdiv(a.Cout, 32 * MT);
   p.nNT = e2_cdiv(a.Cin, 32 * NT);
   p.rem = 0; p.stamps = nullptr;
+  p.T = 1; p.kh = p.kw = 1; p.flip = 0; p.planes = 1; p.asZ = p.bsZ = p.bsY = 0; p.bLim = 0;
   p.stepsPerSample = (int)((K + 15) / 16);
   const long steps = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(steps < (1L << 30), "pointwise wgrad: too many positions");
@@ -431,6 +467,7 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.nNT = e2_cdiv(a.Cin, 16 * NT);
   p.stepsPerSample = (int)(K / 32);                  // (here: WHOLE 32-position units)
   p.rem = (int)(K % 32); p.stamps = nullptr;
+  p.T = 1; p.kh = p.kw = 1; p.flip = 0; p.planes = 1; p.asZ = p.bsZ = p.bsY = 0; p.bLim = 0;
   const long units = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(units < (1L << 29), "pointwise wgrad: too many positions");
   p.steps = (int)units;
@@ -447,5 +484,60 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   E2_L(13, 2) E2_L(7, 2) E2_L(7, 4) E2_L(4, 4) E2_L(10, 2)
 #undef E2_L
   e2_set_error("pointwise wgrad (position-split waves): no instance MT=%d NT=%d", MT, NT);
+  return 2;
+}
+
+// "MT,NT,9,0,S": the SAME kernel for a conv with taps (T = kd * kh * kw > 1).  dy lives in the
+// interior of its zero-padded buffer at the INPUT's row pitch (WgradArgs.dy_padded), so over the
+// memory span of a plane -- K = (Ho - 1) * pitch + Wo positions, zeros in the kw - 1 gap columns
+// -- tap (tz, ty, tx) of input channel ci is the channel's plane read at the constant shift
+// tz * plane + ty * pitch + tx: every column (ci, tap) of dW (Cout x Cin * T, the weight tensor's
+// own layout) is a K-contiguous row, and the 1x1x1 GEMM above applies with per-lane row offsets.
+// Units are whole: one that runs past the end of its plane multiplies dy's zero border ((kh - 1)
+// rows >= 31 positions: required) with whatever x holds there -- x loads are clamped to the
+// channel's volume, nothing outside the tensor is read.
+int e2i_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
+  const int T = a.kd * a.kh * a.kw;
+  E2_REQUIRE(T > 1 && a.upR <= 1, "wgrad (position-split GEMM): a conv kernel with taps");
+  E2_REQUIRE(a.dy_padded, "wgrad (position-split GEMM): dy must be the interior of its zero-padded buffer");
+  E2_REQUIRE(a.dsY == a.xsY, "wgrad (position-split GEMM): dy rows at the input's pitch (%ld vs %ld)", (long)a.dsY, (long)a.xsY);
+  E2_REQUIRE((a.kh - 1) * a.xsY + (a.kw - 1) >= 31, "wgrad (position-split GEMM): %d x %d kernel rows of %ld leave fewer than 31 zeros behind a plane",
+             a.kh, a.kw, (long)a.xsY);
+  E2_REQUIRE(!ctx->mfma_bf16, "wgrad (position-split GEMM): an f32 kernel, not offered in bf16 mode");
+  const int Din = a.Do + a.kd - 1, Hin = a.Ho + a.kh - 1;
+  E2_REQUIRE(a.xsZ >= (int64_t)Hin * a.xsY && a.xsC >= (int64_t)Din * a.xsZ, "wgrad (position-split GEMM): x planes / channels overlap");
+  PgP p;
+  p.a = a.dy; p.b = a.x; p.c = a.dw;
+  p.asN = a.dsN; p.asC = a.dsC; p.bsN = a.xsN; p.bsC = a.xsC;
+  p.N = a.N; p.M = a.Cout; p.Ncol = a.Cin * T;
+  const long K = (long)(a.Ho - 1) * a.dsY + a.Wo;             // memory span of a gradient plane
+  E2_REQUIRE(K >= 4 && K < (1L << 28), "wgrad (position-split GEMM): plane of %ld positions", K);
+  E2_REQUIRE(((long)a.Cout * a.dsC + (long)a.Do * a.dsZ + K) * 4 + 256 < (1L << 32) &&
+                 ((long)a.Cin * a.xsC + (long)Din * a.xsZ) * 4 + 256 < (1L << 32) && a.dsC >= 0 && a.xsC >= 0,
+             "wgrad (position-split GEMM): sample too large for 32-bit byte offsets");
+  p.K = (int)K; p.R = 1; p.rem = 0; p.stamps = nullptr;
+  p.T = T; p.kh = a.kh; p.kw = a.kw; p.flip = a.flip; p.planes = a.Do;
+  p.asZ = a.dsZ; p.bsZ = a.xsZ; p.bsY = a.xsY;
+  p.bLim = (long)Din * a.xsZ;                                  // (>= the shifted reads of the last unit: clamped)
+  E2_REQUIRE(p.bLim >= 64, "wgrad (position-split GEMM): input volume too small");
+  p.nMT = e2_cdiv(a.Cout, 16 * MT);
+  p.nNT = e2_cdiv(p.Ncol, 16 * NT);
+  p.stepsPerSample = (int)((K + 31) / 32);                    // (whole units of a PLANE)
+  const long units = (long)a.N * a.Do * p.stepsPerSample;
+  E2_REQUIRE(units < (1L << 29), "wgrad (position-split GEMM): too many positions");
+  p.steps = (int)units;
+  S = (int)std::max<long>(1, std::min<long>(S, std::max<long>(1, (units + 3) / 4)));
+  p.per = (int)std::max<long>(1, (units + S - 1) / S);
+  p.per = (p.per + 3) & ~3;
+  p.S = (int)std::max<long>(1, (units + p.per - 1) / p.per);
+  long grid = (long)p.nMT * p.nNT * p.S;
+  grid = (grid + 7) & ~7L;
+  E2_REQUIRE(grid < (1L << 31), "wgrad (position-split GEMM): grid too large");
+  if (!a.accumulate)
+    if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.Ncol, 0.f)) return rc;
+#define E2_L(M, N_) if (MT == M && NT == N_) return launch_ks<M, N_, true>(ctx, p, grid);
+  E2_L(13, 2) E2_L(7, 2) E2_L(7, 4) E2_L(4, 4) E2_L(10, 2) E2_L(5, 4) E2_L(3, 4) E2_L(2, 4)
+#undef E2_L
+  e2_set_error("wgrad (position-split GEMM): no instance MT=%d NT=%d", MT, NT);
   return 2;
 }

@@ -464,7 +464,12 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
       const bool pw_ok = a.kd == 1 && a.kh == 1 && a.kw == 1 && a.xsY == a.Wo &&
                          a.xsZ == (int64_t)a.Ho * a.Wo && a.dsY == a.Wo &&
                          a.dsZ == (int64_t)a.Ho * a.Wo && !ctx->mfma_bf16;
-      if ((f.WK != 7 && f.WK != 8) || pw_ok) { *ok = 1; return f; }
+      // "MT,NT,9,0,S": the same GEMM for kernels with taps; needs the padded gradient at the
+      // input's row pitch and a zero border of >= 31 positions behind a plane
+      const bool ks_ok = a.dy_padded && a.kd * a.kh * a.kw > 1 && a.upR <= 1 && a.dsY == a.xsY &&
+                         (a.kh - 1) * a.xsY + (a.kw - 1) >= 31 && !ctx->mfma_bf16;
+      if (f.WK == 9) { if (ks_ok) { *ok = 1; return f; } }
+      else if ((f.WK != 7 && f.WK != 8) || pw_ok) { *ok = 1; return f; }
     }
   }
   if (a.dy_padded && nblocks > 2) {
@@ -564,6 +569,9 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   // WK 8 ("MT,NT,8,0,S"): the same GEMM, one 16 MT x 16 NT tile per work-group whose four waves split the positions
   if (c.WK == 7) return e2i_pw_wgrad(ctx, a, c.MT, c.NT, c.PS);
   if (c.WK == 8) return e2i_pw_wgrad_ks(ctx, a, c.MT, c.NT, c.PS);
+  // WK 9 ("MT,NT,9,0,S"): that GEMM for kernels WITH taps -- every (input channel, tap) column of dW is
+  // a K-contiguous row of x at the tap's shift (needs the padded gradient at the input's row pitch)
+  if (c.WK == 9) return e2i_wgrad_ks(ctx, a, c.MT, c.NT, c.PS);
   if (a.dy_padded && (c.WK == 1 || c.WK == 14 || c.WK == 101 || c.WK == 114) && (c.BP == 128 || c.BP == 256))
     return e2i_wgrad_direct(ctx, a, c.MT, c.NT, c.BP, c.PS, (c.WK % 100) == 14 ? 4 : 1, c.WK >= 100);
   E2_REQUIRE(c.WK != 14 && c.WK < 100, "wgrad: WK=14/101/114 need the padded-gradient entry point and BP 128/256");

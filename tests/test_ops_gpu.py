@@ -496,6 +496,59 @@ def test_wgrad_pad_with_the_librarys_own_tiling(ctx, ci, co, k):
     assert relerr(dw, dw_ref) < TOL
 
 
+def _plan_style_padded(dy, k):
+    """the zero-padded gradient buffer as the launch plan lays it out (neuromancer/neural.py Conv
+    _plan_alloc): rows OVERLAP -- the row pitch is the layer INPUT's width Wo + kw - 1"""
+    N, C = dy.shape[:2]
+    osp = dy.shape[2:]
+    pad = [kk - 1 for kk in k]
+    pshape = (N, C) + tuple(osp[i] + 2 * pad[i] for i in range(3))
+    pitch = osp[2] + pad[2]
+    plane = pshape[3] * pitch
+    flat = torch.zeros(N * C * pshape[2] * plane + pad[2] + 32, device="cuda")
+    flat[-32:] = float("nan")              # the slack may be read, never used
+    dyp = flat.as_strided(pshape, (C * pshape[2] * plane, pshape[2] * plane, plane, pitch, 1))
+    dyp[:, :, pad[0]:pad[0] + osp[0], pad[1]:pad[1] + osp[1], pad[2]:pad[2] + osp[2]] = dev(dy)
+    return dyp
+
+
+@pytest.mark.parametrize("force", ["13,2,9,0,1", "13,2,9,0,4", "7,2,9,0,3", "7,4,9,0,100000", "4,4,9,0,2",
+                                   "10,2,9,0,5", "5,4,9,0,2", "3,4,9,0,7", "2,4,9,0,1"])
+@pytest.mark.parametrize("ci,co,k,sp", [(9, 100, (2, 3, 3), (4, 12, 21)), (40, 200, (1, 3, 3), (3, 11, 23)),
+                                        (20, 37, (3, 3, 3), (5, 9, 18)), (33, 150, (2, 4, 4), (3, 14, 17)),
+                                        (7, 30, (1, 5, 5), (2, 13, 16))])
+def test_conv3d_wgrad_as_position_split_gemm(ctx, force, ci, co, k, sp):
+    """csrc/conv_pw_wgrad.hip, "MT,NT,9,0,S": the weight gradient of a conv WITH taps as the
+    K-contiguous GEMM of the 1x1x1 layers -- over the memory span of a gradient plane (dy at the
+    input's row pitch, zeros in the gaps) every (input channel, tap) column of dW reads the
+    channel's plane at a constant shift.  Units that run past the end of a plane (zeros of the
+    border x anything readable), two samples, kd > 1, flipped tap order, channel counts off the
+    tile sizes, one split to more splits than units, overwrite and accumulate; x as a channel slice
+    of a wider tensor."""
+    rng = np.random.RandomState(ci + co)
+    N = 2
+    x = rng.rand(N, ci, *sp).astype(np.float32)
+    w = (rng.randn(co, ci, *k) / 8).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dw_ref = O.conv3d_wgrad(dy, x, w.shape)
+    dyp = _plan_style_padded(dy, k)
+    dw = torch.full(w.shape, float("nan"), device="cuda")
+    ctx.set_tiling("wgrad", force)
+    try:
+        ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
+        assert relerr(dw, dw_ref) < TOL
+        ctx.conv3d_wgrad_pad(dev(x), dyp, dw, accumulate=True)
+        assert relerr(dw, 2 * dw_ref) < TOL
+        wide = torch.full((N, ci + 4) + tuple(sp), float("nan"), device="cuda")
+        wide[:, 1:1 + ci] = dev(x)
+        dw.fill_(float("nan"))
+        ctx.conv3d_wgrad_pad(wide[:, 1:1 + ci], dyp, dw)
+        assert relerr(dw, dw_ref) < TOL
+    finally:
+        ctx.set_tiling("wgrad", None)
+
+
 @pytest.mark.parametrize("force", ["1,1,1,128,3", "2,2,1,256,5", "3,4,1,128,2", "4,1,1,256,7",
                                    "5,2,1,128,1", "7,2,1,128,3", "7,2,1,256,2", "7,1,1,128,40",
                                    "7,2,101,128,8", "2,2,101,256,2", "3,2,114,128,8", "1,1,101,128,8",
