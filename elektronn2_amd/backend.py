@@ -145,6 +145,7 @@ def _load():
         "e2_malis_nll": (C.c_int, [vp, P5, fp, fp, fp, P5, fp]),
         "e2_fill_multi": (C.c_int, [vp, vp, vp, C.c_int, C.c_float]),
         "e2_set_skip_zero_fill": (C.c_int, [vp, C.c_int]),
+        "e2_set_input_slack": (C.c_int, [vp, C.c_int]),
         "e2_conv_last_zero_fill": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
         "e2_set_tiling": (C.c_int, [vp, C.c_int, C.c_char_p]),
@@ -686,6 +687,11 @@ class Context:
 
     def bf16_memory_wgrad(self):
         return getattr(self, '_tiling', {}).get('wgrad', '').startswith('32,')
+
+    def set_input_slack(self, nbytes):
+        """promise (or, 0, withdraw the promise) that the x of the conv launches that follow has
+        nbytes readable finite bytes behind its last element (e2_set_input_slack)"""
+        _chk(_lib.e2_set_input_slack(self.h, int(nbytes)), "e2_set_input_slack")
 
     def current_tiling(self, kind):
         """the tiling string in force for kind ('igemm' | 'wgrad'), '' when none is pinned"""

@@ -50,6 +50,7 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->skip_zero_fill = 0;
   c->loss_sum_mode = 0;
   c->loss_count_out = nullptr;
+  c->input_slack = 0;
   c->last_fill_ptr = nullptr;
   c->last_fill_n = 0;
   c->tiling[0][0] = c->tiling[1][0] = 0;
@@ -73,6 +74,17 @@ extern "C" int e2_set_loss_grad_mode(e2_ctx* ctx, int sum_mode, float* count_out
   E2_REQUIRE(ctx, "set_loss_grad_mode: null context");
   ctx->loss_sum_mode = sum_mode ? 1 : 0;
   ctx->loss_count_out = count_out;
+  return 0;
+}
+
+/* The caller vouches that the input tensor x of the conv launches that follow is followed by at
+ * least `bytes` readable bytes holding FINITE values (its own allocation's zeroed slack, or more
+ * of the buffer a view was cut from): the weight gradient "MT,NT,9,0,S" lets the last 32-position
+ * unit of a plane run past the plane's end -- the gradient's zero border times whatever x holds
+ * there -- and is offered only with >= 128.  0 (the default) withdraws the promise. */
+extern "C" int e2_set_input_slack(e2_ctx* ctx, int bytes) {
+  E2_REQUIRE(ctx && bytes >= 0, "e2_set_input_slack: bad argument");
+  ctx->input_slack = bytes;
   return 0;
 }
 

@@ -22,6 +22,7 @@ struct e2_ctx {
   char tiling[2][64];       // e2_set_tiling: forced tiling of the igemm / wgrad launches ("" = cost model)
   int loss_sum_mode;        // e2_set_loss_grad_mode: 1 = NLL gradients are NOT divided by the labelled count
   float* loss_count_out;    // ... and the count is also written here (the slot behind the gradient arena)
+  int input_slack;          // e2_set_input_slack: finite readable bytes behind the x of the launches that follow
 };
 
 // Debug switches (timing ablations, in-kernel stamps, verbose launch log) are compiled in

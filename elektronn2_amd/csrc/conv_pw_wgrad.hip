@@ -50,7 +50,6 @@ struct PgP {
   // the GEMM is (input channel j / T, tap j % T) and reads the channel's plane at the tap's shift
   int T, kh, kw, flip, planes;                     // taps, kernel rows / cols, planes per sample
   long asZ, bsZ, bsY;                              // plane strides of dy / x, row stride of x
-  long bLim;                                       // floats of one channel's volume in x (loads stay inside)
   unsigned long long* stamps;                      // debug build (E2_PWKS_STAMPS): 8 s_memtime stamps per work-group
 };
 
@@ -200,7 +199,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
   // BYTE offsets of the lane's rows inside a sample (32 bits: checked by the host), so that a
   // load is "scalar sample base + vector offset"
   unsigned aoff[MT], boff[NT];
-  unsigned bend[NT];                                 // (TAPS) last byte offset a load of the row may start at
 #pragma unroll
   for (int mb = 0; mb < MT; ++mb) aoff[mb] = (unsigned)min(m0 + 16 * mb + l15, p.M - 1) * (unsigned)p.asC * 4u + 16u * q;
 #pragma unroll
@@ -214,10 +212,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
       const int ty = r2 / p.kw, tx = r2 - ty * p.kw;
       const unsigned row = (unsigned)ci * (unsigned)p.bsC * 4u;
       boff[nb] = row + (unsigned)(tz * p.bsZ + ty * p.bsY + tx) * 4u + 16u * q;
-      bend[nb] = row + (unsigned)p.bLim * 4u - 80u;  // (a unit's two loads: 16 bytes at +0 and +64)
     } else {
       boff[nb] = (unsigned)j * (unsigned)p.bsC * 4u + 16u * q;
-      bend[nb] = 0;
     }
   }
 
@@ -228,9 +224,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // unit i of this wave (WHOLE 32-position units only): sample bases and byte offset of the unit
-  // (TAPS: units of a PLANE; zb = byte offset of the plane inside the sample's x, which the
-  // B loads add to their row offsets and clamp against the end of the channel's volume: a unit
-  // may run past the end of its plane -- dy holds zeros there, x must only stay readable)
+  // (TAPS: units of a PLANE; zb = byte offset of the plane inside the sample's x.  A unit may run
+  // past the end of its plane: dy holds zeros there -- its border -- and x whatever follows, up to
+  // 124 bytes behind the tensor for the last plane of the last channel: e2_set_input_slack)
   auto where = [&](int i, const char*& ap, const char*& bp, unsigned& kb, unsigned& zb) {
     const int u = u0 + 4 * i;
     const int pl = u / p.stepsPerSample;
@@ -247,7 +243,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_ks_kernel(PgP p) {
     }
   };
   auto bo = [&](int nb, unsigned kb, unsigned zb) -> unsigned {
-    return TAPS ? min(boff[nb] + zb + kb, bend[nb]) : boff[nb] + kb;
+    return TAPS ? boff[nb] + zb + kb : boff[nb] + kb;
   };
   auto load2 = [&](f32x4 (&d)[2], const char* base, unsigned off) {
     const char* r = base + off;                      // (4-byte aligned only: rows need not be 16-byte aligned)
@@ -426,7 +422,7 @@ int e2i_pw_wgrad(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.nMT = e2_cdiv(a.Cout, 32 * MT);
   p.nNT = e2_cdiv(a.Cin, 32 * NT);
   p.rem = 0; p.stamps = nullptr;
-  p.T = 1; p.kh = p.kw = 1; p.flip = 0; p.planes = 1; p.asZ = p.bsZ = p.bsY = 0; p.bLim = 0;
+  p.T = 1; p.kh = p.kw = 1; p.flip = 0; p.planes = 1; p.asZ = p.bsZ = p.bsY = 0;
   p.stepsPerSample = (int)((K + 15) / 16);
   const long steps = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(steps < (1L << 30), "pointwise wgrad: too many positions");
@@ -467,7 +463,7 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.nNT = e2_cdiv(a.Cin, 16 * NT);
   p.stepsPerSample = (int)(K / 32);                  // (here: WHOLE 32-position units)
   p.rem = (int)(K % 32); p.stamps = nullptr;
-  p.T = 1; p.kh = p.kw = 1; p.flip = 0; p.planes = 1; p.asZ = p.bsZ = p.bsY = 0; p.bLim = 0;
+  p.T = 1; p.kh = p.kw = 1; p.flip = 0; p.planes = 1; p.asZ = p.bsZ = p.bsY = 0;
   const long units = (long)a.N * p.stepsPerSample;
   E2_REQUIRE(units < (1L << 29), "pointwise wgrad: too many positions");
   p.steps = (int)units;
@@ -494,8 +490,8 @@ int e2i_pw_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
 // tz * plane + ty * pitch + tx: every column (ci, tap) of dW (Cout x Cin * T, the weight tensor's
 // own layout) is a K-contiguous row, and the 1x1x1 GEMM above applies with per-lane row offsets.
 // Units are whole: one that runs past the end of its plane multiplies dy's zero border ((kh - 1)
-// rows >= 31 positions: required) with whatever x holds there -- x loads are clamped to the
-// channel's volume, nothing outside the tensor is read.
+// rows >= 31 positions: required) with whatever x holds there -- the next plane / channel / sample,
+// or up to 124 bytes behind the tensor, which the caller vouches for (e2_set_input_slack).
 int e2i_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   const int T = a.kd * a.kh * a.kw;
   E2_REQUIRE(T > 1 && a.upR <= 1, "wgrad (position-split GEMM): a conv kernel with taps");
@@ -518,8 +514,7 @@ int e2i_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.K = (int)K; p.R = 1; p.rem = 0; p.stamps = nullptr;
   p.T = T; p.kh = a.kh; p.kw = a.kw; p.flip = a.flip; p.planes = a.Do;
   p.asZ = a.dsZ; p.bsZ = a.xsZ; p.bsY = a.xsY;
-  p.bLim = (long)Din * a.xsZ;                                  // (>= the shifted reads of the last unit: clamped)
-  E2_REQUIRE(p.bLim >= 64, "wgrad (position-split GEMM): input volume too small");
+  E2_REQUIRE(ctx->input_slack >= 128, "wgrad (position-split GEMM): needs e2_set_input_slack(ctx, >= 128)");
   p.nMT = e2_cdiv(a.Cout, 16 * MT);
   p.nNT = e2_cdiv(p.Ncol, 16 * NT);
   p.stepsPerSample = (int)((K + 31) / 32);                    // (whole units of a PLANE)

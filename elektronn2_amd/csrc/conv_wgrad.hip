@@ -467,7 +467,8 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
       // "MT,NT,9,0,S": the same GEMM for kernels with taps; needs the padded gradient at the
       // input's row pitch and a zero border of >= 31 positions behind a plane
       const bool ks_ok = a.dy_padded && a.kd * a.kh * a.kw > 1 && a.upR <= 1 && a.dsY == a.xsY &&
-                         (a.kh - 1) * a.xsY + (a.kw - 1) >= 31 && !ctx->mfma_bf16;
+                         (a.kh - 1) * a.xsY + (a.kw - 1) >= 31 && !ctx->mfma_bf16 &&
+                         ctx->input_slack >= 128;
       if (f.WK == 9) { if (ks_ok) { *ok = 1; return f; } }
       else if ((f.WK != 7 && f.WK != 8) || pw_ok) { *ok = 1; return f; }
     }

@@ -754,11 +754,17 @@ class Conv(NeuralLayer):
             else:
                 self._need_f32_dy(plan)
                 ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=accumulate)
-        # the weight gradient is independent of the data-gradient chain below: side stream
-        plan.on_side(lambda: plan.tuned(
-            'wgrad', sigw,
-            autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]) + wcands,
-            lambda: wgrad(True), fn_tune=lambda: wgrad(False)))
+        # the weight gradient is independent of the data-gradient chain below: side stream.
+        # (x is a tensor of the plan, or a view into one: Plan.SLACK zeroed floats behind it)
+        def wgrad_launch():
+            ctx.set_input_slack(4 * plan.SLACK)
+            try:
+                plan.tuned('wgrad', sigw,
+                           autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]) + wcands,
+                           lambda: wgrad(True), fn_tune=lambda: wgrad(False))
+            finally:
+                ctx.set_input_slack(0)
+        plan.on_side(wgrad_launch)
         if plan.needs_grad(self.parent) and not tail:
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

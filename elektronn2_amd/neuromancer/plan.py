@@ -80,20 +80,30 @@ class Plan(object):
         self._dp_cut_cache = False
 
     # ---- allocation helpers ---------------------------------------------------
+    SLACK = 32       # floats of ZEROED slack behind every tensor of the plan (e2_set_input_slack)
+
     def empty(self, shape):
-        return torch.empty(tuple(int(s) for s in shape), dtype=torch.float32,
-                           device=self.ctx.device)
+        """an uninitialised tensor followed by SLACK zeros: the position-split weight gradient
+        (csrc/conv_pw_wgrad.hip, "MT,NT,9,0,S") reads up to 31 floats behind its input"""
+        shape = tuple(int(s) for s in shape)
+        n = int(np.prod(shape)) if shape else 1
+        flat = torch.empty(n + self.SLACK, dtype=torch.float32, device=self.ctx.device)
+        flat[n:].zero_()
+        return flat[:n].view(shape)
 
     def zeros(self, shape):
-        return torch.zeros(tuple(int(s) for s in shape), dtype=torch.float32,
-                           device=self.ctx.device)
+        shape = tuple(int(s) for s in shape)
+        n = int(np.prod(shape)) if shape else 1
+        return torch.zeros(n + self.SLACK, dtype=torch.float32, device=self.ctx.device)[:n].view(shape)
 
     def full(self, shape, v):
         return torch.full(tuple(int(s) for s in shape), float(v), dtype=torch.float32,
                           device=self.ctx.device)
 
     def empty_flat(self, n):
-        return torch.empty(int(n), dtype=torch.float32, device=self.ctx.device)
+        flat = torch.empty(int(n) + self.SLACK, dtype=torch.float32, device=self.ctx.device)
+        flat[int(n):].zero_()
+        return flat[:int(n)]
 
     def zeros_flat(self, n):
         return torch.zeros(int(n), dtype=torch.float32, device=self.ctx.device)

@@ -308,6 +308,10 @@ int e2_fill(e2_ctx*, float* ptr, size_t n, float value);
 int e2_fill_multi(e2_ctx*, const void* ptrs_dev, const void* counts_dev, int nregions,
                   float value);
 int e2_set_skip_zero_fill(e2_ctx*, int on);
+/* the conv launches that follow may read up to `bytes` (finite, readable) bytes behind the last
+ * element of their input x (0 withdraws the promise): required (>= 128) by the weight-gradient
+ * tiling "MT,NT,9,0,S", csrc/conv_pw_wgrad.hip */
+int e2_set_input_slack(e2_ctx*, int bytes);
 int e2_conv_last_zero_fill(const e2_ctx*, void** ptr, size_t* n);
 
 /* ---- loss (computations.py:175-176 softmax; loss.py:261-347

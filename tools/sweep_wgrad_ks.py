@@ -11,7 +11,10 @@ extra = sys.argv[9:]
 k = (kd, kh, kw)
 ctx = backend.Context(0)
 D, H, W = Do + kd - 1, Ho + kh - 1, Wo + kw - 1
-x = torch.rand(1, cin, D, H, W, device="cuda")
+xf = torch.zeros(cin * D * H * W + 32, device="cuda")
+x = xf[:cin * D * H * W].view(1, cin, D, H, W)
+x.copy_(torch.rand(1, cin, D, H, W, device="cuda"))
+ctx.set_input_slack(128)
 pad = [kk - 1 for kk in k]
 pshape = (1, cout, Do + 2 * pad[0], Ho + 2 * pad[1], Wo + 2 * pad[2])
 pitch = Wo + pad[2]
