@@ -279,8 +279,18 @@ def test_tiling_candidate_lists():
     inst = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", host7))
     assert inst == set(autotune.PW_WGRAD_TILES)
     # ... and "MT,NT,8,0,S": one tile per work-group, its four waves split the positions
+    host8, host9 = host8.split("int e2i_wgrad_ks(")
     inst8 = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", host8))
     assert inst8 == set(autotune.PW_WGRAD_KS_TILES)
+    # ... and "MT,NT,9,0,S": the same GEMM for kernels WITH taps (needs (kh - 1) input rows >= 31
+    # zeros behind a gradient plane: not offered for short rows)
+    inst9 = set((int(a), int(b)) for a, b in re.findall(r"E2_L\((\d+), (\d+)\)", host9))
+    assert inst9 == set(autotune.WGRAD_KS_TILES)
+    k9 = autotune.position_split_wgrad_candidates(200, 200, (1, 3, 3), (10, 37, 37))
+    assert k9 and all(re.fullmatch(r"\d+,\d+,9,0,\d+", c) for c in k9) and "7,2,9,0,4" in k9
+    assert set(k9) <= set(autotune.wgrad_candidates(200, 200, (1, 3, 3), (10, 37, 37)))
+    assert autotune.position_split_wgrad_candidates(200, 200, (1, 1, 1), (10, 37, 37)) == []
+    assert autotune.position_split_wgrad_candidates(200, 200, (1, 2, 2), (10, 9, 9)) == []    # 10 + 1 < 31 zeros
     pg = autotune.pointwise_wgrad_candidates(2048, 256, (1, 1, 1), (18, 10, 10))
     assert pg and all(re.fullmatch(r"\d+,\d+,[78],0,\d+", c) for c in pg)
     ks = [c for c in autotune.pointwise_wgrad_candidates(200, 200, (1, 1, 1), (10, 37, 37)) if ",8,0," in c]
