@@ -255,7 +255,7 @@ def wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
                   | set(position_split_wgrad_candidates(cout, cin, k, out_sp, n_cu)))
 
 
-WGRAD_KS_TILES = [(13, 2), (10, 2), (7, 2), (7, 4), (5, 4), (4, 4), (3, 4), (2, 4)]
+WGRAD_KS_TILES = [(13, 2), (10, 2), (8, 2), (8, 4), (7, 2), (7, 4), (6, 4), (5, 4), (4, 4), (3, 4), (2, 4)]
 
 
 def position_split_wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
@@ -277,7 +277,7 @@ def position_split_wgrad_candidates(cout, cin, k, out_sp, n_cu=256):
         scored.append((-eff, -mt * nt, mt, nt, nm * nn))
     scored.sort()
     out = []
-    for _, _, mt, nt, tiles in scored[:3]:
+    for _, _, mt, nt, tiles in scored[:4]:
         for fill in (0.5, 1, 2):
             s = max(1, min(-(-units // 4), int(n_cu * fill) // tiles))
             out.append("%d,%d,9,0,%d" % (mt, nt, s))

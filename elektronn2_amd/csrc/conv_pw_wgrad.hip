@@ -531,7 +531,7 @@ int e2i_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   if (!a.accumulate)
     if (int rc = e2i_fill_flat(ctx, a.dw, (size_t)a.Cout * p.Ncol, 0.f)) return rc;
 #define E2_L(M, N_) if (MT == M && NT == N_) return launch_ks<M, N_, true>(ctx, p, grid);
-  E2_L(13, 2) E2_L(7, 2) E2_L(7, 4) E2_L(4, 4) E2_L(10, 2) E2_L(5, 4) E2_L(3, 4) E2_L(2, 4)
+  E2_L(13, 2) E2_L(7, 2) E2_L(7, 4) E2_L(4, 4) E2_L(10, 2) E2_L(5, 4) E2_L(3, 4) E2_L(2, 4) E2_L(8, 2) E2_L(8, 4) E2_L(6, 4)
 #undef E2_L
   e2_set_error("wgrad (position-split GEMM): no instance MT=%d NT=%d", MT, NT);
   return 2;

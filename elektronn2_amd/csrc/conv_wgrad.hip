@@ -466,9 +466,15 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
                          a.dsZ == (int64_t)a.Ho * a.Wo && !ctx->mfma_bf16;
       // "MT,NT,9,0,S": the same GEMM for kernels with taps; needs the padded gradient at the
       // input's row pitch and a zero border of >= 31 positions behind a plane
+      // (and 32-bit byte offsets inside a sample: a larger problem takes the cost model's choice)
+      const long spanK = (long)(a.Ho - 1) * a.dsY + a.Wo;
+      const bool ks_fits = ((long)a.Cout * a.dsC + (long)a.Do * a.dsZ + spanK) * 4 + 256 < (1L << 32) &&
+                           ((long)a.Cin * a.xsC + (long)(a.Do + a.kd - 1) * a.xsZ) * 4 + 256 < (1L << 32) &&
+                           a.dsC >= 0 && a.xsC >= 0 && a.xsZ >= (int64_t)(a.Ho + a.kh - 1) * a.xsY &&
+                           a.xsC >= (int64_t)(a.Do + a.kd - 1) * a.xsZ;
       const bool ks_ok = a.dy_padded && a.kd * a.kh * a.kw > 1 && a.upR <= 1 && a.dsY == a.xsY &&
                          (a.kh - 1) * a.xsY + (a.kw - 1) >= 31 && !ctx->mfma_bf16 &&
-                         ctx->input_slack >= 128;
+                         ctx->input_slack >= 128 && ks_fits;
       if (f.WK == 9) { if (ks_ok) { *ok = 1; return f; } }
       else if ((f.WK != 7 && f.WK != 8) || pw_ok) { *ok = 1; return f; }
     }

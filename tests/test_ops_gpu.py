@@ -513,7 +513,8 @@ def _plan_style_padded(dy, k):
 
 
 @pytest.mark.parametrize("force", ["13,2,9,0,1", "13,2,9,0,4", "7,2,9,0,3", "7,4,9,0,100000", "4,4,9,0,2",
-                                   "10,2,9,0,5", "5,4,9,0,2", "3,4,9,0,7", "2,4,9,0,1"])
+                                   "10,2,9,0,5", "5,4,9,0,2", "3,4,9,0,7", "2,4,9,0,1", "8,2,9,0,3", "8,4,9,0,2",
+                                   "6,4,9,0,4"])
 @pytest.mark.parametrize("ci,co,k,sp", [(9, 100, (2, 3, 3), (4, 12, 21)), (40, 200, (1, 3, 3), (3, 11, 23)),
                                         (20, 37, (3, 3, 3), (5, 9, 18)), (33, 150, (2, 4, 4), (3, 14, 17)),
                                         (7, 30, (1, 5, 5), (2, 13, 16))])
