@@ -378,3 +378,42 @@ def test_batch_larger_than_one(batch):
     for i in range(3):
         loss = float(m.trainingstep(x, t, optimiser='Adam')[0])
         assert abs(loss - ref_losses[i]) < 2 * TOL * abs(ref_losses[i])
+
+
+def test_plan_tensors_carry_zeroed_slack_and_the_step_uses_the_position_split_wgrad():
+    """every tensor of a launch plan is followed by Plan.SLACK zeroed floats -- the promise
+    (e2_set_input_slack) under which the weight gradient "MT,NT,9,0,S" lets the last unit of a
+    plane run past the plane's end -- and a step with those tilings pinned matches the oracle"""
+    from elektronn2_amd import autotune
+    spec, sp = O.NEURO3D_LITE, (9, 71, 71)
+    params = O.init_net(spec, 1, seed=4)
+    rng = np.random.RandomState(6)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    loss_ref, grads_ref, _ = O.net_loss_and_grads(spec, params, x, t)
+    m = build('lite', sp, params)
+    autotune.force('wgrad', "7,2,9,0,3")        # (layers it does not fit take the library's choice)
+    try:
+        got = m.gradients(x, t)
+        plan = getattr(m._grad_func, 'func', None)
+    finally:
+        autotune.force('wgrad', None)
+    flat_ref = []
+    for gw, gb in grads_ref:
+        flat_ref += [gw, gb]
+    for g in got:
+        cands = [r for r in flat_ref if r.shape == g.shape]
+        assert min(rel(g, r) for r in cands) < TOL
+    from elektronn2_amd.neuromancer.plan import Plan
+    assert plan is not None and plan.out
+    plans = [plan]
+    for p in plans:
+        for node, buf in p.out.items():
+            if buf is None or not buf.is_contiguous():
+                continue
+            n = buf.numel()
+            st = buf.untyped_storage().nbytes() // 4 - buf.storage_offset()
+            assert st >= n + Plan.SLACK or buf.storage_offset() > 0, node.name
+            if buf.storage_offset() == 0 and st >= n + Plan.SLACK:
+                tail = torch.as_strided(buf, (Plan.SLACK,), (1,), n)
+                assert float(tail.abs().max()) == 0.0, node.name
