@@ -93,6 +93,33 @@ def main():
             print('   "%s": "%s",   (was %s; step %.4f -> %.4f ms)' % (key, best_c, cur, base, best_ms), flush=True)
             changed[key] = best_c
             base = best_ms
+    # UpConv nodes: their weight gradient is the 1x1x1 GEMM over the space-to-depth image
+    from elektronn2_amd.neuromancer.neural import UpConv
+    for node in plan.nodes:
+        if type(node) is not UpConv or not plan.training:
+            continue
+        sig, cw = node._tune_sigs(plan)['wgrad']
+        key = "wgrad|" + ",".join(str(int(v)) for v in sig)
+        cur = cache.get(key)
+        if cur is None:
+            continue
+        best_c, best_ms = cur, base
+        for cand in [c for c in cw if ",8,0," in c]:
+            if cand == cur:
+                continue
+            cache[key] = cand
+            try:
+                ms = measure()
+            except Exception as err:
+                print("   %s %s: %s" % (key, cand, str(err)[:80]))
+                ms = float("inf")
+            if ms < best_ms - min_gain:
+                best_c, best_ms = cand, ms
+        cache[key] = best_c
+        if best_c != cur:
+            print('   "%s": "%s",   (was %s; step %.4f -> %.4f ms)' % (key, best_c, cur, base, best_ms), flush=True)
+            changed[key] = best_c
+            base = best_ms
     final = measure()
     print("%s with %d entries changed: %.4f ms per step" % (wl, len(changed), final))
     import json
