@@ -80,8 +80,14 @@ int  e2_get_mfma_dtype(const e2_ctx* ctx);
  * kind E2_TILING_WGRAD: cfg = "MT,NT,WK,BP,PS" for
  * e2_conv3d_wgrad / e2_conv3d_wgrad_pad (WK 1 / 14 direct kernel, 0 / 4 LDS-staged, 7 =
  * "MT,NT,7,0,S": 1x1x1 kernels and UpConv, the GEMM with K-contiguous operands of
- * conv_pw_wgrad.hip, 2 x 2 waves of MT x NT blocks, S position splits;
- * BP positions per tile, PS position splits).  The setting holds for every following
+ * conv_pw_wgrad.hip, 2 x 2 waves of MT x NT blocks, S position splits; 8 = "MT,NT,8,0,S": the
+ * same GEMM with ONE 16 MT x 16 NT tile of dW per work-group whose four waves split the positions
+ * and sum their partial tiles through LDS; 9 = "MT,NT,9,0,S": that kernel for a conv WITH taps --
+ * every (input channel, tap) column of dW is a K-contiguous row of x at the tap's constant shift;
+ * e2_conv3d_wgrad_pad only: needs the gradient at the input's row pitch, (kh - 1) input rows
+ * + kw - 1 >= 31 zeros behind a gradient plane, f32 mode and e2_set_input_slack(ctx, >= 128);
+ * BP positions per tile, PS position splits).  The forms 7, 8 and 9 are exempt from the rule
+ * below: where their layout requirements are not met the call takes the cost model's choice.  The setting holds for every following
  * launch of that kind on this context until changed; cfg NULL or "" returns the choice
  * to the library's cost model.  A tiling the problem cannot use (LDS, instance list)
  * makes the launch fail with an error, never silently fall back.  A launch captured
