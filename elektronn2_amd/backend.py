@@ -149,6 +149,8 @@ def _load():
         "e2_conv_last_zero_fill": (C.c_int, [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "e2_set_mfma_dtype": (C.c_int, [vp, C.c_int]),
         "e2_set_tiling": (C.c_int, [vp, C.c_int, C.c_char_p]),
+        "e2_last_launch": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "e2_tiling_fallbacks": (C.c_uint, [vp]),
         "e2_conv3d_bf16_workspace_bytes": (sz, [i, i, i, i, i, i, i, i, i]),
         "e2_conv3d_fwd_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, fp, i, P5, vp, sz]),
         "e2_conv3d_dgrad_bf16": (C.c_int, [vp, P5, fp, i, i, i, i, P5, vp, sz]),
@@ -835,6 +837,18 @@ class Context:
         _chk(_lib.e2_set_tiling(self.h, code, (cfg or "").encode()), "e2_set_tiling")
         self._tiling = getattr(self, '_tiling', {})
         self._tiling[kind] = cfg or ""
+
+    def last_launch(self):
+        """(kernel family, tiling that ran, 'forced' | 'model' | 'fallback') of the last conv GEMM
+        launch of this context (e2_last_launch), or None before the first one"""
+        buf = C.create_string_buffer(160)
+        _chk(_lib.e2_last_launch(self.h, buf, 160), "e2_last_launch")
+        parts = buf.value.decode().split(" ")
+        return tuple(parts) if len(parts) == 3 else None
+
+    def tiling_fallbacks(self):
+        """launches of this context whose forced tiling was not the one that ran"""
+        return int(_lib.e2_tiling_fallbacks(self.h))
 
     def bf16_memory_form(self):
         """True while the forced igemm tiling selects the kernel with bf16 operands in memory

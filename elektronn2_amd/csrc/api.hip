@@ -54,6 +54,8 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->last_fill_ptr = nullptr;
   c->last_fill_n = 0;
   c->tiling[0][0] = c->tiling[1][0] = 0;
+  c->last_launch[0] = 0;
+  c->tiling_fallbacks = 0;
   for (int i = 0; i < 32; ++i) c->fork_ev[i] = nullptr;
   if (hipMalloc(&c->zeros, 1024) != hipSuccess || hipMemset(c->zeros, 0, 1024) != hipSuccess) {
     delete c;
@@ -104,6 +106,32 @@ extern "C" int e2_set_tiling(e2_ctx* ctx, int kind, const char* cfg) {
   strcpy(ctx->tiling[kind], cfg);
   return 0;
 }
+
+void e2_note_launch(e2_ctx* ctx, const char* family, int src, const char* fmt, ...) {
+  char til[96];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(til, sizeof(til), fmt, ap);
+  va_end(ap);
+  snprintf(ctx->last_launch, sizeof(ctx->last_launch), "%s %s %s", family, til,
+           src == E2_SRC_FORCED ? "forced" : (src == E2_SRC_FALLBACK ? "fallback" : "model"));
+  if (src == E2_SRC_FALLBACK) ++ctx->tiling_fallbacks;
+}
+
+/* Which kernel the last conv GEMM launch of this context ran (forward / data gradient / UpConv /
+ * weight gradient, f32 and bf16 forms): "<kernel family> <tiling> <source>", source = "forced"
+ * (the e2_set_tiling string was honoured), "model" (none was set: the cost model chose) or
+ * "fallback" (a string was set but the launch could not run it and took the cost model's
+ * choice: only the weight-gradient forms 7 / 8 / 9 may, see e2_set_tiling).  Host-side
+ * bookkeeping only: legal during capture; empty before the first launch. */
+extern "C" int e2_last_launch(e2_ctx* ctx, char* buf, int n) {
+  E2_REQUIRE(ctx && buf && n > 0, "e2_last_launch: bad argument");
+  snprintf(buf, (size_t)n, "%s", ctx->last_launch);
+  return 0;
+}
+
+/* launches since e2_ctx_create whose forced tiling was not the one that ran */
+extern "C" unsigned e2_tiling_fallbacks(const e2_ctx* ctx) { return ctx ? ctx->tiling_fallbacks : 0; }
 
 extern "C" int e2_ctx_destroy(e2_ctx* ctx) {
   if (ctx && ctx->zeros) (void)hipFree(ctx->zeros);

@@ -23,7 +23,14 @@ struct e2_ctx {
   int loss_sum_mode;        // e2_set_loss_grad_mode: 1 = NLL gradients are NOT divided by the labelled count
   float* loss_count_out;    // ... and the count is also written here (the slot behind the gradient arena)
   int input_slack;          // e2_set_input_slack: finite readable bytes behind the x of the launches that follow
+  char last_launch[160];    // e2_last_launch: "<kernel family> <tiling that ran> <forced|model|fallback>"
+  unsigned tiling_fallbacks;   // launches since e2_ctx_create whose forced tiling was NOT the one that ran
 };
+
+// what decided the tiling of a launch (third word of e2_last_launch)
+enum { E2_SRC_MODEL = 0, E2_SRC_FORCED = 1, E2_SRC_FALLBACK = 2 };
+// record the conv GEMM launch that is about to be issued (api.hip)
+void e2_note_launch(e2_ctx* ctx, const char* family, int src, const char* fmt, ...);
 
 // Debug switches (timing ablations, in-kernel stamps, verbose launch log) are compiled in
 // only with -DE2_DEBUG_ENV (make DEBUG_ENV=1): the release library never reads the process

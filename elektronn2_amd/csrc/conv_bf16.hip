@@ -513,6 +513,12 @@ static int conv_bf16(e2_ctx* ctx, const e2_tensor5* in, const float* w, int nf, 
   const long units = (long)p.N * p.Do * p.nPT;
   const long grid = (units + 7) / 8 * 8 * p.nMT;
   E2_REQUIRE(grid < (1L << 31), "conv_bf16: grid too large");
+  {
+    int v[3];
+    const bool forced = sscanf(ctx->tiling[E2_TILING_IGEMM], "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] == 32;
+    e2_note_launch(ctx, "conv_bf16", forced ? E2_SRC_FORCED : (ctx->tiling[E2_TILING_IGEMM][0] ? E2_SRC_FALLBACK : E2_SRC_MODEL),
+                   "32,%d,%d", MB, NB);
+  }
   if (MB == 1 && NB == 1) return launch<1, 1>(ctx, p, (int)grid, ldsb);
   if (MB == 1 && NB == 2) return launch<1, 2>(ctx, p, (int)grid, ldsb);
   if (MB == 2 && NB == 1) return launch<2, 1>(ctx, p, (int)grid, ldsb);

@@ -499,12 +499,19 @@ int e2i_igemm_conv(e2_ctx* ctx, const IgemmArgs& a) {
   if (a.gm_done) *a.gm_done = 0;
   if (a.up_bias_done) *a.up_bias_done = 0;
   if (a.nparts) *a.nparts = 1;
-  if (c.kind == 4) return igemm4_conv(ctx, a, c);
+  const int src = ctx->tiling[E2_TILING_IGEMM][0] ? E2_SRC_FORCED : E2_SRC_MODEL;   // (no fallback here)
+  if (c.kind == 4) {
+    e2_note_launch(ctx, "igemm4", src, "4,%d,%d,%d,%d,%d,%d,%d", c.MT, c.NT, c.CC, c.SK, c.WM, c.WN, c.G);
+    return igemm4_conv(ctx, a, c);
+  }
   if (c.kind == 1) {                                             // "1,MT,NT": conv_pw.hip
     E2_REQUIRE(!ctx->mfma_bf16, "pointwise conv: an f32 kernel, not offered in bf16 mode");
+    e2_note_launch(ctx, "pw_gemm", src, "1,%d,%d,%d,0", c.MT, c.NT, c.KC);
     return e2i_pw_conv(ctx, a, c.MT, c.NT, c.KC);
   }
   const bool fast = has_fast_kw(a.kw);
+  e2_note_launch(ctx, !fast ? "igemm_generic" : (ctx->mfma_bf16 ? "igemm_bf16r" : "igemm"), src, "%d,%d,%d,%d",
+                 c.MT, c.NT, c.CC, c.SK);
   // the gradient-mask epilogue lives in the specialised-width 16x16x4 kernel
   const bool gm = a.gm && fast && a.upz * a.upy * a.upx == 1 && a.Wo >= 4;
   E2_REQUIRE(c.CC >= 4 && c.CC % 4 == 0 && c.CC <= (fast ? 64 : 32),

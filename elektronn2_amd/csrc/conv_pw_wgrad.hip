@@ -515,6 +515,21 @@ int e2i_wgrad_ks(e2_ctx* ctx, const WgradArgs& a, int MT, int NT, int S) {
   p.T = T; p.kh = a.kh; p.kw = a.kw; p.flip = a.flip; p.planes = a.Do;
   p.asZ = a.dsZ; p.bsZ = a.xsZ; p.bsY = a.xsY;
   E2_REQUIRE(ctx->input_slack >= 128, "wgrad (position-split GEMM): needs e2_set_input_slack(ctx, >= 128)");
+#ifdef E2_DEBUG_ENV
+  // debug build (make DEBUG_ENV=1): CHECK the caller's promise -- the 32 floats behind the last
+  // element of x must be finite (they meet the gradient's zero border: 0 x Inf / NaN = NaN in dW
+  // where the reference produces none).  Synchronises: never during capture.
+  if (!ctx->capturing) {
+    const float* end = a.x + (int64_t)(a.N - 1) * a.xsN + (int64_t)(a.Cin - 1) * a.xsC +
+                       (int64_t)(Din - 1) * a.xsZ + (int64_t)(Hin - 1) * a.xsY + (a.Wo + a.kw - 1);
+    float h[32];
+    E2_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    E2_CHECK_HIP(hipMemcpy(h, end, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 32; ++i)
+      E2_REQUIRE(h[i] == h[i] && h[i] - h[i] == 0.f, "wgrad (position-split GEMM): e2_set_input_slack promised finite "
+                 "values behind x, but float %d behind its last element is %g", i, (double)h[i]);
+  }
+#endif
   p.nMT = e2_cdiv(a.Cout, 16 * MT);
   p.nNT = e2_cdiv(p.Ncol, 16 * NT);
   p.stepsPerSample = (int)((K + 31) / 32);                    // (whole units of a PLANE)

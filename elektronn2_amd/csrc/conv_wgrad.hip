@@ -443,7 +443,7 @@ struct WCfg { int MT, NT, WK, BP, PS; };
 // Cost model (cycles): MFMA time of a work-group's waves (they run 1-2 per
 // SIMD), DMA bytes at ~20 B/clk/CU, and the flush atomics against the chip-wide
 // 1.3 TB/s rate; position splits only as needed to fill the CUs.
-static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
+static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok, int* src) {
   const int mblocks = e2_cdiv(a.Cout, 16);
   const int T = a.kd * a.kh * a.kw;
   const long NTOT = (long)a.Cin * T;
@@ -453,7 +453,9 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
   double bestCost = 1e300;
   const double dw_bytes = 4.0 * a.Cout * (double)NTOT;
   const char* force = ctx->tiling[E2_TILING_WGRAD];
+  *src = E2_SRC_MODEL;
   if (force[0]) {
+    *src = E2_SRC_FALLBACK;           // ... unless one of the returns below honours the string
     WCfg f{0, 0, 0, 0, 0};
     if (sscanf(force, "%d,%d,%d,%d,%d", &f.MT, &f.NT, &f.WK, &f.BP, &f.PS) == 5) {
       // "MT,NT,7,0,S" names the K-contiguous 1x1x1 GEMM (conv_pw_wgrad.hip), which takes dense
@@ -475,8 +477,8 @@ static WCfg choose_wcfg(const e2_ctx* ctx, const WgradArgs& a, int* ok) {
       const bool ks_ok = a.dy_padded && a.kd * a.kh * a.kw > 1 && a.upR <= 1 && a.dsY == a.xsY &&
                          (a.kh - 1) * a.xsY + (a.kw - 1) >= 31 && !ctx->mfma_bf16 &&
                          ctx->input_slack >= 128 && ks_fits;
-      if (f.WK == 9) { if (ks_ok) { *ok = 1; return f; } }
-      else if ((f.WK != 7 && f.WK != 8) || pw_ok) { *ok = 1; return f; }
+      if (f.WK == 9) { if (ks_ok) { *ok = 1; *src = E2_SRC_FORCED; return f; } }
+      else if ((f.WK != 7 && f.WK != 8) || pw_ok) { *ok = 1; *src = E2_SRC_FORCED; return f; }
     }
   }
   if (a.dy_padded && nblocks > 2) {
@@ -564,10 +566,20 @@ int e2i_wgrad_conv(e2_ctx* ctx, const WgradArgs& a) {
   E2_REQUIRE(a.Do > 0 && a.Ho > 0 && a.Wo > 0 && a.Cin > 0 && a.Cout > 0,
              "wgrad: empty problem");
   E2_REQUIRE(a.xsY < (1 << 20), "wgrad: input row stride too large");
-  int ok = 0;
-  WCfg c = choose_wcfg(ctx, a, &ok);
+  int ok = 0, src = E2_SRC_MODEL;
+  WCfg c = choose_wcfg(ctx, a, &ok, &src);
   E2_REQUIRE(ok, "wgrad: no tiling fits LDS (Cin=%d Cout=%d k=%dx%dx%d)", a.Cin, a.Cout,
              a.kd, a.kh, a.kw);
+  {
+    // e2_last_launch: the kernel family this call is about to run, its tiling, and whether a
+    // forced string was honoured ("fallback": a 7 / 8 / 9 form the problem's layout cannot run)
+    const bool direct = a.dy_padded && (c.WK == 1 || c.WK == 14 || c.WK == 101 || c.WK == 114) &&
+                        (c.BP == 128 || c.BP == 256);
+    const char* fam = c.WK == 7 ? "pw_wgrad" : c.WK == 8 ? "pw_wgrad_ks" : c.WK == 9 ? "wgrad_ks"
+                      : direct ? (ctx->mfma_bf16 ? "wgrad_direct_bf16r" : "wgrad_direct")
+                      : "wgrad_lds";
+    e2_note_launch(ctx, fam, src, "%d,%d,%d,%d,%d", c.MT, c.NT, c.WK, c.BP, c.PS);
+  }
   // WK field: 1 = direct kernel when dy is padded (BP 128/256), else the LDS-staged
   // kernel; 14 = direct kernel, waves split the quads of a tile (NT 2/4);
   // 0 = LDS-staged kernel forced; 4 = LDS-staged kernel, waves split K

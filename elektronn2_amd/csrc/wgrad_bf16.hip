@@ -495,6 +495,12 @@ static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int
   const long grid = 8L * p.perXcd;                                 // (work-groups past the last one exit)
   E2_REQUIRE(grid < (1L << 31), "conv3d_wgrad_bf16: grid too large");
   E2_REQUIRE((size_t)T * 33 * 4 <= 64 * 1024, "conv3d_wgrad_bf16: %d taps exceed the output pass's LDS tile", T);
+  {
+    int v[5];
+    const bool forced = sscanf(ctx->tiling[E2_TILING_WGRAD], "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5 && v[0] == 32;
+    e2_note_launch(ctx, "wgrad_bf16", forced ? E2_SRC_FORCED : (ctx->tiling[E2_TILING_WGRAD][0] ? E2_SRC_FALLBACK : E2_SRC_MODEL),
+                   "32,%d,%d,%d,%d", MB, NB, rows ? 1 : 0, S);
+  }
   int rc = 2;
 #define E2_L(M, N_) if (MB == M && NB == N_) rc = rows ? launch<M, N_, true>(ctx, p, grid, ldsb) : launch<M, N_, false>(ctx, p, grid, ldsb);
   E2_L(1, 1) E2_L(1, 2) E2_L(1, 3) E2_L(1, 4) E2_L(2, 1) E2_L(2, 2) E2_L(2, 3) E2_L(2, 4)

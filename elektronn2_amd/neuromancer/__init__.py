@@ -9,3 +9,4 @@ from .loss import (Softmax, MultinoulliNLL, MalisNLL, AggregateLoss, Classificat
                    Errors)
 from .optimiser import Optimiser, SGD, Adam
 from .model import Model, modelload, params_from_model_file
+from .options import set_plan_options, plan_options

@@ -23,10 +23,6 @@ import torch
 from .. import autotune, backend
 
 
-import os
-_WGRAD_ONLY = os.environ.get("E2_BF16_AHEAD_WGRAD_ONLY", "0") == "1"
-_MIN_SHARE = float(os.environ.get("E2_BF16_AHEAD_MIN", "0.6"))
-
 
 def _known(plan, kind, sig):
     return autotune.known(plan.ctx, kind, sig)
@@ -78,7 +74,7 @@ def prepare(plan):
                     return                    # (not tuned yet: after the first eager step)
                 tot += 1
                 mem += t.startswith('32,')
-        if tot == 0 or mem < _MIN_SHARE * tot:
+        if tot == 0 or mem < float(plan.opt['bf16_ahead_min']) * tot:
             plan._bf16_ahead_on = False
             return
     new_jobs = False
@@ -133,7 +129,7 @@ def prepare(plan):
         # waits for); a layer whose data gradient reads f32 keeps the f32 pass + the weight
         # gradient's own conversion on the side stream (measured: neuro3d@185 1.22 -> 1.15 ms)
         if (node, 'dy') not in a and ((node, 'dgrad') in a or
-                                      ((node, 'wgrad') in a and (not want_d or _WGRAD_ONLY))):
+                                      ((node, 'wgrad') in a and (not want_d or plan.opt['bf16_ahead_wgrad_only']))):
             d, wg = a.get((node, 'dgrad')), a.get((node, 'wgrad'))
             pad = [kk - 1 for kk in k]
             dst = backend.bf16_dst(cl=d['cl'] if d else None, cl_dims=d['cl_dims'] if d else None,

@@ -361,11 +361,10 @@ class Conv(NeuralLayer):
         position tile out of LDS.  Returns (head conv, softmax, nll) or None."""
         key = (self, 'tail')
         if key not in plan.scratch:
-            import os
             r = None
             kids = list(self.children.values())
             par = self.parent
-            if (os.environ.get('E2_FUSE_TAIL', '1') == '1' and plan.training
+            if (plan.opt['fuse_tail'] and plan.training
                     and type(self) is Conv and not self._bn() and not self.mfp
                     and tuple(self._k3) == (1, 1, 1) and all(p == 1 for p in self._p3)
                     and self.activation_func == 'relu' and len(kids) == 1
@@ -394,9 +393,8 @@ class Conv(NeuralLayer):
         feeds only this node -- Conv._tail): a plain Conv without pooling / batch norm, relu or
         lin, with gradient buffers of its own.  Returns (mode, src tensor, bias) for
         e2_tail_fwd_bwd or None (the launch writes the parent's plain output gradient)."""
-        import os
         par = self.parent
-        if not (os.environ.get('E2_TAIL_GM', '1') == '1' and type(par) is Conv and not par._bn()
+        if not (plan.opt['tail_gm'] and type(par) is Conv and not par._bn()
                 and all(p == 1 for p in par._p3) and par.activation_func in ('relu', 'lin')
                 and (par, 'dy') in plan.scratch and not par._fused_first(plan)
                 and par._fused_head(plan) is None and par._tail(plan) is None
@@ -755,9 +753,12 @@ class Conv(NeuralLayer):
                 self._need_f32_dy(plan)
                 ctx.conv3d_wgrad_pad(x, dyp, dw, accumulate=accumulate)
         # the weight gradient is independent of the data-gradient chain below: side stream.
-        # (x is a tensor of the plan, or a view into one: Plan.SLACK zeroed floats behind it)
+        # (x is a tensor of the plan, or a view into one: Plan.SLACK zeroed floats behind it --
+        # checked against the allocation, not assumed: Plan.slack_behind)
+        slack = min(4 * plan.SLACK, plan.slack_behind(x))
+
         def wgrad_launch():
-            ctx.set_input_slack(4 * plan.SLACK)
+            ctx.set_input_slack(slack)
             try:
                 plan.tuned('wgrad', sigw,
                            autotune.wgrad_candidates(self.n_f, cin, self._k3, dy.shape[2:]) + wcands,
@@ -1045,9 +1046,8 @@ class UpConv(Conv):
         # the two packed images, refreshed by the plan's one repack launch per step (they
         # used to be repacked inside every forward and backward call: two launches per node)
         w5 = plan._w5(plan.param(self.w))
-        import os
         if w5.dim() == 5 and tuple(w5.shape[2:]) == tuple(self.pool_shape) \
-                and os.environ.get("E2_UPCONV_PACKED", "1") == "1":
+                and plan.opt['upconv_packed']:
             ib = plan.ctx.upconv_image_bytes(self.n_f, cin, self.pool_shape)
             plan.scratch[self, 'wp_f'] = plan.zeros_flat(ib // 4 + 64)
             plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 2))

@@ -438,7 +438,7 @@ class Node(object, metaclass=MetaNode):
             # activations of one sample: every node's output, conv nodes twice (pre-activation)
             per = sum(4.0 * float(np.prod([1 if v is None else v for v in n.shape.shape]))
                       * (2 if hasattr(n, 'filter_shape') else 1) for n in plan.nodes)
-            budget = float(os.environ.get("E2_DENSE_ACT_GIB", "48")) * 2.0 ** 30
+            budget = float(plan.opt['dense_act_gib']) * 2.0 ** 30
             B = int(max(1, min(16, n_pass, budget // max(per, 1.0))))
         x_sh = (B, raw.shape[0]) + tuple(int(v) for v in ps)
         plan.set_inputs([np.zeros(x_sh, np.float32)])      # builds the plan for batch B
@@ -588,11 +588,10 @@ class Concat(Node):
         of the concat buffer as output and the slice of the concat gradient as gradient; a
         Crop (a view of ITS parent's output, which others read too) keeps the forward copy
         but takes the gradient slice.  Per U-Net merge that removes one copy launch from the
-        forward and two from the backward pass (E2_CONCAT_ALIAS=0: every parent is copied)."""
-        import os
+        forward and two from the backward pass (option concat_alias=False: every parent is copied)."""
         plan.alloc_out(self)
         alias = plan.scratch[self, 'alias'] = {}
-        if self.axis != 1 or os.environ.get("E2_CONCAT_ALIAS", "1") != "1":
+        if self.axis != 1 or not plan.opt['concat_alias']:
             return
         out, g = plan.out[self], plan.grad.get(self)
         c0 = 0

@@ -1,0 +1,94 @@
+"""Host-side switches of the launch plan as ARGUMENTS.
+
+Until round 4 the plan read ``E2_*`` environment variables at import, at build and per step, and
+a test flipped ``os.environ`` mid-process to choose a code path.  Now every switch is a named
+option: ``set_plan_options(name=value, ...)`` changes the process-wide default, ``plan_options(
+name=value, ...)`` is the same as a context manager, and a ``Plan`` SNAPSHOTS the options when
+it is constructed (``Plan.opt``) -- a plan never changes behaviour after it was built or
+captured, whatever is set later.  The environment variable of each option is its DEFAULT only
+(read when the option is first asked for), kept so that the A/B scripts under tools/ still work.
+
+The reference has no counterpart (Theano's flags, ``theano.config.*``, are the closest analogue:
+process-wide, read at compile time -- graphutils.py:376-387)."""
+import contextlib
+import os
+
+
+def _b(v):
+    return str(v).strip().lower() not in ("0", "", "false", "off", "no")
+
+
+def _tri(v):
+    return None if v is None or str(v) == "" else _b(v)
+
+
+# name: (environment variable, parser, default, what it does)
+SPEC = {
+    "graph": ("E2_NO_GRAPH", lambda v: not _b(v), True,
+              "capture the step into hipGraphs after one eager call (E2_NO_GRAPH=1 turns it off)"),
+    "side_stream": ("E2_SIDE_STREAM", _tri, None,
+                    "weight gradients on a second stream; None = only in bf16 mode (DESIGN finding 7)"),
+    "side_pack": ("E2_SIDE_PACK", _b, False, "weight repack as a parallel branch (measured slower)"),
+    "fuse_actbwd": ("E2_FUSE_ACTBWD", int, 0, "relu backward in the consumer's dgrad epilogue (finding 17)"),
+    "fuse_tail": ("E2_FUSE_TAIL", _b, True, "last 1x1x1 conv + head + loss in one launch (finding 33)"),
+    "tail_gm": ("E2_TAIL_GM", _b, True, "the tail launch carries its parent's activation backward"),
+    "upconv_packed": ("E2_UPCONV_PACKED", _b, True, "UpConv weight images packed by the plan's one repack launch"),
+    "concat_alias": ("E2_CONCAT_ALIAS", _b, True, "a concat hands channel slices to parents only it consumes"),
+    "zero_in_update": ("E2_ZERO_IN_UPDATE", _b, True, "the optimiser launch clears the gradient arena (finding 38)"),
+    "dp_overlap": ("E2_DP_OVERLAP", _b, True, "exchange the late layers' gradients under the early backward"),
+    "dp_fused_scale": ("E2_DP_FUSED_SCALE", _b, True, "collectives only sum, the optimiser kernel normalises"),
+    "bf16_ahead": ("E2_BF16_AHEAD", _b, True, "bf16 mode: producers write the GEMM operands (finding 43)"),
+    "bf16_ahead_min": ("E2_BF16_AHEAD_MIN", float, 0.6, "... only when this share of the GEMM launches are memory forms"),
+    "bf16_ahead_wgrad_only": ("E2_BF16_AHEAD_WGRAD_ONLY", _b, False, "... gradient images for the weight gradient alone"),
+    "bf16_xkeep": ("E2_BF16_XKEEP", _b, True, "bf16 mode: the forward's channels-last copy of x serves the wgrad"),
+    "bf16_wpack": ("E2_BF16_WPACK", str, "step", "'step': one filter-row pack launch per step; 'call': per launch"),
+    "dense_act_gib": ("E2_DENSE_ACT_GIB", float, 48.0, "activation budget of tiled dense prediction (GiB)"),
+}
+
+_set = {}          # process-wide overrides (set_plan_options)
+
+
+def get(name):
+    if name in _set:
+        return _set[name]
+    env, parse, default, _ = SPEC[name]
+    v = os.environ.get(env)
+    return default if v is None else parse(v)
+
+
+def snapshot(overrides=None):
+    """all options as a dict (what a Plan keeps)"""
+    d = {k: get(k) for k in SPEC}
+    for k, v in (overrides or {}).items():
+        if k not in SPEC:
+            raise KeyError("unknown plan option %r (known: %s)" % (k, ", ".join(sorted(SPEC))))
+        d[k] = v
+    return d
+
+
+def set_plan_options(**kw):
+    """process-wide defaults of plans constructed from now on; ``name=None`` returns an option
+    to its environment / built-in default (except side_stream, where None IS a value: pass
+    ``reset=('side_stream',)``)"""
+    reset = kw.pop("reset", ())
+    for k in reset:
+        _set.pop(k, None)
+    for k, v in kw.items():
+        if k not in SPEC:
+            raise KeyError("unknown plan option %r (known: %s)" % (k, ", ".join(sorted(SPEC))))
+        if v is None and k != "side_stream":
+            _set.pop(k, None)
+        else:
+            _set[k] = v
+
+
+@contextlib.contextmanager
+def plan_options(**kw):
+    """``with plan_options(bf16_ahead=False): ...`` -- plans CONSTRUCTED inside see the values"""
+    old = dict(_set)
+    try:
+        set_plan_options(**kw)
+        yield
+    finally:
+        _set.clear()
+        _set.update(old)

@@ -50,7 +50,11 @@ def set_mfma_dtype(dtype):
 
 
 class Plan(object):
-    def __init__(self, inputs, outputs, model=None, step=None, name='', use_graph=True):
+    def __init__(self, inputs, outputs, model=None, step=None, name='', use_graph=True, options=None):
+        # the host switches, SNAPSHOT at construction (options.py): what is set later -- in the
+        # environment or through set_plan_options -- never reaches a plan that exists
+        from . import options as _options
+        self.opt = _options.snapshot(options)
         self.inputs = list(inputs)
         self.outputs = list(outputs)
         self.step = step                       # None | 'SGD' | 'Adam' | 'grad'
@@ -59,8 +63,7 @@ class Plan(object):
         self.model = model if model is not None else getattr(self.outputs[0], '_model', None)
         if self.model is None:
             raise RuntimeError("plan: nodes are not registered in a model")
-        import os as _os
-        self.use_graph = use_graph and _os.environ.get('E2_NO_GRAPH', '0') != '1'
+        self.use_graph = use_graph and self.opt['graph']
         self.ctx = None
         self.batch = None
         self.last_device_time = None
@@ -99,6 +102,16 @@ class Plan(object):
     def full(self, shape, v):
         return torch.full(tuple(int(s) for s in shape), float(v), dtype=torch.float32,
                           device=self.ctx.device)
+
+    def slack_behind(self, t):
+        """bytes of the tensor's own allocation behind the view's last element: what the plan may
+        promise to e2_set_input_slack.  Tensors from empty / zeros / empty_flat / the input arena
+        end in SLACK zeroed floats; a view into one of them (Crop, a concat slice) is followed by
+        more of the written buffer.  Anything else (torch.* allocations without slack) yields its
+        true remainder, possibly 0 -- the position-split weight gradient is then not offered and
+        the library's own tiling runs."""
+        last = t.storage_offset() + sum((int(n) - 1) * int(st) for n, st in zip(t.shape, t.stride()))
+        return int(t.untyped_storage().nbytes()) - 4 * (last + 1)
 
     def empty_flat(self, n):
         flat = torch.empty(int(n) + self.SLACK, dtype=torch.float32, device=self.ctx.device)
@@ -195,7 +208,7 @@ class Plan(object):
         """the per-layer buffer that keeps the forward's channels-last bf16 copy of the layer's
         input for its weight gradient (zero-filled once: the pixels behind the last plane are
         never written); ``only_valid``: None unless this step's forward filled it"""
-        if os.environ.get("E2_BF16_XKEEP", "1") != "1":
+        if not self.opt['bf16_xkeep']:
             return None
         if only_valid and not self._xkeep_valid.get(node, False):
             return None
@@ -360,30 +373,28 @@ class Plan(object):
         # data-gradient chain; inside the captured graph they are parallel branches
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
-        import os
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
         # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
         # branch pays there (lite183 0.884 -> 0.855 ms, neuro3d 1.223 -> 1.198, unet3d 7.23 ->
-        # 7.05).  E2_SIDE_STREAM=0/1 overrides.
-        env_side = os.environ.get("E2_SIDE_STREAM")
-        self.use_side = (env_side == "1") if env_side is not None else \
+        # 7.05).  Option side_stream = True / False overrides.
+        self.use_side = self.opt['side_stream'] if self.opt['side_stream'] is not None else \
             (getattr(self.ctx, 'mfma_dtype', 'f32') == 'bf16')
         # the repack of the weight images as a parallel branch of the graph next to the first
         # layer (the first kernel that reads a packed image joins it, Conv._plan_fwd): measured
         # on one box, interleaved (tools/ab.sh), the fork / join costs more than the overlap
         # saves -- lite183 1.715 vs 1.699 ms, full185 2.120 vs 2.095 ms -- so it stays off
-        self.use_side_pack = os.environ.get("E2_SIDE_PACK", "0") == "1"
+        self.use_side_pack = bool(self.opt['side_pack'])
         # activation backward of an un-pooled conv inside its consumer's data-gradient launch
         # (e2_conv3d_dgrad_packed_actbwd).  Measured (tools/ab.sh, DESIGN.md finding 17): the
         # mask loads in the GEMM epilogue cost what the removed 10 us kernel cost, and the
         # bias-gradient atomics of split-K grids cost more (neuro3d@185 +0.7 ms) -- off
-        self.fuse_actbwd = int(os.environ.get("E2_FUSE_ACTBWD", "0"))
+        self.fuse_actbwd = int(self.opt['fuse_actbwd'])
         self.out, self.grad, self.scratch = {}, {}, {}
         # bf16 mode: operands of the GEMM launches made ahead of them (bf16_ahead.py)
         self.bf16a, self._bf16_wjobs = {}, None
         self._xb_ready, self._dy_ready, self._wb_ready = {}, {}, False
-        self._bf16_ahead_on = os.environ.get("E2_BF16_AHEAD", "1") == "1"
+        self._bf16_ahead_on = bool(self.opt['bf16_ahead'])
         self._xkeep_valid = {}       # Conv node -> its kept bf16 input copy is this step's
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.model.ensure_arena(self.ctx)
@@ -411,7 +422,8 @@ class Plan(object):
                 self._pack_dev = self.ctx.make_pack_jobs(jobs)
         self._graphs = None
         self._segs = None
-        self._segs_world = None
+        self._segs_key = None
+        self._dp_scale_mode = False          # (False = not decided yet; _segments decides)
         self._seg_idx = 0
         self._zero_seen, self._zero_batched, self._zero_keep = [], {}, None
         self._capturing = False
@@ -446,9 +458,9 @@ class Plan(object):
     def ensure_wb(self):
         """bf16 mode: every layer's packed filter rows by ONE launch per step, issued in front of
         the first launch that reads them (behind the fused first layer, which does not).
-        E2_BF16_WPACK=call: each launch's own conversion pass packs its rows instead (A/B switch)"""
+        Option bf16_wpack='call': each launch's own conversion pass packs its rows instead (A/B switch)"""
         if not self._wb_ready and self._bf16_wjobs is not None and \
-                os.environ.get("E2_BF16_WPACK", "step") == "step":
+                self.opt['bf16_wpack'] == "step":
             self.ctx.conv3d_bf16_pack_w_multi(*self._bf16_wjobs)
             self._wb_ready = True
         return self._wb_ready
@@ -481,7 +493,7 @@ class Plan(object):
             return self._dp_cut_cache
         self._dp_cut_cache = None
         m = self.model
-        if os.environ.get('E2_DP_OVERLAP', '1') == '0' or m.n_train < (1 << 16):
+        if not self.opt['dp_overlap'] or m.n_train < (1 << 16):
             return None
         nodes = self._bwd_nodes()
         last = {}                                  # id(param) -> last backward index using it
@@ -521,22 +533,39 @@ class Plan(object):
         (e2_adam_step_ex zero_g): no fill launch at the head of the backward pass.  G is
         zero on entry because the last step left it so -- or _run_device fills it first
         (Model._g_clean)."""
-        return (self.training and self.step in ('Adam', 'SGD')
-                and os.environ.get('E2_ZERO_IN_UPDATE', '1') == '1')
+        return (self.training and self.step in ('Adam', 'SGD') and bool(self.opt['zero_in_update']))
 
-    def _dp_scale(self):
+    def _dp_key(self):
+        """everything outside the plan that the segmentation and the captured graphs depend on:
+        the data-parallel state of the model.  A change re-plans and re-captures (_run_device);
+        between two changes the plan uses the values STORED by _segments -- never a fresh read
+        (a flag flipped after capture made the host exchange scale by the count while
+        the captured optimiser still divided by it)."""
+        m = self.model
+        if not self.training:
+            return (1,)
+        return (m.dp_world(), bool(getattr(m, '_dp_weighted', False)), bool(getattr(m, '_dp_force', False)),
+                id(getattr(m, '_dp_group', None)))
+
+    def _dp_scale_now(self):
         """how the data-parallel step normalises: None = the exchange object scales with
         elementwise launches (parallel.BucketedMean); ('sum',) = the loss kernels leave the
         gradients unnormalised and put the labelled count into the slot behind the arena, the
         collectives only SUM, the optimiser kernel divides by the summed count; ('mean', 1/w)
         = plain mean, the factor applied by the optimiser kernel."""
         if not (self.training and self.step in ('Adam', 'SGD') and self.model.dp_world() > 1
-                and os.environ.get('E2_DP_FUSED_SCALE', '1') == '1' and self.model.G.is_cuda):
+                and self.opt['dp_fused_scale'] and self.model.G.is_cuda):
             return None
         if getattr(self.model, '_dp_weighted', False):
             return ('sum',) if self._labelled_count() is not None else None
         import torch.distributed as dist
         return ('mean', 1.0 / dist.get_world_size(self.model._dp_group))
+
+    def _dp_scale(self):
+        """the mode decided when the step was last segmented (see _dp_key)"""
+        if self._dp_scale_mode is False:
+            self._dp_scale_mode = self._dp_scale_now()
+        return self._dp_scale_mode
 
     def loss_grad_mode(self):
         """context manager around the NLL backward launches of a loss node"""
@@ -559,6 +588,7 @@ class Plan(object):
         run between two segments -- the gradient exchange of the data-parallel step, or
         the host part of a node (MALIS: Kruskal on the CPU between forward and loss)."""
         dp = self.training and self.step in ('Adam', 'SGD') and self.model.dp_world() > 1
+        self._dp_scale_mode = self._dp_scale_now()       # decided ONCE per segmentation
         host = [n for n in self.nodes if hasattr(n, '_plan_host')]
         upd = self.training and self.step in ('Adam', 'SGD')
         segs = []
@@ -615,10 +645,11 @@ class Plan(object):
     def _run_device(self):
         """fwd (+ bwd + all-reduce + update) on self.stream, graph-replayed."""
         ctx = self.ctx
-        world = self.model.dp_world() if self.training else 1
-        if self._segs is None or self._segs_world != world:
-            # (data parallelism switched on after earlier steps: re-plan and re-capture)
-            self._segs, self._segs_world = self._segments(), world
+        key = self._dp_key()
+        if self._segs is None or self._segs_key != key:
+            # (data parallelism switched on / its weighting changed after earlier steps: re-plan
+            # and re-capture)
+            self._segs, self._segs_key = self._segments(), key
             for g in (self._graphs or []):
                 ctx.graph_destroy(g)
             if self._graphs is not None:

@@ -87,12 +87,31 @@ int  e2_get_mfma_dtype(const e2_ctx* ctx);
  * e2_conv3d_wgrad_pad only: needs the gradient at the input's row pitch, (kh - 1) input rows
  * + kw - 1 >= 31 zeros behind a gradient plane, f32 mode and e2_set_input_slack(ctx, >= 128);
  * BP positions per tile, PS position splits).  The forms 7, 8 and 9 are exempt from the rule
- * below: where their layout requirements are not met the call takes the cost model's choice.  The setting holds for every following
+ * below: where their layout requirements are not met the call takes the cost model's choice --
+ * a FALLBACK, which e2_last_launch() reports as such and e2_tiling_fallbacks() counts (the tuning
+ * keys hold the row pitch, not the plane pitch, so a shipped entry can meet a view it cannot
+ * run; a caller that wants the error checks e2_last_launch after the call).  The setting holds for every following
  * launch of that kind on this context until changed; cfg NULL or "" returns the choice
  * to the library's cost model.  A tiling the problem cannot use (LDS, instance list)
  * makes the launch fail with an error, never silently fall back.  A launch captured
  * into a graph keeps the tiling that was set at capture time. */
 int  e2_set_tiling(e2_ctx* ctx, int kind, const char* cfg);
+/* Which kernel the last conv GEMM launch of this context ran (packed forward / data gradient /
+ * UpConv, weight gradient, f32 and bf16 forms; same seam: Theano reports the chosen `algo` of a
+ * dnn conv op in its profile, computations.py:30,391).  buf receives
+ * "<kernel family> <tiling that ran> <source>", e.g. "wgrad_ks 13,2,9,0,4 forced":
+ *   family: igemm | igemm_bf16r | igemm_generic | igemm4 | pw_gemm | conv_bf16 |
+ *           wgrad_ks | pw_wgrad_ks | pw_wgrad | wgrad_direct | wgrad_direct_bf16r | wgrad_lds |
+ *           wgrad_bf16
+ *   source: "forced"   = the e2_set_tiling string was honoured,
+ *           "model"    = no string was set, the library's cost model chose,
+ *           "fallback" = a string was set but this launch could not run it and took the cost
+ *                        model's choice (weight-gradient forms 7 / 8 / 9 only; every other
+ *                        unrunnable string is an ERROR of the launch).
+ * Host-side bookkeeping, legal during capture; "" before the first launch.
+ * e2_tiling_fallbacks: number of "fallback" launches since e2_ctx_create. */
+int  e2_last_launch(e2_ctx* ctx, char* buf, int n);
+unsigned e2_tiling_fallbacks(const e2_ctx* ctx);
 
 /* ---- conv  (computations.py:364-428 conv(), 3-D branch; F1: true
  *      convolution, kernel flipped in every spatial dim, 'valid') --------- */

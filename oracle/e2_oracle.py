@@ -173,19 +173,24 @@ def bias_act_bwd(dout, y, b, act='relu'):
 # --------------------------------------------------------------------------
 # Conv node = conv -> pool -> +bias -> act   (neural.py:662-712, F3)
 # --------------------------------------------------------------------------
-def conv_node_fwd(x, w, b, pool=(1, 1, 1), act='relu'):
-    c = conv3d_fwd(x, w)
+def conv_node_fwd(x, w, b, pool=(1, 1, 1), act='relu', rnd=None):
+    """``rnd``: optional rounding of the GEMM's two operands (the bf16 row: operands
+    rounded to bf16, accumulation and every tensor in memory unrounded); None = the reference's
+    float arithmetic."""
+    r = rnd if rnd is not None else (lambda a: a)
+    c = conv3d_fwd(r(x), r(w))
     p = maxpool3d_fwd(c, pool)
     return bias_act_fwd(p, b, act), (c, p)
 
 
 def conv_node_bwd(dout, x, w, b, cache, pool=(1, 1, 1), act='relu',
-                  need_dx=True):
+                  need_dx=True, rnd=None):
+    r = rnd if rnd is not None else (lambda a: a)
     c, p = cache
     dp, db = bias_act_bwd(dout, p, b, act)
     dc = maxpool3d_bwd(dp, c, pool)
-    dw = conv3d_wgrad(dc, x, w.shape)
-    dx = conv3d_dgrad(dc, w, x.shape) if need_dx else None
+    dw = conv3d_wgrad(r(dc), r(x), w.shape)
+    dx = conv3d_dgrad(r(dc), r(w), x.shape) if need_dx else None
     return dx, dw, db
 
 
@@ -428,19 +433,22 @@ def init_net(spec, n_in=1, seed=1):
     return params
 
 
-def net_fwd(spec, params, x):
+def net_fwd(spec, params, x, rnd=None, rnd_layers=None):
+    """``rnd`` / ``rnd_layers``: operand rounding (conv_node_fwd) for the layers whose index is in
+    ``rnd_layers`` (default: all)"""
     caches = []
     h = np.asarray(x, F64)
-    for (n_f, k, p, act), (w, b) in zip(spec, params):
-        out, cache = conv_node_fwd(h, w, b, p, act)
+    for i, ((n_f, k, p, act), (w, b)) in enumerate(zip(spec, params)):
+        ri = rnd if (rnd is not None and (rnd_layers is None or i in rnd_layers)) else None
+        out, cache = conv_node_fwd(h, w, b, p, act, rnd=ri)
         caches.append((h, cache))
         h = out
     return h, caches
 
 
-def net_loss_and_grads(spec, params, x, target):
+def net_loss_and_grads(spec, params, x, target, rnd=None, rnd_layers=None):
     """loss (softmax+NLL+aggregate) and gradients wrt every (w, b)."""
-    logits, caches = net_fwd(spec, params, x)
+    logits, caches = net_fwd(spec, params, x, rnd=rnd, rnd_layers=rnd_layers)
     loss, dlogits, probs = nll_loss_and_grad(logits, target)
     grads = [None] * len(spec)
     d = dlogits
@@ -448,8 +456,9 @@ def net_loss_and_grads(spec, params, x, target):
         n_f, k, p, act = spec[i]
         w, b = params[i]
         h, cache = caches[i]
+        ri = rnd if (rnd is not None and (rnd_layers is None or i in rnd_layers)) else None
         d, dw, db = conv_node_bwd(d, h, np.asarray(w, F64), b, cache, p, act,
-                                  need_dx=(i > 0))
+                                  need_dx=(i > 0), rnd=ri)
         grads[i] = (dw, db)
     return loss, grads, probs
 

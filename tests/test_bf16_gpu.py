@@ -471,50 +471,171 @@ def test_wgrad_bf16_with_ready_made_operands(ctx, case, tile):
         ctx.set_tiling("wgrad", None)
 
 
-def _lite_steps(n_steps, sp=(9, 71, 71), ahead=True, use_graph=True, net="neuro3d_lite"):
-    """n training steps of a small-input neuro3d_lite / neuro3d in bf16 mode with every conv launch
-    pinned to the kernels with bf16 operands in memory; returns (losses, parameters, launches)"""
-    from elektronn2_amd import nets, autotune, neuromancer as nm
+# ---- the bf16 STEP: operands made ahead (bf16_ahead.py) against the converting form -------------
+# What round 4 asserted here -- four Adam steps of both forms agreeing to 2e-5 -- failed once on the
+# driver's box (4th loss off by 8.75e-5) and was the wrong object to bound: tools/bf16_ahead_diag.py
+# (gpurun_out/r5a/diag_neuro3d.log, DESIGN finding 45) shows
+#   * forward outputs and output gradients of the two forms are BIT-identical, run after run,
+#   * parameter gradients differ by <= 2.4e-7 of their largest element -- between the two forms
+#     exactly as between two runs of ONE form (the f32 atomics of the weight / bias gradients),
+#   * the same one-step gradients sit 1e-2 away from the f64 oracle fed with bf16-rounded operands,
+#     although every single kernel holds 2e-5 against it: a chain of layers that each round their
+#     input to 8 bits amplifies f32-order noise to bf16 size within four layers (an activation
+#     1e-7 off lands on the other side of a bf16 rounding boundary with probability 1e-7 * 2^8,
+#     each flip moves it by 2^-8).  A trajectory of such steps is chaotic at the 1e-4 level.
+# So the claims are tested where they are exact: ONE evaluation, tensor by tensor, bits; the step
+# against the oracle LAYER BY LAYER on the tensors the HIP pass itself produced (no amplification:
+# the kernel bound 2e-5 holds); and the multi-step run only for what it can show -- that no
+# operand goes stale across optimiser steps (a stale image moves the loss by 1e-2 and more).
+PIN_I, PIN_W = "32,1,2", "32,1,2,0,1"        # (S = 1: one writer per element of the wgrad sums)
+
+
+def _bf16_net(net, sp, ahead, seed=3):
+    from elektronn2_amd import nets, neuromancer as nm
     nm.model_manager.reset()
-    os.environ["E2_BF16_AHEAD"] = "1" if ahead else "0"
     spec = O.NEURO3D_LITE if net == "neuro3d_lite" else O.NEURO3D
-    params = O.init_net(spec, 1, seed=3)
+    params = O.init_net(spec, 1, seed=seed)
     rng = np.random.RandomState(5)
     x = rng.rand(1, 1, *sp).astype(np.float32)
     t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
-    m = getattr(nets, net)((None, 1) + sp, params=params)
-    m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
-    autotune.force('igemm', "32,1,2")
-    autotune.force('wgrad', "32,1,2,0,0")
-    try:
-        opt = m.optimisers['Adam']
-        opt.step.compile()
-        opt.step.func.use_graph = use_graph
-        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(n_steps)]
-        plan = opt.step.func
-        kinds = sorted(set(k for (_, k) in plan.bf16a))
-        ps = [p.detach().cpu().numpy().copy() for p in m.device_params_list()] \
-            if hasattr(m, 'device_params_list') else [plan.model.P.detach().cpu().numpy().copy()]
-    finally:
+    with nm.plan_options(bf16_ahead=ahead, bf16_ahead_min=0.0):
+        m = getattr(nets, net)((None, 1) + sp, params=params)
+        m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        m.optimisers['Adam'].step.compile()          # (plans snapshot the options when constructed)
+        m._grad_func.compile()
+    return m, spec, params, x, t
+
+
+class _pinned(object):
+    """every conv launch pinned to the kernels with bf16 operands in memory"""
+    def __enter__(self):
+        from elektronn2_amd import autotune
+        autotune.force('igemm', PIN_I)
+        autotune.force('wgrad', PIN_W)
+
+    def __exit__(self, *a):
+        from elektronn2_amd import autotune
         autotune.force('igemm', None)
         autotune.force('wgrad', None)
-        os.environ.pop("E2_BF16_AHEAD", None)
-    return losses, ps, kinds
+
+
+def _one_evaluation(net, sp, ahead, calls=1):
+    """`calls` gradient evaluations (the 1st eager, the 2nd captured, then replays); returns the
+    last one's node outputs, output gradients, parameter gradients and the launch kinds"""
+    m, spec, params, x, t = _bf16_net(net, sp, ahead)
+    with _pinned():
+        for _ in range(calls):
+            g = m.gradients(x, t)
+    plan = m._grad_func.func
+    torch.cuda.synchronize()
+    outs = {n.name: plan.out[n].detach().cpu().numpy().copy() for n in plan.nodes if plan.out.get(n) is not None}
+    douts = {n.name: plan.grad[n].detach().cpu().numpy().copy() for n in plan.nodes if plan.grad.get(n) is not None}
+    names = list(m.loss_node.all_trainable_params.keys())
+    ys = {n.name: plan.scratch[n, 'y'].detach().cpu().numpy().copy() for n in plan.nodes if (n, 'y') in plan.scratch}
+    return dict(outs=outs, douts=douts, ys=ys, g=dict(zip(names, g)), kinds=sorted(set(k for (_, k) in plan.bf16a)),
+                plan=plan, model=m, spec=spec, params=params, x=x, t=t)
 
 
 @pytest.mark.parametrize("net,sp", [("neuro3d_lite", (9, 71, 71)), ("neuro3d", (23, 121, 121))])
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_step_with_operands_made_ahead_equals_the_converting_step(process_bf16, net, sp, use_graph):
-    """the same bf16 step with the GEMM operands written by their producers (bf16_ahead.py) and
-    with every launch converting for itself: the images are bit-identical, so losses and
-    parameters agree to the weight gradients' atomic summation order"""
-    l0, p0, k0 = _lite_steps(4, sp=sp, ahead=False, use_graph=use_graph, net=net)
-    l1, p1, k1 = _lite_steps(4, sp=sp, ahead=True, use_graph=use_graph, net=net)
+@pytest.mark.parametrize("calls", [1, 3], ids=["eager", "replay"])
+def test_operands_made_ahead_give_the_converting_steps_tensors(process_bf16, net, sp, calls):
+    """ONE gradient evaluation of the bf16 step with the GEMM operands written by their producers
+    and with every launch converting for itself: every node output and every output gradient is
+    bit-identical (forward and data gradients have no atomics), every parameter gradient agrees to
+    the f32 atomics of the weight / bias sums (measured <= 2.4e-7 of the tensor's largest element,
+    the same between two runs of one form; bound 2e-6)"""
+    A = _one_evaluation(net, sp, False, calls)
+    B = _one_evaluation(net, sp, True, calls)
+    assert A['kinds'] == [] and {'fwd', 'dgrad', 'wgrad', 'dy', 'next'} <= set(B['kinds']), (A['kinds'], B['kinds'])
+    for what in ("outs", "douts"):
+        assert set(A[what]) == set(B[what])
+        for name in A[what]:
+            a, b = A[what][name], B[what][name]
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), \
+                "%s of %s: %d words differ" % (what, name, int((a.view(np.int32) != b.view(np.int32)).sum()))
+    for name, ga in A['g'].items():
+        gb = B['g'][name]
+        assert np.isfinite(gb).all()
+        assert np.abs(gb - ga).max() <= 2e-6 * max(np.abs(ga).max(), 1e-30), name
+
+
+@pytest.mark.parametrize("ahead", [False, True], ids=["converting", "ahead"])
+def test_bf16_step_layer_by_layer_against_the_oracle(process_bf16, ahead):
+    """Step-level bf16 parity against oracle/e2_oracle.py, without the
+    amplification a deep chain of bf16 roundings applies to f32-order noise: every layer of ONE
+    gradient evaluation of neuro3d_lite is checked on the tensors the HIP pass itself produced --
+    forward: oracle conv(bf16(x_hip), bf16(w)) -> pool -> bias -> relu against the node's output;
+    backward: the pre-activation gradient dc the oracle derives from the HIP output gradient, then
+    dgrad(bf16(dc), bf16(w)) against the parent's HIP output gradient and wgrad(bf16(dc),
+    bf16(x_hip)) / sum(dc) against the HIP parameter gradients -- all at the kernels' 2e-5 (of the
+    tensor's largest element).  The fused first layer and the classifier head compute in f32."""
+    R = _one_evaluation("neuro3d_lite", (9, 71, 71), ahead)
+    spec, params, plan, m = R['spec'], R['params'], R['plan'], R['model']
+    convs = [n for n in plan.nodes if type(n).__name__ == 'Conv']
+    assert len(convs) == len(spec)
+    src = {n.name: n.parent.name for n in convs}
+    f64 = lambda a: np.asarray(a, np.float64)
+    worst = {}
+    for i, (node, (n_f, k, p, act), (w, b)) in enumerate(zip(convs, spec, params)):
+        last = i == len(spec) - 1
+        rnd = (lambda a: a) if (i == 0 or last) else bf16_round          # first layer / head: f32
+        x_hip = f64(R['outs'][src[node.name]])
+        if last:
+            # the head's logits are never materialised: softmax output against the oracle's
+            logits = O.conv3d_fwd(x_hip, w) + np.asarray(b, np.float64).reshape(1, -1, 1, 1, 1)
+            sm = [n for n in plan.nodes if type(n).__name__ == 'Softmax'][0]
+            worst['fwd softmax'] = relerr(torch.tensor(R['outs'][sm.name]), O.softmax(logits))
+            loss, dlogits, _ = O.nll_loss_and_grad(logits, R['t'])
+            dc = dlogits
+        else:
+            out_ref, (c, pooled) = O.conv_node_fwd(rnd(x_hip), rnd(w), b, p, act)
+            out_hip = R['outs'][node.name]
+            worst['fwd ' + node.name] = relerr(torch.tensor(out_hip), out_ref)
+            # the backward takes the DECISIONS of the HIP pass (which unit is active, which
+            # element of a window is the largest): a pre-activation within f32 rounding of zero
+            # may fall on the other side in float64, and that is not what is under test here
+            if node.name in R['ys']:                   # the pre-pool conv output was kept
+                c = f64(R['ys'][node.name])
+                worst['conv ' + node.name] = relerr(torch.tensor(R['ys'][node.name]), O.conv3d_fwd(rnd(x_hip), rnd(w)))
+                pooled = O.maxpool3d_fwd(c, p)
+                dp, _ = O.bias_act_bwd(f64(R['douts'][node.name]), pooled, b, act)
+            else:                                      # slope off the stored activations (signed zeros)
+                pre = np.where(out_hip > 0, 1.0, np.where(np.signbit(out_hip), -1.0, 0.0))
+                dp, _ = O.bias_act_bwd(f64(R['douts'][node.name]), pre, np.zeros_like(np.asarray(b, np.float64)), act)
+            dc = O.maxpool3d_bwd(dp, c, p)
+        dw_ref = O.conv3d_wgrad(rnd(dc), rnd(x_hip), np.shape(w))
+        worst['dW ' + node.name] = relerr(torch.tensor(R['g'][node.name + '_w']), dw_ref)
+        worst['db ' + node.name] = relerr(torch.tensor(R['g'][node.name + '_b']), dc.sum(axis=(0, 2, 3, 4)))
+        if i > 0:
+            dx_ref = O.conv3d_dgrad(rnd(dc), rnd(w), x_hip.shape)
+            worst['dx ' + node.name] = relerr(torch.tensor(R['douts'][src[node.name]]), dx_ref)
+    bad = {k: v for k, v in worst.items() if not v < TOL}
+    assert not bad, bad
+    assert len(worst) >= 4 * len(spec) - 2
+
+
+@pytest.mark.parametrize("net,sp", [("neuro3d_lite", (9, 71, 71)), ("neuro3d", (23, 121, 121))])
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_no_operand_goes_stale_across_optimiser_steps(process_bf16, net, sp, use_graph):
+    """four Adam steps in both forms: the images written once per plan (borders, padding channel
+    groups, gaps, the wgrad sums) and the ones rewritten every step (filter rows after the update,
+    the kept input copies) stay right -- a stale operand moves a loss by 1e-2 and more (the loss
+    falls 40 % per step here).  NOT a bit-level claim: the trajectory of a bf16 step amplifies
+    the f32 atomics' noise (header comment; driver r4: 8.75e-5 on the 4th loss), bounds 2e-3."""
+    res = []
+    for ahead in (False, True):
+        m, spec, params, x, t = _bf16_net(net, sp, ahead)
+        with _pinned():
+            plan = m.optimisers['Adam'].step.func
+            plan.use_graph = use_graph
+            losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(4)]
+        res.append((losses, plan.model.P.detach().cpu().numpy().copy(), sorted(set(k for (_, k) in plan.bf16a))))
+    (l0, p0, k0), (l1, p1, k1) = res
     assert k0 == [] and {'fwd', 'dgrad', 'wgrad', 'dy', 'next'} <= set(k1), (k0, k1)
-    assert np.isfinite(l1).all()
-    np.testing.assert_allclose(l1, l0, rtol=2e-5)
-    for a, b in zip(p1, p0):
-        assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30) + 1e-7
+    assert np.isfinite(l1).all() and l1[-1] < 0.6 * l1[0]
+    assert abs(l1[0] - l0[0]) <= 1e-6 * abs(l0[0])          # the first forward pass: the same bits
+    np.testing.assert_allclose(l1, l0, rtol=2e-3)
+    assert np.abs(p1 - p0).max() <= 2e-3 * np.abs(p0).max()
 
 
 @pytest.mark.parametrize("k,pool,cout,sp", [((1, 4, 4), (1, 2, 2), 20, (3, 35, 73)), ((1, 6, 6), (1, 2, 2), 20, (2, 37, 41)),

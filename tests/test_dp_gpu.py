@@ -3,7 +3,7 @@ rank): the data-parallel training step of the launch plan.
 
   * replicas stay bit-identical over Adam steps,
   * the sliced exchange overlapped with the backward pass (plan._dp_cut, on by default)
-    and the single all-reduce (E2_DP_OVERLAP=0) give the same parameters,
+    and the single all-reduce (plan option dp_overlap=False) give the same parameters,
   * both equal the torch-CPU port of the oracle stepping on the hand-averaged gradients
     of the two ranks' batches.
 """
@@ -39,7 +39,7 @@ def _worker(rank, world, port, q):
     x, t = _data(rank)
     out = {}
     for overlap in ("1", "0"):
-        os.environ["E2_DP_OVERLAP"] = overlap
+        nm.set_plan_options(dp_overlap=overlap == "1")
         nm.model_manager.reset()
         m = nets.neuro3d_lite((None, 1) + SP, params=O.init_net(O.NEURO3D_LITE, 1, seed=5))
         m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
@@ -115,7 +115,7 @@ def _ragged_worker(rank, world, port, q):
     x, t = _ragged_data(rank)
     out = {}
     for fused in ("1", "0"):
-        os.environ["E2_DP_FUSED_SCALE"] = fused
+        nm.set_plan_options(dp_fused_scale=fused == "1")
         nm.model_manager.reset()
         m = nets.neuro3d_lite((None, 1) + SP, params=O.init_net(O.NEURO3D_LITE, 1, seed=5))
         m.set_opt_meta_params('SGD', dict(lr=1e-2, mom=0.9, wd=0.0))
@@ -197,7 +197,7 @@ def _rccl_worker(port, q):
     t.flat[::7] = -1                              # some unlabelled voxels: the count rides along
     out = {}
     for mode in ("plain", "rccl-overlap", "rccl-single"):
-        os.environ["E2_DP_OVERLAP"] = "0" if mode == "rccl-single" else "1"
+        nm.set_plan_options(dp_overlap=mode != "rccl-single")
         nm.model_manager.reset()
         m = nets.neuro3d_lite((None, 1) + SP, params=O.init_net(O.NEURO3D_LITE, 1, seed=5))
         m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))

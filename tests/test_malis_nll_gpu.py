@@ -117,13 +117,11 @@ def test_training_steps_graph_replay_matches_eager_and_learns():
     x, aff_gt, seg_gt = _inputs(3)
     finals, losses = [], []
     for no_graph in ("0", "1"):
-        os.environ["E2_NO_GRAPH"] = no_graph
-        try:
+        from elektronn2_amd.neuromancer import plan_options
+        with plan_options(graph=no_graph == "0"):
             m, nll = _build(_params(4))
             ls = [float(m.trainingstep(x, aff_gt, seg_gt, optimiser='Adam')[0])
                   for _ in range(40)]
-        finally:
-            os.environ.pop("E2_NO_GRAPH", None)
         finals.append(m.P.cpu().numpy().copy())
         losses.append(ls)
         assert np.isfinite(ls).all()

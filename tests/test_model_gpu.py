@@ -86,10 +86,11 @@ def test_activation_backward_fused_into_the_consumers_dgrad(name, spec, sp, monk
     t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
     res = {}
     for fuse in ("0", "1"):
-        monkeypatch.setenv("E2_FUSE_ACTBWD", fuse)
-        m = build(name, sp, params)
-        g = m.gradients(x, t)
-        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(3)]
+        from elektronn2_amd.neuromancer import plan_options
+        with plan_options(fuse_actbwd=int(fuse)):
+            m = build(name, sp, params)
+            g = m.gradients(x, t)
+            losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(3)]
         res[fuse] = (g, losses, [p.get_value() for p in m.loss_node.all_trainable_params.values()])
         plan = m.optimisers['Adam'].step.func
         assert bool(plan.fuse_actbwd) == (fuse == "1")

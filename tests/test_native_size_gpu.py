@@ -222,6 +222,31 @@ def check_against_f64(model, x, t, adam=True, same_decisions=False):
         assert relmax(p.get_value(), ref) < TOL, k
 
 
+class shipped_tilings_honoured(object):
+    """every launch inside the block ran the tiling the table (or a pin) asked for: the library
+    reports the kernel family and tiling of each launch (e2_last_launch) and autotune collects
+    the ones that fell back to the cost model"""
+
+    def __enter__(self):
+        from elektronn2_amd import autotune
+        self.at = autotune
+        del autotune.fallbacks[:]
+        autotune.launch_log = self.log = []
+        return self.log
+
+    def __exit__(self, *exc):
+        self.at.launch_log = None
+        if exc[0] is None:
+            assert not self.at.fallbacks, "table entries the launches could not run: %s" % self.at.fallbacks
+            asked = [(k, til, ll) for (k, til, ll) in self.log if til]
+            assert asked, "no launch went through the tiling table"
+            for k, til, ll in asked:
+                assert ll is not None and ll[2] == "forced", (k, til, ll)
+                if til.split(",")[2:3] == ["9"] and k.startswith("wgrad"):
+                    assert ll[0] == "wgrad_ks" and ll[1] == til, (k, til, ll)
+        return False
+
+
 CASES = [('lite', (23, 183, 183)), ('full', (23, 185, 185))]
 
 
@@ -238,11 +263,14 @@ def test_benchmark_shapes_with_shipped_tilings(name, sp):
     t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
     t.flat[::23] = -1
     shipped = dict(autotune._load())
-    check_against_f64(model, x, t)
+    with shipped_tilings_honoured() as log:
+        check_against_f64(model, x, t)
     # every conv launch of these two workloads found its tiling in the shipped table
     # (nothing was tuned on the fly, so what ran is what bench.py runs)
     new = {k: v for k, v in autotune._load().items() if k not in shipped}
     assert not new, "tilings tuned on the fly (not in tuned.json): %s" % sorted(new)
+    # ... and the position-split weight-gradient GEMM is among what ran (finding 44)
+    assert sum(1 for (_, til, ll) in log if ll[0] == "wgrad_ks") >= (4 if name == 'lite' else 8)
 
 
 def test_unet3d_lite_native_size():
@@ -258,7 +286,8 @@ def test_unet3d_lite_native_size():
     rng = np.random.RandomState(6)
     x = rng.rand(1, 1, 22, 140, 140).astype(np.float32)
     t = rng.randint(0, 2, (1, 1, 10, 52, 52)).astype(np.float32)
-    check_against_f64(model, x, t, adam=False, same_decisions=True)
+    with shipped_tilings_honoured():
+        check_against_f64(model, x, t, adam=False, same_decisions=True)
     pre64, poolin64 = check_against_f64.f64_state
     names = list(model.loss_node.all_trainable_params.keys())
     L0 = float(model.loss(x, t))
@@ -291,7 +320,8 @@ def test_unet3d_full_native_size():
     rng = np.random.RandomState(8)
     x = rng.rand(1, 1, 116, 132, 132).astype(np.float32)
     t = rng.randint(0, 2, (1, 1, 28, 44, 44)).astype(np.float32)
-    check_against_f64(model, x, t, adam=False, same_decisions=True)
+    with shipped_tilings_honoured():
+        check_against_f64(model, x, t, adam=False, same_decisions=True)
     # replayed graphs reproduce the eager result
     L0 = float(model.loss(x, t))
     for _ in range(3):

@@ -541,23 +541,70 @@ def test_conv3d_wgrad_as_position_split_gemm(ctx, force, ci, co, k, sp):
     xd = xflat[:x.size].view(x.shape)
     xd.copy_(dev(x))
     ctx.set_tiling("wgrad", force)
+    ctx.allowed_fallbacks = 1
     try:
-        # without the promise the tiling is not offered: the library's own choice runs
+        # without the promise the tiling is not offered: the library's own choice runs -- and
+        # e2_last_launch says so (a fallback, another kernel family)
         ctx.conv3d_wgrad_pad(xd, dyp, dw)
         assert relerr(dw, dw_ref) < TOL
+        fam, til, src = ctx.last_launch()
+        assert src == "fallback" and fam != "wgrad_ks", (fam, til, src)
         ctx.set_input_slack(128)
         dw.fill_(float("nan"))
         ctx.conv3d_wgrad_pad(xd, dyp, dw)
         assert relerr(dw, dw_ref) < TOL
+        assert ctx.last_launch() == ("wgrad_ks", force, "forced")     # pw_wgrad_ks_kernel<MT,NT,true> ran
         ctx.conv3d_wgrad_pad(xd, dyp, dw, accumulate=True)
         assert relerr(dw, 2 * dw_ref) < TOL
+        assert ctx.last_launch() == ("wgrad_ks", force, "forced")
         wide = torch.full((N, ci + 4) + tuple(sp), 1e30, device="cuda")   # (a channel slice: more of the buffer follows)
         wide[:, 1:1 + ci] = dev(x)
         dw.fill_(float("nan"))
         ctx.conv3d_wgrad_pad(wide[:, 1:1 + ci], dyp, dw)
         assert relerr(dw, dw_ref) < TOL
+        assert ctx.last_launch() == ("wgrad_ks", force, "forced")
     finally:
         ctx.set_input_slack(0)
+        ctx.set_tiling("wgrad", None)
+
+
+def test_an_unrunnable_forced_wgrad_tiling_is_reported_not_hidden(ctx):
+    """"13,2,9,0,4" on a problem that does not qualify for the position-split
+    GEMM -- (kh - 1) rows + kw - 1 = 11 zeros behind a gradient plane where 31 are needed -- takes
+    the cost model's choice (the documented exemption of the forms 7 / 8 / 9, e2hip.h), and
+    e2_last_launch / e2_tiling_fallbacks say so; any OTHER string the launch cannot run is an
+    error, never a fallback"""
+    from elektronn2_amd.backend import E2Error
+    rng = np.random.RandomState(4)
+    k = (1, 2, 2)
+    x = rng.rand(1, 8, 2, 9, 10).astype(np.float32)
+    dy = rng.randn(1, 16, 2, 8, 9).astype(np.float32)
+    ref = O.conv3d_wgrad(dy, x, (16, 8) + k)
+    dyp = _plan_style_padded(dy, k)
+    xflat = torch.zeros(x.size + 32, device="cuda")
+    xd = xflat[:x.size].view(x.shape)
+    xd.copy_(dev(x))
+    dw = torch.full(ref.shape, float("nan"), device="cuda")
+    n0 = ctx.tiling_fallbacks()
+    ctx.set_tiling("wgrad", "13,2,9,0,4")
+    ctx.allowed_fallbacks = 1
+    ctx.set_input_slack(128)
+    try:
+        ctx.conv3d_wgrad_pad(xd, dyp, dw)
+        fam, til, src = ctx.last_launch()
+        assert src == "fallback" and fam != "wgrad_ks" and til != "13,2,9,0,4", (fam, til, src)
+        assert ctx.tiling_fallbacks() == n0 + 1
+        assert relerr(dw, ref) < TOL
+    finally:
+        ctx.set_input_slack(0)
+        ctx.set_tiling("wgrad", None)
+    ctx.conv3d_wgrad_pad(xd, dyp, dw)                     # no string set: the cost model, by name
+    assert ctx.last_launch()[2] == "model"
+    ctx.set_tiling("wgrad", "6,3,1,128,2")                # no such instance of the direct kernel
+    try:
+        with pytest.raises(E2Error):
+            ctx.conv3d_wgrad_pad(xd, dyp, dw)
+    finally:
         ctx.set_tiling("wgrad", None)
 
 
@@ -618,10 +665,14 @@ def test_conv3d_pointwise_wgrad_gemm(ctx, force, Ci, Co, N, sp):
     dyp = flat[:dy.size].view(dy.shape)                   # is the gradient itself + its slack)
     dyp.copy_(dev(dy))
     dw = torch.full((Co, Ci) + k, float("nan"), device="cuda")
+    fam = "pw_wgrad" if force.split(",")[2] == "7" else "pw_wgrad_ks"
+    fb0 = ctx.tiling_fallbacks()
     ctx.set_tiling("wgrad", force)
+    ctx.allowed_fallbacks = 2                 # (the two cropped views at the end)
     try:
         ctx.conv3d_wgrad_pad(dev(x), dyp, dw)
         assert relerr(dw, ref) < TOL
+        assert ctx.last_launch() == (fam, force, "forced")
         ctx.conv3d_wgrad_pad(dev(x), dyp, dw, accumulate=True)
         assert relerr(dw, 2 * ref) < TOL
         # x as a channel slice of a wider buffer (a concat input): planes stay dense
@@ -629,6 +680,7 @@ def test_conv3d_pointwise_wgrad_gemm(ctx, force, Ci, Co, N, sp):
         wide[:, 3:3 + Ci] = dev(x)
         ctx.conv3d_wgrad_pad(wide[:, 3:3 + Ci], dyp, dw)
         assert relerr(dw, ref) < TOL
+        assert ctx.last_launch() == (fam, force, "forced") and ctx.tiling_fallbacks() == fb0
         # views whose rows or planes are not dense (a crop of the parent: the tuning keys
         # hold the row pitch only, so a shipped "...,7,..." entry can meet one) are never
         # mis-read: the call takes the library's own tiling instead
@@ -637,11 +689,13 @@ def test_conv3d_pointwise_wgrad_gemm(ctx, force, Ci, Co, N, sp):
         dw.fill_(float("nan"))
         ctx.conv3d_wgrad_pad(crop[..., 1:-1], dyp, dw)
         assert relerr(dw, ref) < TOL
+        assert ctx.last_launch()[2] == "fallback" and not ctx.last_launch()[0].startswith("pw_wgrad")
         crop2 = torch.zeros((N, Ci, sp[0], sp[1] + 3, sp[2]), device="cuda")   # rows dense, planes not
         crop2[:, :, :, 2:-1] = dev(x)
         dw.fill_(float("nan"))
         ctx.conv3d_wgrad_pad(crop2[:, :, :, 2:-1], dyp, dw)
         assert relerr(dw, ref) < TOL
+        assert ctx.last_launch()[2] == "fallback" and ctx.tiling_fallbacks() == fb0 + 2
     finally:
         ctx.set_tiling("wgrad", None)
 

@@ -294,7 +294,7 @@ def test_concat_slices_as_parent_buffers_change_nothing(monkeypatch):
     its output into the concat buffer and reads its gradient from the concat gradient, a Crop
     reads its gradient slice; node_basic.Concat._plan_alloc, reference node_basic.py:1403-1451)
     and the UpConv images ride in the step's one repack launch.  Same seed, same batches:
-    the copying / per-call-packing form (E2_CONCAT_ALIAS=0, E2_UPCONV_PACKED=0) and the
+    the copying / per-call-packing form (plan options concat_alias / upconv_packed off) and the
     shipped form give the same loss, gradients and 8 Adam steps (graph replay included) --
     to summation order of the weight gradients' atomics only."""
     sp, osp = (7, 30, 30), (3, 16, 16)
@@ -303,26 +303,26 @@ def test_concat_slices_as_parent_buffers_change_nothing(monkeypatch):
     t = rng.randint(0, 2, (2, 1) + osp).astype(np.int16)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("E2_CONCAT_ALIAS", mode)
-        monkeypatch.setenv("E2_UPCONV_PACKED", mode)
-        np.random.seed(21)
-        nm, inp, probs = small_unet(sp, n_out=2, batch=2)
-        tgt = nm.Input((2, 1) + osp, 'b,f,z,x,y', name='target', dtype='int16')
-        nll = nm.MultinoulliNLL(probs, tgt, target_is_sparse=True)
-        loss = nm.AggregateLoss(nll)
-        m = nm.model_manager.getmodel()
-        m.designate_nodes(input_node=inp, target_node=tgt, loss_node=loss, prediction_node=probs)
-        m.set_opt_meta_params('Adam', dict(lr=2e-3, mom=0.9, beta2=0.999, wd=0.5e-4))
-        l0 = float(m.loss(x, t))
-        g = m.gradients(x, t)
-        steps = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(8)]
-        params = np.concatenate([p.get_value().ravel() for p in m.loss_node.all_trainable_params.values()])
-        concat = [n for n in m.nodes.values() if type(n).__name__ == 'Concat'][0]
-        tplan = m.optimisers['Adam'].step.func
-        res[mode] = dict(l0=l0, g=g, steps=steps, params=params,
-                         alias=dict(tplan.scratch[concat, 'alias']),
-                         packed=any(isinstance(k, tuple) and len(k) == 2 and k[1] == 'wp_d'
-                                    and type(k[0]).__name__ == 'UpConv' for k in tplan.scratch))
+        from elektronn2_amd.neuromancer import plan_options
+        with plan_options(concat_alias=mode == "1", upconv_packed=mode == "1"):
+            np.random.seed(21)
+            nm, inp, probs = small_unet(sp, n_out=2, batch=2)
+            tgt = nm.Input((2, 1) + osp, 'b,f,z,x,y', name='target', dtype='int16')
+            nll = nm.MultinoulliNLL(probs, tgt, target_is_sparse=True)
+            loss = nm.AggregateLoss(nll)
+            m = nm.model_manager.getmodel()
+            m.designate_nodes(input_node=inp, target_node=tgt, loss_node=loss, prediction_node=probs)
+            m.set_opt_meta_params('Adam', dict(lr=2e-3, mom=0.9, beta2=0.999, wd=0.5e-4))
+            l0 = float(m.loss(x, t))
+            g = m.gradients(x, t)
+            steps = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(8)]
+            params = np.concatenate([p.get_value().ravel() for p in m.loss_node.all_trainable_params.values()])
+            concat = [n for n in m.nodes.values() if type(n).__name__ == 'Concat'][0]
+            tplan = m.optimisers['Adam'].step.func
+            res[mode] = dict(l0=l0, g=g, steps=steps, params=params,
+                             alias=dict(tplan.scratch[concat, 'alias']),
+                             packed=any(isinstance(k, tuple) and len(k) == 2 and k[1] == 'wp_d'
+                                        and type(k[0]).__name__ == 'UpConv' for k in tplan.scratch))
     assert res["0"]["alias"] == {} and not res["0"]["packed"]
     kinds = sorted(res["1"]["alias"].values())
     assert kinds == ['grad', 'out+grad'] and res["1"]["packed"], kinds
