@@ -80,7 +80,8 @@ def test_every_candidate_tiling_is_correct(ctx, prob):
         assert all(c.split(",")[2] in ("7", "8", "9") for c, _, _ in fell), fell
         taps, pitch = k[0] * k[1] * k[2], sp[2]
         if (taps > 1 and (k[1] - 1) * pitch + k[2] - 1 >= 31) or taps == 1:
-            assert not fell and ks_ran >= 1, (fell, ks_ran)
+            offered = [c for c in autotune.wgrad_candidates(cout, cin, k, osp) if c.split(",")[2] in ("8", "9")]
+            assert not fell and (ks_ran >= 1 or not offered), (fell, ks_ran, offered)
         ctx.allowed_fallbacks = len(fell)
         ctx.set_input_slack(0)
         ctx.set_tiling("wgrad", None)
