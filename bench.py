@@ -25,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's intra-node
+# transport fails with `hipIpcGetMemHandle: invalid argument` (it is exported on the pool's boxes;
+# set here as well, before anything initialises HIP, so that a bare launcher inherits it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch

@@ -180,6 +180,12 @@ def _load():
         "e2_adam_step": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_sgd_step": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp]),
         "e2_set_loss_grad_mode": (C.c_int, [vp, i, fp]),
+        "e2_upd_job_bytes": (sz, []),
+        "e2_upd_rest_bytes": (sz, []),
+        "e2_upd_job_fill": (C.c_int, [vp, C.c_long, vp, vp, i, i, i, i, i, C.c_float, i,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+        "e2_upd_rest_fill": (C.c_int, [vp, C.c_long, C.c_long, C.c_float]),
+        "e2_adam_pack_step": (C.c_int, [vp, fp, fp, fp, fp, vp, i, i, vp, i, fp, fp, C.c_float, i, sz]),
         "e2_adam_step_ex": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp, fp, C.c_float, i]),
         "e2_sgd_step_ex": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp, fp, C.c_float, i]),
         "e2_graph_begin": (C.c_int, [vp]),
@@ -890,6 +896,41 @@ class Context:
                                   C.c_void_p(seg_off.data_ptr()), _fp(seg_reg),
                                   seg_reg.numel(), _fp(hyper), _fp(gdiv), float(gmul),
                                   int(bool(zero_g))), "e2_adam_step_ex")
+
+    def make_upd_jobs(self, jobs, rests):
+        """records of adam_pack_step.  jobs: (arena offset, forward image | None, data-gradient
+        image | None, (cout, cin, kd, kh, kw), weight-decay multiplier) per conv weight tensor;
+        rests: (arena offset, elements, multiplier) for every other trainable run.  Returns the
+        handle adam_pack_step takes."""
+        rj, rr = int(_lib.e2_upd_job_bytes()), int(_lib.e2_upd_rest_bytes())
+        bj = (C.c_char * max(rj * len(jobs), 1))()
+        br = (C.c_char * max(rr * len(rests), 1))()
+        tile0, lds = 0, 16
+        keep = []
+        for n, (off, wf, wd_, shape, reg) in enumerate(jobs):
+            nt, lb = C.c_int(), C.c_size_t()
+            cout, cin, kd, kh, kw = (int(v) for v in shape)
+            _chk(_lib.e2_upd_job_fill(C.byref(bj, n * rj), int(off),
+                                      C.c_void_p(wf.data_ptr()) if wf is not None else None,
+                                      C.c_void_p(wd_.data_ptr()) if wd_ is not None else None,
+                                      cout, cin, kd, kh, kw, float(reg), tile0, C.byref(nt), C.byref(lb)),
+                 "e2_upd_job_fill")
+            tile0 += nt.value
+            lds = max(lds, int(lb.value))
+            keep += [wf, wd_]
+        for n, (off, cnt, reg) in enumerate(rests):
+            _chk(_lib.e2_upd_rest_fill(C.byref(br, n * rr), int(off), int(cnt), float(reg)), "e2_upd_rest_fill")
+        return dict(jobs=torch.frombuffer(bytearray(bj), dtype=torch.uint8).to(self.device), njobs=len(jobs),
+                    ntiles=tile0, rest=torch.frombuffer(bytearray(br), dtype=torch.uint8).to(self.device),
+                    nrest=len(rests), lds=lds, keep=keep)
+
+    def adam_pack_step(self, p, g, m, s, upd, hyper, gdiv=None, gmul=1.0, zero_g=False):
+        """adam_step + the repack of every conv's weight images in one launch (make_upd_jobs)"""
+        _chk(_lib.e2_adam_pack_step(self.h, _fp(p), _fp(g), _fp(m), _fp(s),
+                                    C.c_void_p(upd['jobs'].data_ptr()), upd['njobs'], upd['ntiles'],
+                                    C.c_void_p(upd['rest'].data_ptr()), upd['nrest'], _fp(hyper),
+                                    _fp(gdiv), float(gmul), int(bool(zero_g)), upd['lds']),
+             "e2_adam_pack_step")
 
     def sgd_step(self, p, g, d, seg_off, seg_reg, hyper, gdiv=None, gmul=1.0, zero_g=False):
         _chk(_lib.e2_sgd_step_ex(self.h, _fp(p), _fp(g), _fp(d), p.numel(),

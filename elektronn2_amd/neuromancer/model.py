@@ -106,6 +106,7 @@ class Model(GraphManager):
         self.debug_outputs = []
         # device state
         self.P = self.G = None
+        self._img_owner = None    # the plan whose optimiser launch last wrote the conv weight images
         self._slots = None          # id(param) -> (offset, size, shape)
         self._ctx = None
         self._dp_group = None
@@ -210,6 +211,7 @@ class Model(GraphManager):
         for p in params:
             o, n, sh = self._slots[id(p)]
             p.bind(self.P[o:o + n].view(sh))
+            p._owner = self           # (set_value tells the model that its parameters changed)
             if p.apply_train:
                 seg_off.append(o)
                 r = p.apply_reg
@@ -262,6 +264,7 @@ class Model(GraphManager):
             from .plan import get_ctx
             self.ensure_arena(get_ctx())
         dist.broadcast(self.P, src=0, group=self._dp_group)
+        self._img_owner = None
         # the broadcast is ordered on the current stream only; plans run on streams of
         # their own -- a one-time host sync keeps the first step from reading P early
         if self.P.is_cuda:

@@ -70,7 +70,7 @@ class Optimiser(object):
         vals = (float(self.global_lr.get_value()), float(self.global_mom.get_value()),
                 float(self._beta2()), float(self.global_weight_decay.get_value()))
         if self._hyper is None:
-            self._hyper = torch.zeros(8, dtype=torch.float32, device=plan.ctx.device)
+            self._hyper = torch.zeros(24, dtype=torch.float32, device=plan.ctx.device)   # ([8..23]: arrival counters of e2_adam_pack_step)
             self._apply_pending_hyper()
         if vals != self._hyper_host:
             self._hyper[:4].copy_(torch.tensor(vals, dtype=torch.float32))
@@ -211,6 +211,11 @@ class Adam(Optimiser):
 
     def device_update(self, plan):
         m = self.model
+        if getattr(plan, '_upd', None) is not None:
+            # the update that also writes the packed conv weight images (csrc/update_pack.hip)
+            plan.ctx.adam_pack_step(m.P, m.G, self.momentum, self.squared_accum, plan._upd,
+                                    self._hyper, **self._grad_scaling(plan))
+            return
         plan.ctx.adam_step(m.P[:m.n_train] if m.n_train < m.P.numel() else m.P, m.G,
                            self.momentum, self.squared_accum, m.seg_off, m.seg_reg,
                            self._hyper, **self._grad_scaling(plan))

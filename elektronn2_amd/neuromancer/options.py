@@ -35,6 +35,9 @@ SPEC = {
     "upconv_packed": ("E2_UPCONV_PACKED", _b, True, "UpConv weight images packed by the plan's one repack launch"),
     "concat_alias": ("E2_CONCAT_ALIAS", _b, True, "a concat hands channel slices to parents only it consumes"),
     "zero_in_update": ("E2_ZERO_IN_UPDATE", _b, True, "the optimiser launch clears the gradient arena (finding 38)"),
+    "adam_pack": ("E2_ADAM_PACK", _b, False,
+                  "the Adam launch writes the packed weight images (e2_adam_pack_step); measured slower "
+                  "than the two launches it replaces (DESIGN finding 46): off"),
     "dp_overlap": ("E2_DP_OVERLAP", _b, True, "exchange the late layers' gradients under the early backward"),
     "dp_fused_scale": ("E2_DP_FUSED_SCALE", _b, True, "collectives only sum, the optimiser kernel normalises"),
     "bf16_ahead": ("E2_BF16_AHEAD", _b, True, "bf16 mode: producers write the GEMM operands (finding 43)"),

@@ -416,10 +416,11 @@ class Plan(object):
                 n._plan_alloc(self)
             if getattr(self.ctx, 'mfma_dtype', 'f32') == 'bf16':
                 self._bf16_ws_alloc()
-            self._pack_dev = None
+            self._pack_dev = self._pack_dev_up = self._upd = None
             if self.pack_jobs:
                 jobs = [(self._w5(self.param(w)), wp, mode) for (w, wp, mode) in self.pack_jobs]
                 self._pack_dev = self.ctx.make_pack_jobs(jobs)
+                self._plan_fused_update(jobs)
         self._graphs = None
         self._segs = None
         self._segs_key = None
@@ -446,8 +447,48 @@ class Plan(object):
         return self._ev_pairs[self._ev_idx][1]
 
     # ---- kernel sequences ----------------------------------------------------------------
+    def _plan_fused_update(self, jobs):
+        """Adam plans: the optimiser launch itself writes the conv weight images
+        (e2_adam_pack_step, csrc/update_pack.hip) -- the repack launch at the head of the step
+        and its second pass over the weights are gone; what stays in `_pack_dev_up` are the UpConv
+        images (other layouts).  The images are then current from step to step as long as nobody
+        else writes the parameters: Model._img_owner names the plan whose last update wrote them,
+        every other writer (set_value, load, broadcast, another optimiser) clears it, and
+        _run_device repacks eagerly, outside the graphs, when it is not this plan."""
+        if self.step != 'Adam' or not self.opt['adam_pack']:
+            return
+        m = self.model
+        by_param, order, up = {}, [], []
+        for (w, wp, mode), (w5, _, _) in zip(self.pack_jobs, jobs):
+            if mode in (0, 1):
+                if id(w) not in by_param:
+                    if not getattr(w, 'apply_train', False) or id(w) not in m._slots:
+                        return                       # (a frozen conv weight: keep the two launches)
+                    by_param[id(w)] = [w, tuple(int(v) for v in w5.shape), None, None]
+                    order.append(id(w))
+                by_param[id(w)][2 + mode] = wp
+            else:
+                up.append((w5, wp, mode))
+        if not order:
+            return
+
+        def mult(p):
+            r = p.apply_reg
+            return float(r) if (r and r is not True) else (1.0 if r else 0.0)
+        ujobs = [(m._slots[k][0], by_param[k][2], by_param[k][3], by_param[k][1], mult(by_param[k][0]))
+                 for k in order]
+        rests = [(m._slots[id(p)][0], m._slots[id(p)][1], mult(p)) for p in m._param_list
+                 if p.apply_train and id(p) not in by_param]
+        self._upd = self.ctx.make_upd_jobs(ujobs, rests)
+        self._pack_dev_up = self.ctx.make_pack_jobs(up) if up else None
+
     def _emit_forward(self):
-        if self._pack_dev is not None:       # all packed weight images, one launch
+        if self._upd is not None:
+            # (conv images: written by this plan's optimiser launch, or by the eager repack of
+            # _run_device when someone else touched the parameters)
+            if self._pack_dev_up is not None:
+                self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev_up), always=True)
+        elif self._pack_dev is not None:     # all packed weight images, one launch
             self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
         self._xb_ready, self._dy_ready = {}, {}
         self._wb_ready = False               # bf16 mode: see ensure_wb
@@ -660,6 +701,10 @@ class Plan(object):
             if self._upd_zeroes_g() and not self.model._g_clean:
                 ctx.fill(self.model.G, 0.0)            # (someone else wrote G: eager, outside the graphs)
             self.model._g_clean = False
+        if self._upd is not None and getattr(self.model, '_img_owner', None) is not self:
+            # (someone else wrote P since this plan's last update -- or this is its first step:
+            # the conv images are packed eagerly, outside the graphs)
+            ctx.conv3d_pack_multi(*self._pack_dev)
         if self._graphs is None:
             from . import bf16_ahead
             bf16_ahead.prepare(self)                   # (allocates: never during a capture)
@@ -705,6 +750,7 @@ class Plan(object):
             ctx.record(self._ev1)
             self._calls += 1
             self.model._g_clean = self._upd_zeroes_g()
+            self.model._img_owner = self if self._upd is not None else None
             return
         ctx.record(self._ev0)
         if not capture:
@@ -721,6 +767,8 @@ class Plan(object):
         self._calls += 1
         if self.training:
             self.model._g_clean = self._upd_zeroes_g()
+            if self.step in ('Adam', 'SGD'):       # (this step wrote P: whose images are current?)
+                self.model._img_owner = self if self._upd is not None else None
 
     # ---- call ----------------------------------------------------------------------------------
     def set_inputs(self, args):

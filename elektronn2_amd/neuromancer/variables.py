@@ -34,6 +34,7 @@ class VariableParam(object):
             value = value.astype(dtype)
         self._host = value
         self._dev = None          # torch view into the model's arena
+        self._owner = None        # the model that owns the arena
 
     # -- device binding -----------------------------------------------------
     def bind(self, dev_view):
@@ -67,6 +68,10 @@ class VariableParam(object):
             import torch
             self._dev.copy_(torch.from_numpy(
                 np.ascontiguousarray(self._host, np.float32)).reshape(self._dev.shape))
+            if self._owner is not None:
+                # (a training plan whose optimiser launch keeps the packed weight images current
+                # must repack before its next step: Plan._plan_fused_update)
+                self._owner._img_owner = None
 
     @property
     def updates(self):

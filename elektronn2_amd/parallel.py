@@ -61,6 +61,7 @@ def init_from_env(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # (dmabuf IPC only on this pool's hosts)
     if torch.cuda.is_available():
         torch.cuda.set_device(local_device(backend))
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)

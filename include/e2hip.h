@@ -453,6 +453,32 @@ int e2_sgd_step_ex(e2_ctx*, float* p, float* g, float* d, size_t n, const int64_
                    const float* seg_reg, int n_seg, const float* hyper, const float* gdiv,
                    float gmul, int zero_g);
 
+/* The Adam update of optimiser.py:301-329 that also WRITES the packed weight images of every
+ * conv (what e2_conv3d_pack_multi does at the head of a step): a work-group owns a tile of one
+ * weight tensor -- 32 output channels x IC input channels x the taps of one kernel plane --,
+ * updates it (arithmetic and order of e2_adam_step_ex: bit-identical p / m / s), and writes the
+ * new values from LDS as the tile of the forward image and of the data-gradient image, each along
+ * its contiguous axis, zeros in the fetched padding exactly where e2_conv3d_pack_multi writes them.
+ * One launch instead of two, the weights read once (csrc/update_pack.hip).
+ *   e2_upd_job_fill: one record per conv weight tensor w[cout][cin][kd][kh][kw] at element offset
+ *     `off` of the arenas; wp_f / wp_d = its e2_conv3d_pack images of mode 0 / 1 (either may be
+ *     NULL); reg = weight-decay multiplier (0 = none); tile0 = tiles of the records before it;
+ *     *ntiles = this record's tiles, *lds_bytes = LDS a launch holding it needs.
+ *   e2_upd_rest_fill: a run of `n` elements at `off` without images (biases, first layer, head,
+ *     UpConv): the plain update.
+ *   e2_adam_pack_step: jobs_dev / rest_dev = device arrays of those records; every trainable
+ *     element must be covered exactly once by the two lists (caller's contract); lds_bytes = the
+ *     largest *lds_bytes; hyper / gdiv / gmul / zero_g as e2_adam_step_ex, except that hyper
+ *     holds 24 floats here ([8..23]: arrival counters, zero before the first launch). */
+size_t e2_upd_job_bytes(void);
+size_t e2_upd_rest_bytes(void);
+int e2_upd_job_fill(void* rec, long off, void* wp_f, void* wp_d, int cout, int cin, int kd, int kh,
+                    int kw, float reg, int tile0, int* ntiles, size_t* lds_bytes);
+int e2_upd_rest_fill(void* rec, long off, long n, float reg);
+int e2_adam_pack_step(e2_ctx*, float* p, float* g, float* m, float* s, const void* jobs_dev,
+                      int njobs, int ntiles, const void* rest_dev, int nrest, float* hyper,
+                      const float* gdiv, float gmul, int zero_g, size_t lds_bytes);
+
 /* ---- step capture (replaces theano.function, graphutils.py:376-387) ---- */
 typedef struct e2_graph e2_graph;
 int e2_graph_begin(e2_ctx*);                 /* hipStreamBeginCapture      */

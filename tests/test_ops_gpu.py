@@ -960,6 +960,94 @@ def test_adam_and_sgd(ctx, n):
     assert relerr(p, out) < 1e-6
 
 
+@pytest.mark.parametrize("gdiv", [False, True])
+def test_adam_step_that_writes_the_packed_images(ctx, gdiv):
+    """e2_adam_pack_step (csrc/update_pack.hip): the Adam update of optimiser.py:301-329 and the
+    repack of every conv's weight images in ONE launch.  Against the two launches it replaces --
+    e2_adam_step_ex, then e2_conv3d_pack_multi on the updated weights -- parameters, both moments,
+    the cleared gradient arena, the published step counter AND both images of every tensor are
+    bit-identical: kernels with 1, 9, 16, 25 taps per plane and 1-3 planes, channel counts off
+    the 32-channel tiles, a tensor with a forward image only, tensors without images (biases, a
+    first-layer weight) between them, weight decay on and off, the data-parallel scaling
+    (gmul / gdiv)."""
+    rng = np.random.RandomState(21)
+    convs = [(40, 20, 3, 3, 3, True, True), (200, 150, 1, 3, 3, True, True), (100, 80, 3, 4, 4, True, True),
+             (40, 30, 1, 5, 5, True, False), (200, 200, 1, 1, 1, True, True), (37, 21, 2, 2, 3, False, True)]
+    # arena: conv weight, its bias, ... + one tensor without images at the front (a first layer)
+    tensors = [("w0", (20, 1, 1, 4, 4), 1.0, None)]
+    for i, (co, ci, kd, kh, kw, f, d) in enumerate(convs):
+        tensors.append(("w%d" % (i + 1), (co, ci, kd, kh, kw), 1.0 if i != 2 else 0.0, (f, d)))
+        tensors.append(("b%d" % (i + 1), (co,), 0.0, None))
+    offs, off = {}, 0
+    for name, sh, reg, _ in tensors:
+        offs[name] = off
+        off += (int(np.prod(sh)) + 3) // 4 * 4
+    n = off
+    P0 = np.zeros(n, np.float32); G0 = np.zeros(n, np.float32)
+    M0 = np.zeros(n, np.float32); S0 = np.zeros(n, np.float32)
+    seg_off, seg_reg = [], []
+    for name, sh, reg, _ in tensors:
+        o, c = offs[name], int(np.prod(sh))
+        P0[o:o + c] = rng.randn(c) * 0.1; G0[o:o + c] = rng.randn(c) * 0.01
+        M0[o:o + c] = rng.randn(c) * 0.01; S0[o:o + c] = rng.rand(c) * 1e-3
+        seg_off.append(o); seg_reg.append(reg)
+    seg_off.append(n)
+    hyp = [5e-4, 0.9, 0.999, 0.5e-4, 3, 0, 0, 0] + [0] * 16     # (e2_adam_pack_step: 24 floats)
+    count = dev([1234.0]) if gdiv else None
+    kw = dict(gdiv=count, gmul=1.0 if gdiv else 0.125, zero_g=True)
+
+    def images(Pdev):
+        """zero-filled images + the pack jobs / update jobs that refer to them"""
+        pj, uj, imgs = [], [], {}
+        for name, sh, reg, im in tensors:
+            if im is None:
+                continue
+            co, ci, kd, kh, kwd = sh
+            w = Pdev[offs[name]:offs[name] + int(np.prod(sh))].view(sh)
+            nb = ctx.conv_ws_bytes(co, ci, (kd, kh, kwd))
+            wf = torch.zeros(nb // 4 + 64, device="cuda") if im[0] else None
+            wd_ = torch.zeros(nb // 4 + 64, device="cuda") if im[1] else None
+            if wf is not None:
+                pj.append((w, wf, 0))
+            if wd_ is not None:
+                pj.append((w, wd_, 1))
+            uj.append((offs[name], wf, wd_, sh, reg))
+            imgs[name] = (wf, wd_)
+        return pj, uj, imgs
+
+    # the two launches
+    Pr, Gr, Mr, Sr, Hr = dev(P0), dev(G0), dev(M0), dev(S0), dev(hyp)
+    pj, _, img_ref = images(Pr)
+    ctx.adam_step(Pr, Gr, Mr, Sr, torch.tensor(seg_off, device="cuda"), dev(seg_reg), Hr, **kw)
+    ctx.conv3d_pack_multi(*ctx.make_pack_jobs(pj))
+    # the one launch
+    Pf, Gf, Mf, Sf, Hf = dev(P0), dev(G0), dev(M0), dev(S0), dev(hyp)
+    _, uj, img = images(Pf)
+    rests = [(offs[name], int(np.prod(sh)), reg) for name, sh, reg, im in tensors if im is None]
+    upd = ctx.make_upd_jobs(uj, rests)
+    ctx.adam_pack_step(Pf, Gf, Mf, Sf, upd, Hf, **kw)
+    torch.cuda.synchronize()
+    same = lambda a, b: torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert same(Pf, Pr) and same(Mf, Mr) and same(Sf, Sr)
+    assert float(Gf.abs().max()) == 0.0 and float(Gr.abs().max()) == 0.0
+    assert float(Hf[4]) == 4.0 and same(Hf[:6], Hr[:6])
+    assert not torch.equal(Pf, dev(P0))
+    for name, (wf, wd_) in img.items():
+        rf, rd = img_ref[name]
+        if wf is not None:
+            assert float(wf.abs().max()) > 0 and same(wf, rf), name
+        if wd_ is not None:
+            assert float(wd_.abs().max()) > 0 and same(wd_, rd), name
+    # a second step on top (t = 5): still the same as the two launches
+    Gr.copy_(dev(G0)); Gf.copy_(dev(G0))
+    ctx.adam_step(Pr, Gr, Mr, Sr, torch.tensor(seg_off, device="cuda"), dev(seg_reg), Hr, **kw)
+    ctx.conv3d_pack_multi(*ctx.make_pack_jobs(pj))
+    ctx.adam_pack_step(Pf, Gf, Mf, Sf, upd, Hf, **kw)
+    assert same(Pf, Pr) and float(Hf[4]) == 5.0
+    for name, (wf, wd_) in img.items():
+        assert (wf is None or same(wf, img_ref[name][0])) and (wd_ is None or same(wd_, img_ref[name][1])), name
+
+
 def test_graph_capture_replay(ctx):
     """e2_graph_*: capture conv+pool on a side stream, replay twice."""
     rng = np.random.RandomState(17)
