@@ -2,7 +2,7 @@
 tile, next to the f32 and the operand-rounding bf16 form:
   python tools/bench_bf16_conv.py cin cout kd kh kw D H W"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from elektronn2_amd import backend, autotune

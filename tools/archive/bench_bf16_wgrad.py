@@ -1,7 +1,7 @@
 """time e2_conv3d_wgrad_bf16 (conversion pass included) on one layer next to the f32 and the
 operand-rounding bf16 wgrad:  python tools/bench_bf16_wgrad.py cin cout kd kh kw D H W"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from elektronn2_amd import backend, autotune

@@ -1,7 +1,7 @@
 """time the 1x1x1 conv forward on one layer for a list of forced tilings:
 python tools/bench_pw.py cin cout D H W tiling [tiling ...]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend, autotune
 

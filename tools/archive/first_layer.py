@@ -3,7 +3,7 @@ usage: python tools/first_layer.py <lite|full> [iters]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend
 

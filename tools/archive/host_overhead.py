@@ -1,7 +1,7 @@
 """wall time of Model.trainingstep per call vs the device time of the step (HIP events):
 what the synchronous reference API (loss returned every step) costs on the host."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from elektronn2_amd import nets
 np.random.seed(0)

@@ -7,7 +7,7 @@ Times the replayed training step of a workload with
           at the step boundary; the in-graph copy into the arena is not included)
 usage: python tools/input_gap.py [workload] [steps]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

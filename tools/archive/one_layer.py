@@ -1,7 +1,7 @@
 """Run one conv layer op repeatedly (for rocprofv3 PMC / forced-config sweeps).
 usage: python tools/one_layer.py <fwd|dgrad|wgrad> cin cout kd kh kw D H W [iters]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend
 

@@ -1,7 +1,7 @@
 """30 launches of e2_conv3d_wgrad_bf16 on one layer with one tiling (for rocprofv3; see
 tools/kstats_one_wgrad.sh):  python tools/one_wgrad.py cin cout kd kh kw D H W tile"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend
 

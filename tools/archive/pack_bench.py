@@ -1,7 +1,7 @@
 """The weight repack alone (debug build: E2_PACK_GRID = blocks per job):
     E2HIP_LIB=.../build/dbg/libe2hip.so E2_PACK_GRID=1024 python tools/pack_bench.py [workload]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import bench

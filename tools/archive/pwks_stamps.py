@@ -6,7 +6,7 @@ prints, per tiling, the launch's duration (HIP events, accumulate: no fill) and 
 s_memtime ticks a work-group spends between the kernel's stage boundaries, for the 200 -> 200
 layers of neuro3d_lite@183 and neuro3d@185."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend, autotune
 

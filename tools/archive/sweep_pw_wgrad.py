@@ -1,7 +1,7 @@
 """Time every weight-gradient tiling candidate of a 1x1x1 problem (both kernels):
 usage: python tools/sweep_pw_wgrad.py cin cout D H W [top]     (UpConv: cout = n_f * prod(pool))"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend, autotune
 

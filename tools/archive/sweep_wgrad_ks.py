@@ -2,7 +2,7 @@
 tiling the shipped table / cost model picks, on the plan's padded-gradient layout:
 usage: python tools/sweep_wgrad_ks.py cin cout kd kh kw Do Ho Wo  [more tilings ...]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from elektronn2_amd import backend, autotune
 

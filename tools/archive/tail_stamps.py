@@ -4,7 +4,7 @@
 prints the mean shader cycles a work-group spends between the kernel's stage boundaries, for
 the tails of neuro3d_lite@183 and neuro3d@185, and the launch's duration (HIP events, 20 launches)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from elektronn2_amd import backend
