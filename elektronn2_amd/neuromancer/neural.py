@@ -667,6 +667,10 @@ class Conv(NeuralLayer):
             return
         x = plan.out[self.parent]
         if self._fused_first(plan):
+            if plan.opt['side_join_first']:
+                # (the last launch of the backward chain: next to the side stream's weight
+                # gradients it shares the CUs and takes 1.8x its time; behind them it runs alone)
+                plan.join_side()
             ctx.conv1_pool_act_bwd(x, self._w5(plan.param(self.w)), plan.param(self.b), plan.grad[self],
                                    self._p3, self.activation_func, plan.pgrad(self.w),
                                    plan.pgrad(self.b), ws=plan.scratch[self, 'ws1'])
