@@ -128,7 +128,18 @@ constexpr size_t tail_lds_bytes() {
 // slot elements: dWh [nc][c2], dbh [nc], db1 [c2], loss sum, then (gm) the parent's bias gradient [c1]
 __host__ __device__ inline int tail_psz(int nc, int c2, int c1gm = 0) { return nc * c2 + nc + c2 + 1 + c1gm; }
 
-template <int WM, int NC, int KC>
+// BF: bf16 mode (e2_set_mfma_dtype): the operands of the layer's two GEMMs -- x and the forward
+// image, dpre and the data-gradient image -- are rounded to bf16 (nearest even) in registers on
+// their way into the matrix core; products and sums stay f32 (bf16 x bf16 is exact in f32, so
+// this IS the bf16 MFMA's arithmetic up to summation order); tensors, the head and every
+// pointwise step stay f32.  Two VALU operations per operand register, next to 32-cycle MFMAs.
+__device__ __forceinline__ float tail_rnd_bf16(float v) {
+  union { __bf16 h[2]; unsigned u; } r;
+  r.h[0] = (__bf16)v; r.h[1] = (__bf16)0.f;           // (a plain conversion: the compiler sees the VALU write)
+  return __uint_as_float(r.u << 16);
+}
+
+template <int WM, int NC, int KC, bool BF>
 __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
   using G = Geo<WM, KC>;
   constexpr int kKC = KC;
@@ -261,9 +272,16 @@ __global__ __launch_bounds__(256) void tail_kernel(TailP p) {
     for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(A[i]));
     asm volatile("" : "+v"(B));
     if (TAIL_DBG(2)) return;
+    if constexpr (BF) {
+      const float Bb = tail_rnd_bf16(B);
+#pragma unroll
+      for (int i = 0; i < MTW; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(tail_rnd_bf16(A[i]), Bb, acc[i], 0, 0, 0);
+    } else {
 #pragma unroll
     for (int i = 0; i < MTW; ++i)
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], B, acc[i], 0, 0, 0);
+    }
   };
   // chunk c of a phase sits in buffer (buf0 + c) & 1; its first chunk was staged by the caller
   auto gemm = [&](const float* img, int coP, int ciP, const int (&woff)[NI], int K, int buf0,
@@ -582,14 +600,14 @@ long tail_grid(long N, long S, int wm) {
   return N * ((S + np - 1) / np);
 }
 
-template <int WM, int NC, int KC>
+template <int WM, int NC, int KC, bool BF>
 int launch_tail(e2_ctx* ctx, TailP p, long grid) {
   constexpr size_t ldsb = tail_lds_bytes<WM, NC, KC>();
   static_assert(ldsb <= 160 * 1024, "tail kernel: LDS");
   static_assert((KC / 4) % 2 == 0, "the K loop is unrolled by two steps");
   static bool attr_done = false;
   if (!attr_done) {
-    E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC, KC>),
+    E2_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<WM, NC, KC, BF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
@@ -601,7 +619,7 @@ int launch_tail(e2_ctx* ctx, TailP p, long grid) {
     E2_CHECK_HIP(hipMemsetAsync(p.stamps, 0, sizeof(unsigned long long) * 12 * grid, ctx->stream));
   }
 #endif
-  hipLaunchKernelGGL((tail_kernel<WM, NC, KC>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
+  hipLaunchKernelGGL((tail_kernel<WM, NC, KC, BF>), dim3((unsigned)grid), dim3(256), ldsb, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
 #ifdef E2_DEBUG_ENV
   if (stamps) {
@@ -644,7 +662,9 @@ extern "C" size_t e2_tail_workspace_bytes(int n, int c1, int c2, int ncls, int d
  * gm_mode != 0: dx goes THROUGH the activation backward of the layer that produced x -- dx *=
  * act'(.), that layer's bias gradient (row sums) joins the slots: 1 = relu slope from gm_src = its
  * activated output (signed zeros, e2_conv3d_fwd_packed_act), 2 = from gm_src = its pre-activation
- * + gm_bias, 3 = linear. */
+ * + gm_bias, 3 = linear.  In bf16 mode (e2_set_mfma_dtype) the operands of the layer's two GEMMs
+ * are rounded to bf16 on their way into the matrix core like those of every other conv GEMM; the
+ * head, the loss and all tensors stay f32. */
 extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp_fwd,
                                const float* wp_dgrad, const float* bias1, int c2,
                                const float* w_head, const float* b_head, int ncls,
@@ -656,7 +676,6 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
                  stats && ws && n_slots, "tail: null argument");
   E2_REQUIRE(!dx || wp_dgrad, "tail: the data gradient needs its packed image");
   E2_REQUIRE(e2_tail_supported(x->c, c2, ncls), "tail: unsupported c1=%d c2=%d ncls=%d", x->c, c2, ncls);
-  E2_REQUIRE(!ctx->mfma_bf16, "tail: an f32 kernel, not offered in bf16 mode");
   E2_REQUIRE(flat_sp(x) && flat_sp(target) && flat_sp(probs) && flat_sp(dpre),
              "tail: tensors need dense (z, y, x) planes");
   E2_REQUIRE(gm_mode >= 0 && gm_mode <= 3 && (gm_mode == 0 || dx), "tail: bad gm_mode %d", gm_mode);
@@ -710,9 +729,14 @@ extern "C" int e2_tail_fwd_bwd(e2_ctx* ctx, const e2_tensor5* x, const float* wp
   }
 #define E2_TL(WM_, KC_)                                              \
   if (wm == WM_ && kc == KC_) {                                      \
-    if (ncls == 2) return launch_tail<WM_, 2, KC_>(ctx, p, grid);    \
-    if (ncls == 3) return launch_tail<WM_, 3, KC_>(ctx, p, grid);    \
-    return launch_tail<WM_, 4, KC_>(ctx, p, grid);                   \
+    if (ctx->mfma_bf16) {                                            \
+      if (ncls == 2) return launch_tail<WM_, 2, KC_, true>(ctx, p, grid);  \
+      if (ncls == 3) return launch_tail<WM_, 3, KC_, true>(ctx, p, grid);  \
+      return launch_tail<WM_, 4, KC_, true>(ctx, p, grid);           \
+    }                                                                \
+    if (ncls == 2) return launch_tail<WM_, 2, KC_, false>(ctx, p, grid);   \
+    if (ncls == 3) return launch_tail<WM_, 3, KC_, false>(ctx, p, grid);   \
+    return launch_tail<WM_, 4, KC_, false>(ctx, p, grid);            \
   }
   E2_TL(1, 40) E2_TL(2, 40) E2_TL(4, 40) E2_TL(1, 16) E2_TL(2, 16) E2_TL(4, 16)
 #undef E2_TL

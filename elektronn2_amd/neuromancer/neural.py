@@ -370,7 +370,7 @@ class Conv(NeuralLayer):
                     and self.activation_func == 'relu' and len(kids) == 1
                     and type(kids[0]) is Conv and not isinstance(par, (list, tuple))
                     and not self._fused_first(plan)
-                    and getattr(plan.ctx, 'mfma_dtype', 'f32') == 'f32'
+                    and (getattr(plan.ctx, 'mfma_dtype', 'f32') == 'f32' or plan.opt['bf16_tail'])
                     and not any(n is self or n is kids[0] for n in plan.outputs)):
                 head = kids[0]
                 sm = head._fused_head(plan)
@@ -394,6 +394,10 @@ class Conv(NeuralLayer):
         lin, with gradient buffers of its own.  Returns (mode, src tensor, bias) for
         e2_tail_fwd_bwd or None (the launch writes the parent's plain output gradient)."""
         par = self.parent
+        if getattr(plan.ctx, 'mfma_dtype', 'f32') != 'f32':
+            # bf16 mode: the parent's own activation backward also writes the bf16 operand images
+            # of its two gradient GEMMs (bf16_ahead.py) -- the tail hands it the plain gradient
+            return None
         if not (plan.opt['tail_gm'] and type(par) is Conv and not par._bn()
                 and all(p == 1 for p in par._p3) and par.activation_func in ('relu', 'lin')
                 and (par, 'dy') in plan.scratch and not par._fused_first(plan)

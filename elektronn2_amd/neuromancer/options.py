@@ -36,6 +36,8 @@ SPEC = {
     "side_pack": ("E2_SIDE_PACK", _b, False, "weight repack as a parallel branch (measured slower)"),
     "fuse_actbwd": ("E2_FUSE_ACTBWD", int, 0, "relu backward in the consumer's dgrad epilogue (finding 17)"),
     "fuse_tail": ("E2_FUSE_TAIL", _b, True, "last 1x1x1 conv + head + loss in one launch (finding 33)"),
+    "bf16_tail": ("E2_BF16_TAIL", _b, True,
+                  "bf16 mode: the tail launch too (its two GEMMs round their operands in registers)"),
     "tail_gm": ("E2_TAIL_GM", _b, True, "the tail launch carries its parent's activation backward"),
     "upconv_packed": ("E2_UPCONV_PACKED", _b, True, "UpConv weight images packed by the plan's one repack launch"),
     "concat_alias": ("E2_CONCAT_ALIAS", _b, True, "a concat hands channel slices to parents only it consumes"),

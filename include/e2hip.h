@@ -63,7 +63,8 @@ int  e2_version(void);
  * gradient kernels (tap rows of 1, 3, 4 or 5) and of e2_conv3d_wgrad_pad are rounded
  * to bf16 (nearest even) on their way into the matrix core; products and sums stay f32;
  * tensors in memory stay f32.  The first-layer, head, generic-width kernels and the plain
- * e2_conv3d_wgrad entry point always compute in f32 (UpConv follows the setting).  Not to be changed while a graph is being captured. */
+ * e2_conv3d_wgrad entry point always compute in f32 (UpConv follows the setting, and so do the
+ * two GEMMs of e2_tail_fwd_bwd's 1x1x1 layer; its head stays f32).  Not to be changed while a graph is being captured. */
 int  e2_set_mfma_dtype(e2_ctx* ctx, int dtype);
 int  e2_get_mfma_dtype(const e2_ctx* ctx);
 /* Tiling of the conv GEMM launches (no reference counterpart; stands where Theano's
