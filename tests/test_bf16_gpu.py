@@ -522,7 +522,7 @@ def test_fused_tail_bf16(bctx, c1, c2, ncls, N, sp):
     assert relerr(dx, dx_own) < TOL
     assert relerr(dx, dx_ref) < 5e-3
     assert relerr(db1, db1_ref) < 1e-4
-    assert 1e-5 < relerr(dx, dx_f32) < 2e-2 and relerr(probs, p_f32) > 1e-6
+    assert relerr(dx, dx_f32) > 1e-5 and 1e-6 < relerr(probs, p_f32) < 2e-2        # (the rounding happened)
 
 
 # ---- the bf16 STEP: operands made ahead (bf16_ahead.py) against the converting form -------------
@@ -590,7 +590,11 @@ def _one_evaluation(net, sp, ahead, calls=1):
     first = [n.name for n in plan.nodes if type(n).__name__ == 'Conv' and n._fused_first(plan)]
     names = list(m.loss_node.all_trainable_params.keys())
     ys = {n.name: plan.scratch[n, 'y'].detach().cpu().numpy().copy() for n in plan.nodes if (n, 'y') in plan.scratch}
-    return dict(outs=outs, douts=douts, ys=ys, first=first, g=dict(zip(names, g)), kinds=sorted(set(k for (_, k) in plan.bf16a)),
+    # (a conv inside the tail launch: neither its output nor its output gradient exist -- what the
+    # launch leaves is the gradient of its pre-activation)
+    dys = {n.name: plan.scratch[n, 'dy'].detach().cpu().numpy().copy() for n in plan.nodes
+           if type(n).__name__ == 'Conv' and plan.out.get(n) is None and (n, 'dy') in plan.scratch}
+    return dict(outs=outs, douts=douts, ys=ys, dys=dys, first=first, g=dict(zip(names, g)), kinds=sorted(set(k for (_, k) in plan.bf16a)),
                 plan=plan, model=m, spec=spec, params=params, x=x, t=t)
 
 
@@ -634,10 +638,40 @@ def test_bf16_step_layer_by_layer_against_the_oracle(process_bf16, ahead):
     src = {n.name: n.parent.name for n in convs}
     f64 = lambda a: np.asarray(a, np.float64)
     worst = {}
+    in_tail = None                                   # (the conv that runs inside the tail launch)
     for i, (node, (n_f, k, p, act), (w, b)) in enumerate(zip(convs, spec, params)):
         last = i == len(spec) - 1
         rnd = (lambda a: a) if (i == 0 or last) else bf16_round          # first layer / head: f32
+        if last and in_tail is not None:
+            continue                                 # (checked with the tail's conv, below)
         x_hip = f64(R['outs'][src[node.name]])
+        if node.name in R['dys']:
+            # ---- csrc/tail.hip: this (1,1,1) conv + the head + the loss in ONE launch.  Its
+            # output is never stored: probabilities against the oracle's chain from the HIP input,
+            # its weight / bias / data gradient from the pre-activation gradient the launch left
+            # (teacher-forced), the head's gradients from the oracle's chain.
+            in_tail = node
+            (nfh, kh_, ph, acth), (wh, bh) = spec[i + 1], params[i + 1]
+            h_ref, (pre_ref, _) = O.conv_node_fwd(rnd(x_hip), rnd(w), b, p, act)
+            logits = O.conv3d_fwd(h_ref, wh) + np.asarray(bh, np.float64).reshape(1, -1, 1, 1, 1)
+            sm = [n for n in plan.nodes if type(n).__name__ == 'Softmax'][0]
+            worst['fwd softmax'] = relerr(torch.tensor(R['outs'][sm.name]), O.softmax(logits))
+            _, dlogits, _ = O.nll_loss_and_grad(logits, R['t'])
+            dh = O.conv3d_dgrad(dlogits, wh, h_ref.shape)
+            dpre_ref, _ = O.bias_act_bwd(dh, pre_ref, b, act)
+            dpre_hip = f64(R['dys'][node.name])
+            # (a unit within f32 rounding of zero may take the other relu slope in float64: at
+            # most a few ELEMENTS may differ, everything else at the kernels' bound)
+            off = np.abs(dpre_hip - dpre_ref) > TOL * np.abs(dpre_ref).max()
+            assert off.sum() <= 3, int(off.sum())
+            head = convs[i + 1]
+            worst['dW ' + head.name] = relerr(torch.tensor(R['g'][head.name + '_w']), O.conv3d_wgrad(dlogits, h_ref, np.shape(wh))) / 5
+            worst['db ' + head.name] = relerr(torch.tensor(R['g'][head.name + '_b']), dlogits.sum(axis=(0, 2, 3, 4))) / 5
+            dc = dpre_hip
+            worst['dW ' + node.name] = relerr(torch.tensor(R['g'][node.name + '_w']), O.conv3d_wgrad(rnd(dc), rnd(x_hip), np.shape(w)))
+            worst['db ' + node.name] = relerr(torch.tensor(R['g'][node.name + '_b']), dc.sum(axis=(0, 2, 3, 4)))
+            worst['dx ' + node.name] = relerr(torch.tensor(R['douts'][src[node.name]]), O.conv3d_dgrad(rnd(dc), rnd(w), x_hip.shape))
+            continue
         if last:
             # the head's logits are never materialised: softmax output against the oracle's
             logits = O.conv3d_fwd(x_hip, w) + np.asarray(b, np.float64).reshape(1, -1, 1, 1, 1)
@@ -672,7 +706,7 @@ def test_bf16_step_layer_by_layer_against_the_oracle(process_bf16, ahead):
             worst['dx ' + node.name] = relerr(torch.tensor(R['douts'][src[node.name]]), dx_ref)
     bad = {k: v for k, v in worst.items() if not v < TOL}
     assert not bad, bad
-    assert len(worst) >= 4 * len(spec) - 2
+    assert len(worst) >= 4 * len(spec) - 4
 
 
 @pytest.mark.parametrize("net,sp", [("neuro3d_lite", (9, 71, 71)), ("neuro3d", (23, 121, 121))])
