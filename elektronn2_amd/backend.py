@@ -93,6 +93,7 @@ def _load():
         "e2_conv3d_wgrad_pad": (C.c_int, [vp, P5, P5, fp, i, i, i, i]),
         "e2_pack_job_bytes": (sz, []),
         "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
+        "e2_pack_job_set_rows": (C.c_int, [vp, i]),
         "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
         "e2_conv3d_pack_multi_ex": (C.c_int, [vp, vp, i, i]),
         "e2_head_supported": (C.c_int, [i, i]),
@@ -471,18 +472,22 @@ class Context:
                                       kd, kh, kw, 1 if accumulate else 0),
              "e2_conv3d_wgrad_pad")
 
-    def make_pack_jobs(self, jobs):
+    def make_pack_jobs(self, jobs, rows=None):
         """jobs: list of (w tensor, wp tensor, mode).  Returns a device byte tensor
-        of job records for conv3d_pack_multi."""
+        of job records for conv3d_pack_multi.  ``rows`` (optional, one entry per job, None / 0 =
+        default): how far the reading launch's M tiles reach (e2_pack_job_set_rows)."""
         rec = int(_lib.e2_pack_job_bytes())
         buf = (C.c_char * (rec * len(jobs)))()
         for n, (w, wp, mode) in enumerate(jobs):
             cout, cin, kd, kh, kw = w.shape
             _chk(_lib.e2_pack_job_fill(C.byref(buf, n * rec), _fp(w), C.c_void_p(wp.data_ptr()),
                                        cout, cin, kd, kh, kw, mode), "e2_pack_job_fill")
+            if rows is not None and rows[n]:
+                _chk(_lib.e2_pack_job_set_rows(C.byref(buf, n * rec), int(rows[n])), "e2_pack_job_set_rows")
         host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
         dev = host.to(self.device)
         dev.max_taps = max(int(w.shape[2] * w.shape[3] * w.shape[4]) for w, _, _ in jobs)
+        dev.keep = [(w, wp) for w, wp, _ in jobs]
         return dev, len(jobs)
 
     def conv3d_pack_multi(self, jobs_dev, njobs):

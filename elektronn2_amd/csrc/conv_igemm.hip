@@ -94,7 +94,16 @@ struct PackJobDev {
   PackDiv dT, dKT, d32T, dTHW;       // divisors of the tiled repack (T, ICT*T, 32*T, THW)
   int up, Rout, Rin;                 // up: an UpConv image (e2_pack_job_fill modes 2 / 3) -- the
                                      // sub-position r of w[co][ci][r] folded into the row / k index
+  int rowsW;                         // > 0: output rows to (re)write (e2_pack_job_set_rows), else the default
 };
+// rows of an image the repack rewrites: the real ones + the padding a GEMM tile may fetch.  Default:
+// up to the widest M tile in use (7 blocks); a caller that knows the tiling of the launch that reads
+// the image says how far its tiles reach (the rest stays zero from the one-time fill: correct for
+// any tiling, only not refreshed in the memory-side cache)
+__device__ __forceinline__ int pack_rows(const PackJobDev& j) {
+  return j.rowsW > 0 ? min(j.coP, max(j.rowsW, ((j.Cout + 15) / 16) * 16))
+                     : min(j.coP, ((j.Cout + 15) / 16) * 16 + 96);
+}
 __global__ void pack_multi_gather_kernel(const PackJobDev* __restrict__ jobs) {
   // Only the part of an image that the kernels actually fetch is rewritten: the channel
   // groups that hold data plus the four a pipeline may prefetch past the end, and the
@@ -107,7 +116,7 @@ __global__ void pack_multi_gather_kernel(const PackJobDev* __restrict__ jobs) {
   const int T = j.kd * j.THW;
   const int nCG = j.ciP >> 2;
   const int nCGw = min(nCG, ((j.Cin + 3) >> 2) + 4);
-  const int coW = min(j.coP, ((j.Cout + 15) / 16) * 16 + 96);
+  const int coW = pack_rows(j);
   const long total = (long)T * nCGw * 4 * coW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJobDev* __res
   const int T = j.kd * j.THW;
   const int nCG = j.ciP >> 2;
   const int nCGw = min(nCG, ((j.Cin + 3) >> 2) + 4);
-  const int coW = min(j.coP, ((j.Cout + 15) / 16) * 16 + 96);
+  const int coW = pack_rows(j);
   const int icW = 4 * nCGw;
   const int ICT = e2_pack_ict(T);                     // input channels per tile
   const int KT = ICT * T;                             // (ic, tap) pairs per tile
@@ -208,7 +217,7 @@ extern "C" int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, i
              "(use e2_conv3d_pack)", kd * kh * kw);
   PackJobDev* j = (PackJobDev*)rec;
   const int T = kd * kh * kw;
-  j->up = 0; j->Rout = j->Rin = 1;
+  j->up = 0; j->Rout = j->Rin = 1; j->rowsW = 0;
   if (mode == 2 || mode == 3) {
     // UpConv weights w[cout][cin][R = kd*kh*kw sub-positions]; mode 2: the forward GEMM's image
     // (rows oc' = co*R + r, k = ci), mode 3: the data gradient's (rows ci, k = co*R + r) --
@@ -238,6 +247,15 @@ extern "C" int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, i
   const int ICT = e2_pack_ict(T);
   j->dT = mk_pack_div(T); j->dKT = mk_pack_div(ICT * T); j->d32T = mk_pack_div(32 * T);
   j->dTHW = mk_pack_div(kh * kw);
+  return 0;
+}
+
+/* how far the tiles of the launch that reads this image reach along its rows (16 * MT * number of
+ * M tiles of the tiling in use): the repack then rewrites only those rows instead of the default
+ * (real rows rounded to 16, + 96).  Purely a bandwidth hint: rows beyond stay zero. */
+extern "C" int e2_pack_job_set_rows(void* rec, int rows) {
+  E2_REQUIRE(rec && rows >= 0, "pack_job_set_rows: bad argument");
+  ((PackJobDev*)rec)->rowsW = rows;
   return 0;
 }
 

@@ -503,6 +503,7 @@ class Conv(NeuralLayer):
         nb = plan.ctx.conv_ws_bytes(self.n_f, cin, k)
         plan.scratch[self, 'wp_f'] = plan.zeros_flat(nb // 4 + 64)   # padding stays zero
         plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_f'], 0))
+        plan.pack_nodes[id(plan.scratch[self, 'wp_f'])] = (self, 0)      # (Plan._refine_pack_rows)
         if plan.training:
             pad = [kk - 1 for kk in k]
             # zero-padded output gradient: dgrad runs a plain correlation over it and
@@ -524,6 +525,7 @@ class Conv(NeuralLayer):
             if plan.needs_grad(self.parent):
                 plan.scratch[self, 'wp_d'] = plan.zeros_flat(nb // 4 + 64)
                 plan.pack_jobs.append((self.w, plan.scratch[self, 'wp_d'], 1))
+                plan.pack_nodes[id(plan.scratch[self, 'wp_d'])] = (self, 1)
 
     # ---- the tuning keys of the node's three GEMM launches --------------------------------
     def _sig_fwd(self, plan):

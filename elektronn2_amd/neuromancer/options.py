@@ -42,6 +42,11 @@ SPEC = {
     "upconv_packed": ("E2_UPCONV_PACKED", _b, True, "UpConv weight images packed by the plan's one repack launch"),
     "concat_alias": ("E2_CONCAT_ALIAS", _b, True, "a concat hands channel slices to parents only it consumes"),
     "zero_in_update": ("E2_ZERO_IN_UPDATE", _b, True, "the optimiser launch clears the gradient arena (finding 38)"),
+    "pack_rows": ("E2_PACK_ROWS", _b, False,
+                  "the repack rewrites the padding rows the TUNED tiling of each launch fetches, not the "
+                  "worst case over all tilings (e2_pack_job_set_rows): the repack itself 31 -> 24 us on "
+                  "neuro3d, in the step -7 us (neuro3d), -13 us (unet3d_lite), +6 us (neuro3d_lite), "
+                  "+-0 (unet3d) -- below the gate; off (DESIGN finding 51)"),
     "adam_pack": ("E2_ADAM_PACK", _b, False,
                   "the Adam launch writes the packed weight images (e2_adam_pack_step); measured slower "
                   "than the two launches it replaces (DESIGN finding 46): off"),

@@ -397,6 +397,8 @@ class Plan(object):
         self._bf16_ahead_on = bool(self.opt['bf16_ahead'])
         self._xkeep_valid = {}       # Conv node -> its kept bf16 input copy is this step's
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
+        self.pack_nodes = {}         # id(packed image) -> (Conv node, mode): whose launch reads it
+        self._pack_rows_done = False
         self.model.ensure_arena(self.ctx)
         with torch.cuda.stream(self.stream):
             # the static input buffers of all Input nodes are slices of ONE allocation (each
@@ -481,6 +483,62 @@ class Plan(object):
                  if p.apply_train and id(p) not in by_param]
         self._upd = self.ctx.make_upd_jobs(ujobs, rests)
         self._pack_dev_up = self.ctx.make_pack_jobs(up) if up else None
+
+    @staticmethod
+    def _tile_rows(tiling, m):
+        """how far the M tiles of a conv GEMM launch with this tiling string reach for m output
+        rows, or 0 (= the repack's default) when the string is unknown / of another kernel family"""
+        if not tiling:
+            return 0
+        try:
+            v = [int(t) for t in tiling.split(",")]
+        except ValueError:
+            return 0
+        if len(v) == 4:                                   # "MT,NT,CC,SK": 16x16x4 kernel
+            per = 16 * v[0]
+        elif len(v) == 8 and v[0] == 4:                   # "4,MG,NT,CC,SK,WM,WN,G": 4x4x1 kernel
+            per = 4 * v[1] * v[5]
+        elif len(v) in (3, 5) and v[0] == 1:              # "1,MT,NT[,KC,0]": pointwise GEMM
+            per = 16 * v[1]
+        elif v[0] == 32:                                  # bf16 operands in memory: image not read
+            per = 16
+        else:
+            return 0
+        # (whole 128-byte lines: a line the repack writes only in part is merged with memory when the
+        # GEMM fetches it -- rows cut at 80 made the 5 x 2 tiles 6 % slower)
+        return -(-(-(-m // per) * per) // 32) * 32
+
+    def _refine_pack_rows(self):
+        """after the first eager step the tiling of every conv launch is known (tuned or from the
+        shipped table): the repack then rewrites, per image, only the padding rows THAT tiling
+        fetches instead of the worst case over all tilings -- 1.5-3x fewer rows for the layers
+        with few channels (the rows beyond stay zero from the one-time fill: correct for any
+        tiling, only not refreshed in the memory-side cache if the tiling changes later)"""
+        self._pack_rows_done = True
+        if not self.opt['pack_rows'] or self._pack_dev is None:
+            return
+        from .. import autotune
+        rows, any_ = [], False
+        for (w, wp, mode) in self.pack_jobs:
+            r = 0
+            ent = self.pack_nodes.get(id(wp))
+            if ent is not None:
+                node, md = ent
+                try:
+                    if md == 0:
+                        r = self._tile_rows(autotune.known(self.ctx, 'igemm', node._sig_fwd(self)), node.n_f)
+                    elif self.needs_grad(node.parent):
+                        r = self._tile_rows(autotune.known(self.ctx, 'igemm', node._sig_dgrad(self)),
+                                            node.parent.shape['f'])
+                except Exception:
+                    r = 0
+            rows.append(r)
+            any_ = any_ or r > 0
+        if any_:
+            jobs = [(self._w5(self.param(w)), wp, mode) for (w, wp, mode) in self.pack_jobs]
+            self._pack_dev = self.ctx.make_pack_jobs(jobs, rows)
+            if self._upd is not None and self._pack_dev_up is not None:
+                pass                                       # (UpConv images keep their own layout)
 
     def _emit_forward(self):
         if self._upd is not None:
@@ -708,6 +766,8 @@ class Plan(object):
         if self._graphs is None:
             from . import bf16_ahead
             bf16_ahead.prepare(self)                   # (allocates: never during a capture)
+            if self._calls >= 1 and not self._pack_rows_done:
+                self._refine_pack_rows()               # (tilings are known after the eager step)
         capture = self.use_graph and self._calls >= 1
         if capture and self._graphs is None:
             # the first captured call runs segment by segment: a host step between two

@@ -204,6 +204,11 @@ int e2_conv3d_wgrad_pad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy_pad,
 size_t e2_pack_job_bytes(void);
 int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin,
                      int kd, int kh, int kw, int mode);
+/* optional, after e2_pack_job_fill: `rows` = how far the M tiles of the launch that reads this image
+ * reach (number of M tiles x 16 MT of its tiling).  The repack rewrites the real rows + the padding
+ * rows up to there instead of its default (rows rounded to 16, + 96: any tiling); rows beyond stay
+ * zero from the one-time fill -- correct for every tiling, a bandwidth hint only. */
+int e2_pack_job_set_rows(void* rec, int rows);
 int e2_conv3d_pack_multi(e2_ctx*, const void* jobs_dev, int njobs);
 /* the same with the launch's LDS tile sized for the largest kd * kh * kw among the jobs */
 int e2_conv3d_pack_multi_ex(e2_ctx*, const void* jobs_dev, int njobs, int max_taps);

@@ -1271,6 +1271,36 @@ def test_pack_multi_equals_single_pack(ctx):
             w.mul_(-0.5)
 
 
+def test_pack_multi_with_row_hints(ctx):
+    """e2_pack_job_set_rows: the repack told how far the reading launch's M tiles reach rewrites
+    the real rows + the padding rows up to there; the image still equals e2_conv3d_pack's full
+    image everywhere (rows beyond the hint are the zeros of the one-time fill, which is what the
+    full image holds there too), and fewer elements are touched than with the default."""
+    rng = np.random.RandomState(6)
+    shapes = [(40, 20, 3, 3, 3), (200, 150, 1, 3, 3), (100, 80, 3, 4, 4)]
+    hints = {(40, 0): 48, (40, 1): 20, (200, 0): 208, (200, 1): 160, (100, 0): 112, (100, 1): 80}
+    ws = [dev(rng.randn(*s)) for s in shapes]
+    jobs, rows = [], []
+    for w in ws:
+        co, ci = w.shape[:2]
+        n = ctx.conv_ws_bytes(co, ci, tuple(w.shape[2:])) // 4 + 64
+        for mode in (0, 1):
+            jobs.append((w, torch.zeros(n, device="cuda"), mode))
+            rows.append(hints[(co, mode)])
+    poison = [(w, torch.full_like(img, float("nan")), mode) for (w, img, mode) in jobs]
+    ctx.conv3d_pack_multi(*ctx.make_pack_jobs(jobs, rows))
+    ctx.conv3d_pack_multi(*ctx.make_pack_jobs(poison, rows))          # which elements are written at all
+    dflt = [(w, torch.full_like(img, float("nan")), mode) for (w, img, mode) in jobs]
+    ctx.conv3d_pack_multi(*ctx.make_pack_jobs(dflt))
+    for (w, img, mode), (_, pz, _), (_, df, _) in zip(jobs, poison, dflt):
+        ref = torch.full_like(img, float("nan"))
+        ctx.conv3d_pack(w, mode, ref)
+        n_img = int(torch.isfinite(ref).sum().item())
+        assert torch.equal(img[:n_img], ref[:n_img])
+        written, written_default = int(torch.isfinite(pz).sum()), int(torch.isfinite(df).sum())
+        assert w.numel() <= written < written_default, (written, written_default)
+
+
 def test_fill_multi_and_skip_zero_fill(ctx):
     """e2_fill_multi zeroes many regions in one launch; a split-K conv reports the region it
     zero-filled (e2_conv_last_zero_fill) and, told that the output is already zero
