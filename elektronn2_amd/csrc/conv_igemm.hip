@@ -392,7 +392,11 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
 
 void e2i_pack_dims(int cout, int cin, int* ciP, int* coP) {
   *ciP = ((cin + 3) / 4) * 4 + 32;        // any channel-chunk size up to 32+
+#ifdef E2_COP_SLACK
+  *coP = ((cout + 15) / 16) * 16 + E2_COP_SLACK;   // (experiment: denser k-rows, fewer tilings fit)
+#else
   *coP = ((cout + 15) / 16) * 16 + 16 * 13;   // room for any MT tiling
+#endif
 }
 
 int e2i_pack_weights(e2_ctx* ctx, const float* w, float* wp, int Cout, int Cin,
