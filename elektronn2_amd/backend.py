@@ -94,6 +94,8 @@ def _load():
         "e2_pack_job_bytes": (sz, []),
         "e2_pack_job_fill": (C.c_int, [vp, fp, vp, i, i, i, i, i, i]),
         "e2_pack_job_set_rows": (C.c_int, [vp, i]),
+        "e2_pack_job_set_stride": (C.c_int, [vp, i]),
+        "e2_set_image_rows": (C.c_int, [vp, i]),
         "e2_conv3d_pack_multi": (C.c_int, [vp, vp, i]),
         "e2_conv3d_pack_multi_ex": (C.c_int, [vp, vp, i, i]),
         "e2_head_supported": (C.c_int, [i, i]),
@@ -472,16 +474,25 @@ class Context:
                                       kd, kh, kw, 1 if accumulate else 0),
              "e2_conv3d_wgrad_pad")
 
-    def make_pack_jobs(self, jobs, rows=None):
+    def set_image_rows(self, rows):
+        """floats per k-row of the packed conv weight images the next conv3d_pack /
+        conv3d_{fwd,dgrad}_packed* calls read (0 / None = the library's formula)"""
+        _chk(_lib.e2_set_image_rows(self.h, int(rows or 0)), "e2_set_image_rows")
+
+    def make_pack_jobs(self, jobs, rows=None, strides=None):
         """jobs: list of (w tensor, wp tensor, mode).  Returns a device byte tensor
         of job records for conv3d_pack_multi.  ``rows`` (optional, one entry per job, None / 0 =
-        default): how far the reading launch's M tiles reach (e2_pack_job_set_rows)."""
+        default): how far the reading launch's M tiles reach (e2_pack_job_set_rows).  ``strides``
+        (optional, likewise): row length of the image (e2_pack_job_set_stride; the launches that
+        read it need set_image_rows with the same value)."""
         rec = int(_lib.e2_pack_job_bytes())
         buf = (C.c_char * (rec * len(jobs)))()
         for n, (w, wp, mode) in enumerate(jobs):
             cout, cin, kd, kh, kw = w.shape
             _chk(_lib.e2_pack_job_fill(C.byref(buf, n * rec), _fp(w), C.c_void_p(wp.data_ptr()),
                                        cout, cin, kd, kh, kw, mode), "e2_pack_job_fill")
+            if strides is not None and strides[n]:
+                _chk(_lib.e2_pack_job_set_stride(C.byref(buf, n * rec), int(strides[n])), "e2_pack_job_set_stride")
             if rows is not None and rows[n]:
                 _chk(_lib.e2_pack_job_set_rows(C.byref(buf, n * rec), int(rows[n])), "e2_pack_job_set_rows")
         host = torch.frombuffer(bytearray(buf), dtype=torch.uint8)

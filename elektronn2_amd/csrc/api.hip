@@ -51,6 +51,7 @@ extern "C" int e2_ctx_create(int device, e2_ctx** out) {
   c->loss_sum_mode = 0;
   c->loss_count_out = nullptr;
   c->input_slack = 0;
+  c->image_rows = 0;
   c->last_fill_ptr = nullptr;
   c->last_fill_n = 0;
   c->tiling[0][0] = c->tiling[1][0] = 0;
@@ -87,6 +88,34 @@ extern "C" int e2_set_loss_grad_mode(e2_ctx* ctx, int sum_mode, float* count_out
 extern "C" int e2_set_input_slack(e2_ctx* ctx, int bytes) {
   E2_REQUIRE(ctx && bytes >= 0, "e2_set_input_slack: bad argument");
   ctx->input_slack = bytes;
+  return 0;
+}
+
+/* Row length of the packed weight images (no reference counterpart).  An image holds, per
+ * (plane, channel group, tap, channel-in-group), one row of output channels; by default a row is
+ * `cout` rounded to 16 plus 208 floats, so that ANY M tiling of the GEMM kernels fits -- 416 floats
+ * for 200 channels, of which the 7 x 2 tiles fetch 224.  A caller that knows the tiling of the
+ * launch that reads an image may pack it with SHORTER rows (e2_pack_job_set_stride, or this
+ * setting around e2_conv3d_pack) and must then announce the same length here around every
+ * e2_conv3d_{fwd,dgrad}_packed* launch that reads it: the repack writes a third less and the
+ * GEMM's weight rows lie closer together (neuro3d@185 -1 %, the U-Nets -0.4 ... -0.7 %, DESIGN
+ * finding 52).  rows = 0 returns to the formula.  A tiling whose tiles reach past the announced
+ * row length is an ERROR of the launch ("packed coP too small"), never a silent over-read.
+ * UpConv images and the images of e2_tail_fwd_bwd always use the formula. */
+extern "C" int e2_set_image_rows(e2_ctx* ctx, int rows) {
+  E2_REQUIRE(ctx && rows >= 0 && rows % 4 == 0, "e2_set_image_rows: rows must be a non-negative multiple of 4");
+  ctx->image_rows = rows;
+  return 0;
+}
+
+// dims of the packed image a conv launch reads: the formula, or the announced row length
+static int image_dims(const e2_ctx* ctx, int cout, int cin, int* ciP, int* coP) {
+  e2i_pack_dims(cout, cin, ciP, coP);
+  if (ctx->image_rows > 0) {
+    E2_REQUIRE(ctx->image_rows >= ((cout + 15) / 16) * 16, "packed image: announced rows of %d floats for %d channels",
+               ctx->image_rows, cout);
+    *coP = ctx->image_rows;
+  }
   return 0;
 }
 
@@ -206,11 +235,11 @@ extern "C" int e2_conv3d_pack(e2_ctx* ctx, const float* w, int cout, int cin, in
   const int T = kd * kh * kw;
   int ciP, coP;
   if (mode == 0) {
-    e2i_pack_dims(cout, cin, &ciP, &coP);
+    if (int rc = image_dims(ctx, cout, cin, &ciP, &coP)) return rc;
     return e2i_pack_weights(ctx, w, (float*)ws, cout, cin, kd, kh, kw, (int64_t)cin * T, T,
                             1, ciP, coP, 1, 1);
   }
-  e2i_pack_dims(cin, cout, &ciP, &coP);
+  if (int rc = image_dims(ctx, cin, cout, &ciP, &coP)) return rc;
   return e2i_pack_weights(ctx, w, (float*)ws, cin, cout, kd, kh, kw, T, (int64_t)cin * T, 0,
                           ciP, coP, 1, 1);
 }
@@ -233,7 +262,7 @@ static int conv_fwd_packed(e2_ctx* ctx, const e2_tensor5* x, const void* wp, int
   a.Do = y->d; a.Ho = y->h; a.Wo = y->w;
   a.isN = x->sn; a.isC = x->sc; a.isZ = x->sd; a.isY = x->sh;
   a.osN = y->sn; a.osC = y->sc; a.osZ = y->sd; a.osY = y->sh;
-  e2i_pack_dims(cout, x->c, &a.ciP, &a.coP);
+  if (int rc = image_dims(ctx, cout, x->c, &a.ciP, &a.coP)) return rc;
   a.upz = a.upy = a.upx = 1;
   a.parts_max = max_parts; a.part_stride = part_stride; a.nparts = nparts;
   return e2i_igemm_conv(ctx, a);
@@ -272,7 +301,7 @@ extern "C" int e2_conv3d_fwd_packed_act(e2_ctx* ctx, const e2_tensor5* x, const 
   a.Do = out->d; a.Ho = out->h; a.Wo = out->w;
   a.isN = x->sn; a.isC = x->sc; a.isZ = x->sd; a.isY = x->sh;
   a.osN = out->sn; a.osC = out->sc; a.osZ = out->sd; a.osY = out->sh;
-  e2i_pack_dims(cout, x->c, &a.ciP, &a.coP);
+  if (int rc = image_dims(ctx, cout, x->c, &a.ciP, &a.coP)) return rc;
   a.upz = a.upy = a.upx = 1;
   a.bias = bias; a.act = act;
   return e2i_igemm_conv(ctx, a);
@@ -298,7 +327,7 @@ static int conv_dgrad_packed(e2_ctx* ctx, const e2_tensor5* dy_pad, const void* 
   a.Do = dx->d; a.Ho = dx->h; a.Wo = dx->w;
   a.isN = dy_pad->sn; a.isC = dy_pad->sc; a.isZ = dy_pad->sd; a.isY = dy_pad->sh;
   a.osN = dx->sn; a.osC = dx->sc; a.osZ = dx->sd; a.osY = dx->sh;
-  e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
+  if (int rc = image_dims(ctx, cin, dy_pad->c, &a.ciP, &a.coP)) return rc;
   a.upz = a.upy = a.upx = 1;
   a.zpad = kd - 1;
   a.parts_max = max_parts; a.part_stride = part_stride; a.nparts = nparts;
@@ -351,7 +380,7 @@ extern "C" int e2_conv3d_dgrad_packed_actbwd(e2_ctx* ctx, const e2_tensor5* dy_p
   a.Do = dx.d; a.Ho = dx.h; a.Wo = dx.w;
   a.isN = dy_pad->sn; a.isC = dy_pad->sc; a.isZ = dy_pad->sd; a.isY = dy_pad->sh;
   a.osN = dx.sn; a.osC = dx.sc; a.osZ = dx.sd; a.osY = dx.sh;
-  e2i_pack_dims(cin, dy_pad->c, &a.ciP, &a.coP);
+  if (int rc = image_dims(ctx, cin, dy_pad->c, &a.ciP, &a.coP)) return rc;
   a.upz = a.upy = a.upx = 1;
   a.zpad = kd - 1;
   int done = 0;

@@ -23,6 +23,7 @@ struct e2_ctx {
   int loss_sum_mode;        // e2_set_loss_grad_mode: 1 = NLL gradients are NOT divided by the labelled count
   float* loss_count_out;    // ... and the count is also written here (the slot behind the gradient arena)
   int input_slack;          // e2_set_input_slack: finite readable bytes behind the x of the launches that follow
+  int image_rows;           // e2_set_image_rows: floats per k-row of the packed images the next launches read (0 = formula)
   char last_launch[160];    // e2_last_launch: "<kernel family> <tiling that ran> <forced|model|fallback>"
   unsigned tiling_fallbacks;   // launches since e2_ctx_create whose forced tiling was NOT the one that ran
 };

@@ -259,6 +259,18 @@ extern "C" int e2_pack_job_set_rows(void* rec, int rows) {
   return 0;
 }
 
+/* pack this image with rows of `rows` floats instead of the formula's (e2_set_image_rows: the
+ * launches that read it must be told the same length); conv images (modes 0 / 1) only */
+extern "C" int e2_pack_job_set_stride(void* rec, int rows) {
+  E2_REQUIRE(rec, "pack_job_set_stride: null record");
+  PackJobDev* j = (PackJobDev*)rec;
+  E2_REQUIRE(!j->up, "pack_job_set_stride: UpConv images keep the formula");
+  E2_REQUIRE(rows % 4 == 0 && rows >= ((j->Cout + 15) / 16) * 16, "pack_job_set_stride: rows of %d floats for %d channels", rows, j->Cout);
+  j->coP = rows;
+  j->total = (long)j->kd * j->THW * j->ciP * j->coP;
+  return 0;
+}
+
 extern "C" int e2_conv3d_pack_multi(e2_ctx* ctx, const void* jobs_dev, int njobs) {
   return e2_conv3d_pack_multi_ex(ctx, jobs_dev, njobs, 248);
 }
@@ -355,6 +367,7 @@ static IgemmCfg choose_cfg(const e2_ctx* ctx, const IgemmArgs& a, int* ok) {
   for (int MT : kMTs) {
     if (MT > mblocks && MT != 1) continue;
     const int nMT = e2_cdiv(mblocks, MT);
+    if (nMT * 16 * MT > a.coP) continue;          // (the tiles would reach past the image's rows)
     for (int NT = 1; NT <= 4; NT *= 2) {
       if (NT == 4 && MT > 5) continue;
       const int BN = 64 * NT;

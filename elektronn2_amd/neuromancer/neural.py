@@ -601,8 +601,9 @@ class Conv(NeuralLayer):
                     plan.bf16_xkeep_valid(self, True)
                 else:
                     plan.bf16_xkeep_valid(self, False)
-                    ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self._k3, plan.param(self.b),
-                                              self.activation_func, out)
+                    with plan.image(wp):
+                        ctx.conv3d_fwd_packed_act(x, wp, self.n_f, self._k3, plan.param(self.b),
+                                                  self.activation_func, out)
             plan.tuned('igemm', sig,
                        autotune.igemm_candidates(self.n_f, cin, self._k3,
                                                  out.shape[2:], split_k=False) +
@@ -620,9 +621,11 @@ class Conv(NeuralLayer):
                 self._bf16_fwd(plan, x, y)
                 got[0] = 1
             elif yp.shape[0] > 1:
-                got[0] = ctx.conv3d_fwd_packed_parts(x, wp, self.n_f, self._k3, yp)
+                with plan.image(wp):
+                    got[0] = ctx.conv3d_fwd_packed_parts(x, wp, self.n_f, self._k3, yp)
             else:
-                ctx.conv3d_fwd_packed(x, wp, self.n_f, self._k3, y)
+                with plan.image(wp):
+                    ctx.conv3d_fwd_packed(x, wp, self.n_f, self._k3, y)
         plan.tuned('igemm', sig,
                    autotune.igemm_candidates(self.n_f, cin, self._k3, y.shape[2:]) +
                    plan.bf16_cands(cin), fwd_plain, out=y)
@@ -797,9 +800,10 @@ class Conv(NeuralLayer):
                 plan.scratch[par, 'dy_done'] = True
 
                 def launch(dbias):
-                    ctx.conv3d_dgrad_packed_actbwd(dyp, wp, cin, self._k3, src,
-                                                   par.activation_func, pdyp, ppad, dbias,
-                                                   bias_prev=pb)
+                    with plan.image(wp):
+                        ctx.conv3d_dgrad_packed_actbwd(dyp, wp, cin, self._k3, src,
+                                                       par.activation_func, pdyp, ppad, dbias,
+                                                       bias_prev=pb)
                 plan.tuned('igemm', sig,
                            autotune.igemm_candidates(cin, self.n_f, self._k3, osp),
                            lambda: launch(plan.pgrad(par.b)), fn_tune=lambda: launch(None),
@@ -828,10 +832,12 @@ class Conv(NeuralLayer):
                     got[0] = 1
                 elif gparts is not None:
                     self._need_f32_dy(plan)
-                    got[0] = ctx.conv3d_dgrad_packed_parts(dyp, wp, cin, self._k3, gparts)
+                    with plan.image(wp):
+                        got[0] = ctx.conv3d_dgrad_packed_parts(dyp, wp, cin, self._k3, gparts)
                 else:
                     self._need_f32_dy(plan)
-                    ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out)
+                    with plan.image(wp):
+                        ctx.conv3d_dgrad_packed(dyp, wp, cin, self._k3, out)
             plan.tuned('igemm', sig,
                        autotune.igemm_candidates(cin, self.n_f, self._k3, out.shape[2:]) +
                        plan.bf16_cands(self.n_f), dgrad, out=out)

@@ -42,6 +42,9 @@ SPEC = {
     "upconv_packed": ("E2_UPCONV_PACKED", _b, True, "UpConv weight images packed by the plan's one repack launch"),
     "concat_alias": ("E2_CONCAT_ALIAS", _b, True, "a concat hands channel slices to parents only it consumes"),
     "zero_in_update": ("E2_ZERO_IN_UPDATE", _b, True, "the optimiser launch clears the gradient arena (finding 38)"),
+    "image_stride": ("E2_IMAGE_STRIDE", _b, True,
+                     "once a conv launch's tiling is known its packed weight image gets rows as long as that "
+                     "tiling's tiles reach (+ 16), not the any-tiling formula (e2_set_image_rows; finding 52)"),
     "pack_rows": ("E2_PACK_ROWS", _b, False,
                   "the repack rewrites the padding rows the TUNED tiling of each launch fetches, not the "
                   "worst case over all tilings (e2_pack_job_set_rows): the repack itself 31 -> 24 us on "

@@ -399,6 +399,7 @@ class Plan(object):
         self.pack_jobs = []          # (param, packed image, mode) of every Conv node
         self.pack_nodes = {}         # id(packed image) -> (Conv node, mode): whose launch reads it
         self._pack_rows_done = False
+        self._img_stride = {}        # id(packed image) -> floats per row it is packed with (absent: formula)
         self.model.ensure_arena(self.ctx)
         with torch.cuda.stream(self.stream):
             # the static input buffers of all Input nodes are slices of ONE allocation (each
@@ -484,6 +485,21 @@ class Plan(object):
         self._upd = self.ctx.make_upd_jobs(ujobs, rests)
         self._pack_dev_up = self.ctx.make_pack_jobs(up) if up else None
 
+    def image(self, wp):
+        """context manager around the launches that read the packed image ``wp``: announces the
+        row length the image was packed with (e2_set_image_rows), the formula otherwise"""
+        plan, rows = self, self._img_stride.get(id(wp), 0)
+
+        class _I(object):
+            def __enter__(self_):
+                if rows:
+                    plan.ctx.set_image_rows(rows)
+
+            def __exit__(self_, *a):
+                if rows:
+                    plan.ctx.set_image_rows(0)
+        return _I()
+
     @staticmethod
     def _tile_rows(tiling, m):
         """how far the M tiles of a conv GEMM launch with this tiling string reach for m output
@@ -515,30 +531,45 @@ class Plan(object):
         with few channels (the rows beyond stay zero from the one-time fill: correct for any
         tiling, only not refreshed in the memory-side cache if the tiling changes later)"""
         self._pack_rows_done = True
-        if not self.opt['pack_rows'] or self._pack_dev is None:
+        want_rows, want_stride = self.opt['pack_rows'], self.opt['image_stride'] and self._upd is None
+        if not (want_rows or want_stride) or self._pack_dev is None:
             return
         from .. import autotune
-        rows, any_ = [], False
+        rows, strides, any_ = [], [], False
+        self._img_stride = {}
         for (w, wp, mode) in self.pack_jobs:
-            r = 0
+            r = st = 0
             ent = self.pack_nodes.get(id(wp))
             if ent is not None:
                 node, md = ent
                 try:
                     if md == 0:
-                        r = self._tile_rows(autotune.known(self.ctx, 'igemm', node._sig_fwd(self)), node.n_f)
+                        t, m = autotune.known(self.ctx, 'igemm', node._sig_fwd(self)), node.n_f
                     elif self.needs_grad(node.parent):
-                        r = self._tile_rows(autotune.known(self.ctx, 'igemm', node._sig_dgrad(self)),
-                                            node.parent.shape['f'])
+                        t, m = autotune.known(self.ctx, 'igemm', node._sig_dgrad(self)), node.parent.shape['f']
+                    else:
+                        t, m = None, 0
+                    r = self._tile_rows(t, m)
+                    # a row length of its own only for the 16x16x4 / pointwise kernels (the 4x4x1
+                    # kernel's lanes read 64 consecutive floats per row; a memory-form tiling does
+                    # not read the image, but the launch that replaces it under another pin would)
+                    v = [int(q) for q in t.split(",")] if t else []
+                    if want_stride and r and (len(v) == 4 or (len(v) in (3, 5) and v[0] == 1)):
+                        st = -(-max(r, -(-m // 16) * 16) // 16) * 16 + 16
                 except Exception:
-                    r = 0
-            rows.append(r)
-            any_ = any_ or r > 0
+                    r = st = 0
+            rows.append(r if want_rows else 0)
+            strides.append(st)
+            if st:
+                self._img_stride[id(wp)] = st
+            any_ = any_ or st > 0 or (want_rows and r > 0)
         if any_:
             jobs = [(self._w5(self.param(w)), wp, mode) for (w, wp, mode) in self.pack_jobs]
-            self._pack_dev = self.ctx.make_pack_jobs(jobs, rows)
-            if self._upd is not None and self._pack_dev_up is not None:
-                pass                                       # (UpConv images keep their own layout)
+            # (an image whose row length changes is re-zeroed first: its old rows sit elsewhere)
+            for (w5, wp, mode), st in zip(jobs, strides):
+                if st:
+                    wp.zero_()
+            self._pack_dev = self.ctx.make_pack_jobs(jobs, rows, strides)
 
     def _emit_forward(self):
         if self._upd is not None:
@@ -768,6 +799,13 @@ class Plan(object):
             bf16_ahead.prepare(self)                   # (allocates: never during a capture)
             if self._calls >= 1 and not self._pack_rows_done:
                 self._refine_pack_rows()               # (tilings are known after the eager step)
+            elif self._calls == 0 and self._img_stride:
+                # (the plan was reset to re-tune: back to images any tiling can read)
+                self._img_stride, self._pack_rows_done = {}, False
+                jobs = [(self._w5(self.param(w)), wp, mode) for (w, wp, mode) in self.pack_jobs]
+                for (_, wp, _) in jobs:
+                    wp.zero_()
+                self._pack_dev = self.ctx.make_pack_jobs(jobs)
         capture = self.use_graph and self._calls >= 1
         if capture and self._graphs is None:
             # the first captured call runs segment by segment: a host step between two

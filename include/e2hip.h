@@ -204,6 +204,17 @@ int e2_conv3d_wgrad_pad(e2_ctx*, const e2_tensor5* x, const e2_tensor5* dy_pad,
 size_t e2_pack_job_bytes(void);
 int e2_pack_job_fill(void* rec, const float* w, void* wp, int cout, int cin,
                      int kd, int kh, int kw, int mode);
+/* Row length of the packed conv weight images (default: cout rounded to 16, + 208 floats -- any M
+ * tiling fits).  e2_pack_job_set_stride packs ONE image of e2_conv3d_pack_multi with rows of `rows`
+ * floats (a multiple of 4, >= cout rounded to 16; modes 0 / 1 only); e2_set_image_rows announces
+ * that length to the e2_conv3d_pack / e2_conv3d_{fwd,dgrad}_packed* calls that follow (0 = the
+ * formula again): the launch that reads an image must be told the length it was packed with.  A
+ * tiling whose tiles reach past the rows is an error of the launch, never an over-read.  Purpose:
+ * once the tiling of a launch is known its image needs 224 instead of 416 floats per row for 200
+ * channels -- the repack writes a third less, the weight rows lie closer (DESIGN finding 52).
+ * UpConv images and e2_tail_fwd_bwd's images always use the formula. */
+int e2_set_image_rows(e2_ctx* ctx, int rows);
+int e2_pack_job_set_stride(void* rec, int rows);
 /* optional, after e2_pack_job_fill: `rows` = how far the M tiles of the launch that reads this image
  * reach (number of M tiles x 16 MT of its tiling).  The repack rewrites the real rows + the padding
  * rows up to there instead of its default (rows rounded to 16, + 96: any tiling); rows beyond stay

@@ -140,6 +140,36 @@ def test_optimiser_launch_that_writes_the_weight_images_in_the_step():
         assert rel(a, b) < 1e-4
 
 
+def test_plan_gives_its_weight_images_their_own_row_length():
+    """Plan option image_stride (default on, DESIGN finding 52): after the first eager step -- the
+    tilings are known -- the conv weight images are re-packed with rows as long as each launch's
+    tiles reach, the launches are told so, and losses / parameters are those of the plan that
+    keeps the any-tiling formula (to the weight gradients' atomic order); eager, capture, replay;
+    a prediction plan of the same model does the same."""
+    from elektronn2_amd.neuromancer import plan_options
+    spec, sp = O.NEURO3D, (17, 109, 109)
+    params = O.init_net(spec, 1, seed=4)
+    rng = np.random.RandomState(6)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    res = {}
+    for on in (False, True):
+        with plan_options(image_stride=on):
+            m = build('full', sp, params)
+            losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(4)]
+            plan = m.optimisers['Adam'].step.func
+            assert bool(plan._img_stride) == on
+            p1 = m.predict(x)
+            p2 = m.predict(x)                      # (second call: images re-packed, graph captured)
+            assert np.array_equal(p1, p2) or rel(p2, p1) < 1e-6
+            res[on] = (losses, [q.get_value() for q in m.loss_node.all_trainable_params.values()], p2)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) < 1e-5 * abs(b)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert rel(a, b) < 1e-4
+    assert rel(res[True][2], res[False][2]) < 1e-5
+
+
 def test_sgd_step_and_lr_change_under_graph():
     spec, sp = O.NEURO3D_LITE, (7, 47, 47)
     params = O.init_net(spec, 1, seed=2)

@@ -1301,6 +1301,76 @@ def test_pack_multi_with_row_hints(ctx):
         assert w.numel() <= written < written_default, (written, written_default)
 
 
+@pytest.mark.parametrize("ci,co,k,sp,tile,rows", [(150, 200, (1, 3, 3), (2, 11, 25), "7,2,32,1", 240),
+                                                 (40, 150, (2, 4, 4), (3, 12, 13), "10,2,16,2", 176),
+                                                 (20, 40, (3, 3, 3), (5, 14, 19), "3,4,12,1", 64),
+                                                 (200, 200, (1, 1, 1), (2, 9, 20), "1,13,1", 224)])
+def test_packed_images_with_their_own_row_length(ctx, ci, co, k, sp, tile, rows):
+    """e2_set_image_rows / e2_pack_job_set_stride (DESIGN finding 52): an image packed with rows as
+    long as its launch's tiles reach instead of the any-tiling formula -- forward, fused bias +
+    relu, and data gradient give the formula's results; the launch must be told the length the
+    image was packed with, and a tiling that reaches past it is an ERROR, never an over-read."""
+    from elektronn2_amd.backend import E2Error
+    rng = np.random.RandomState(ci + co)
+    x = rng.rand(1, ci, *sp).astype(np.float32)
+    w = (rng.randn(co, ci, *k) / np.sqrt(ci * np.prod(k))).astype(np.float32)
+    b = (rng.randn(co) / 4).astype(np.float32)
+    y_ref = O.conv3d_fwd(x, w)
+    out_ref, _ = O.conv_node_fwd(x, w, b, (1, 1, 1), 'relu')
+    dy = rng.randn(*y_ref.shape).astype(np.float32)
+    dx_ref = O.conv3d_dgrad(dy, w, x.shape)
+    wd, xd = dev(w), dev(x)
+    n = ctx.conv_ws_bytes(co, ci, k) // 4 + 64
+    imgs = {0: torch.zeros(n, device="cuda"), 1: torch.zeros(n, device="cuda")}
+    rows_d = -(-ci // 16) * 16 + 16 if tile.count(",") == 3 else 0       # the dgrad image: M = ci
+    ctx.conv3d_pack_multi(*ctx.make_pack_jobs([(wd, imgs[0], 0), (wd, imgs[1], 1)], strides=[rows, rows_d]))
+    pshape = (1, co) + tuple(y_ref.shape[2 + i] + 2 * (k[i] - 1) for i in range(3))
+    dyp = torch.zeros(pshape, device="cuda")
+    dyp[:, :, k[0] - 1:k[0] - 1 + y_ref.shape[2], k[1] - 1:k[1] - 1 + y_ref.shape[3],
+        k[2] - 1:k[2] - 1 + y_ref.shape[4]] = dev(dy)
+    ctx.set_tiling("igemm", tile)
+    try:
+        y = torch.full(y_ref.shape, float("nan"), device="cuda")
+        ctx.set_image_rows(rows)
+        ctx.conv3d_fwd_packed(xd, imgs[0], co, k, y)
+        assert relerr(y, y_ref) < TOL
+        if k[2] in (1, 3, 4, 5) and tile.count(",") == 3:
+            out = torch.full(y_ref.shape, float("nan"), device="cuda")
+            ctx.conv3d_fwd_packed_act(xd, imgs[0], co, k, dev(b), 'relu', out)
+            assert relerr(out, out_ref) < TOL
+        # the single-image pack under the announced length writes the same image
+        again = torch.zeros(n, device="cuda")
+        ctx.conv3d_pack(wd, 0, again)
+        assert torch.equal(again, imgs[0])
+        # told the formula instead, the launch would read the rows at the wrong pitch: results differ
+        ctx.set_image_rows(0)
+        ctx.conv3d_fwd_packed(xd, imgs[0], co, k, y)
+        assert not relerr(y, y_ref) < TOL
+    finally:
+        ctx.set_image_rows(0)
+        ctx.set_tiling("igemm", None)
+    if rows_d:
+        ctx.set_tiling("igemm", "%d,2,16,1" % min(-(-ci // 16), 7))
+        try:
+            dx = torch.full(x.shape, float("nan"), device="cuda")
+            ctx.set_image_rows(rows_d)
+            ctx.conv3d_dgrad_packed(dyp, imgs[1], ci, k, dx)
+            assert relerr(dx, dx_ref) < TOL
+        finally:
+            ctx.set_image_rows(0)
+            ctx.set_tiling("igemm", None)
+    # a tiling whose tiles reach past the announced rows: refused
+    if tile.count(",") == 3 and co > 16 * 10 + 16:
+        ctx.set_tiling("igemm", "10,2,16,1")               # 2 x 160 rows for 200 channels
+        try:
+            ctx.set_image_rows(rows)
+            with pytest.raises(E2Error):
+                ctx.conv3d_fwd_packed(xd, imgs[0], co, k, torch.empty(y_ref.shape, device="cuda"))
+        finally:
+            ctx.set_image_rows(0)
+            ctx.set_tiling("igemm", None)
+
+
 def test_fill_multi_and_skip_zero_fill(ctx):
     """e2_fill_multi zeroes many regions in one launch; a split-K conv reports the region it
     zero-filled (e2_conv_last_zero_fill) and, told that the output is already zero
