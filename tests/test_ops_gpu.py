@@ -1350,7 +1350,9 @@ def test_packed_images_with_their_own_row_length(ctx, ci, co, k, sp, tile, rows)
         ctx.set_image_rows(0)
         ctx.set_tiling("igemm", None)
     if rows_d:
-        ctx.set_tiling("igemm", "%d,2,16,1" % min(-(-ci // 16), 7))
+        nb = -(-ci // 16)
+        mt = [m for m in (5, 4, 3, 2, 1) if -(-nb // m) * m * 16 <= rows_d][0]     # (its tiles fit the rows)
+        ctx.set_tiling("igemm", "%d,2,16,1" % mt)
         try:
             dx = torch.full(x.shape, float("nan"), device="cuda")
             ctx.set_image_rows(rows_d)
