@@ -555,7 +555,9 @@ class Plan(object):
                     # not read the image, but the launch that replaces it under another pin would)
                     v = [int(q) for q in t.split(",")] if t else []
                     if want_stride and r and (len(v) == 4 or (len(v) in (3, 5) and v[0] == 1)):
-                        st = -(-max(r, -(-m // 16) * 16) // 16) * 16 + 16
+                        # exactly as long as the tiles reach: measured against + 16 floats and against
+                        # rows rounded to whole 128-byte lines, the densest form wins (finding 52)
+                        st = -(-max(r, -(-m // 16) * 16) // 16) * 16
                 except Exception:
                     r = st = 0
             rows.append(r if want_rows else 0)
