@@ -554,6 +554,8 @@ class Plan(object):
                     # kernel's lanes read 64 consecutive floats per row; a memory-form tiling does
                     # not read the image, but the launch that replaces it under another pin would)
                     v = [int(q) for q in t.split(",")] if t else []
+                    # (measured for the 4x4x1 kernel too -- rows of 64 floats for 20 channels --:
+                    # neuro3d_lite +5 us, neuro3d -5 us, not of one sign: its images keep the formula)
                     if want_stride and r and (len(v) == 4 or (len(v) in (3, 5) and v[0] == 1)):
                         # exactly as long as the tiles reach: measured against + 16 floats and against
                         # rows rounded to whole 128-byte lines, the densest form wins (finding 52)
