@@ -171,7 +171,13 @@ def test_two_rank_step_with_ragged_label_counts():
         for ref in (want[i], want[nw + i]):
             got = a[off:off + ref.size].reshape(ref.shape)
             err = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)
-            assert err < 1e-4, (i, ref.shape, err)
+            # 5e-4 (the bound of the other step tests, test_model_gpu.TOL_ADAM), not 1e-4: the
+            # second step's forward runs on parameters that carry the first step's f32 atomic
+            # order, a relu unit within rounding of zero then falls on either side, and ONE such
+            # flip moves a bias gradient -- a sum of ~1e5 signed terms -- by 1e-3 of its size
+            # (DESIGN section 2).  Observed over five runs: 4e-5 ... 1.09e-4 on conv1's bias; what
+            # the test distinguishes (count-weighted against plain mean, below) is 1e-2 apart.
+            assert err < 5e-4, (i, ref.shape, err)
             off += (ref.size + 3) // 4 * 4
     # ... and it is NOT the plain mean of the two ranks' gradients (that is what ragged counts
     # distinguish): a net stepping on the hand-averaged per-rank gradients ends elsewhere
