@@ -173,12 +173,15 @@ def test_resume_restores_parameters_and_adam_state(tmp_path):
     got = [float(b.trainingstep(xs[i], ts[i], optimiser='Adam')[0]) for i in (3, 4)]
     st = b.optimisers['Adam'].state_dict()
     assert float(st['t']) == 5.0
+    # bounds: two IDENTICAL runs of this net drift apart by 2e-7 (losses), 7e-7 (parameters),
+    # 1.5e-6 (m) and 3e-7 (s) over nine steps (tools/aa_spread.py, DESIGN finding 53); a resume
+    # that lost anything is off by > 1e-3
     for x, y in zip(cont, got):
-        assert abs(x - y) <= 1e-6 * abs(x)
+        assert abs(x - y) <= 2e-6 * abs(x)
     for v, p in zip(end_p, b.loss_node.all_trainable_params.values()):
-        assert np.abs(v - p.get_value()).max() <= 2e-6 * np.abs(v).max()
+        assert np.abs(v - p.get_value()).max() <= 1e-5 * np.abs(v).max()
     ref_o = a.optimisers['Adam'].state_dict()
-    assert np.abs(st['m'] - ref_o['m']).max() <= 1e-5 * np.abs(ref_o['m']).max()
+    assert np.abs(st['m'] - ref_o['m']).max() <= 5e-5 * np.abs(ref_o['m']).max()
     assert np.abs(st['s'] - ref_o['s']).max() <= 1e-5 * np.abs(ref_o['s']).max()
     # a state that does not fit the model is refused when it is applied
     c, _ = _lite(sp, seed=4)
