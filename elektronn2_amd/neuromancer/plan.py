@@ -317,25 +317,44 @@ class Plan(object):
         return jobs
 
     # ---- second stream ----------------------------------------------------------------
-    def on_side(self, fn, always=False):
+    def on_side(self, fn, always=False, defer=False):
         """run the launches of ``fn`` on the side stream, ordered after everything
         issued on the main stream so far.  ``always``: also when the general side-stream
-        switch is off (the weight repack: it overlaps the first layer's HBM-bound kernel)"""
+        switch is off (the weight repack: it overlaps the first layer's HBM-bound kernel).
+        ``defer``: see plan option side_defer"""
         if not (self.use_side or (always and self.use_side_pack)):
             return fn()
+        self._flush_side()                 # (the side stream keeps the order of the on_side calls)
+        self.ctx.stream_fork(self.side)    # the dependency is fixed HERE: main's launches so far
+        self._side_dirty = True
+        if defer and self.opt['side_defer']:
+            # issue the launches later (at the next on_side / join_side), i.e. BEHIND the next
+            # launches of the main stream: what they wait for is unchanged, but in the captured
+            # graph the main chain's next kernel becomes the fork node's FIRST child -- the
+            # runtime keeps first children on their parent's queue, so the main chain stays on
+            # one queue instead of hopping (a hop costs 6-10 us, DESIGN finding 54)
+            self._side_pending = fn
+            return
+        self._run_side(fn)
+
+    def _run_side(self, fn):
         ctx = self.ctx
         main = ctx.stream
-        ctx.stream_fork(self.side)
         ctx.set_stream(self.side)
         try:
             with torch.cuda.stream(self.side):
                 fn()
         finally:
             ctx.set_stream(main)
-        self._side_dirty = True
+
+    def _flush_side(self):
+        fn, self._side_pending = self._side_pending, None
+        if fn is not None:
+            self._run_side(fn)
 
     def join_side(self):
         """main stream waits for the side stream (no-op when nothing ran there)"""
+        self._flush_side()
         if self._side_dirty:
             self.ctx.stream_join(self.side)
             self._side_dirty = False
@@ -373,6 +392,7 @@ class Plan(object):
         # data-gradient chain; inside the captured graph they are parallel branches
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
+        self._side_pending = None
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
         # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
@@ -581,10 +601,16 @@ class Plan(object):
             # _run_device when someone else touched the parameters)
             if self._pack_dev_up is not None:
                 self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev_up), always=True)
-        elif self._pack_dev is not None:     # all packed weight images, one launch
-            self.on_side(lambda: self.ctx.conv3d_pack_multi(*self._pack_dev), always=True)
         self._xb_ready, self._dy_ready = {}, {}
         self._wb_ready = False               # bf16 mode: see ensure_wb
+        if self._upd is None and self._pack_dev is not None:     # all packed weight images, one launch
+            def packs():
+                self.ctx.conv3d_pack_multi(*self._pack_dev)
+                if self.use_side and self.opt['wb_on_side']:
+                    # bf16 mode: the filter rows of every layer too, beside the fused first layer
+                    # (which reads neither) instead of behind it
+                    self.ensure_wb()
+            self.on_side(packs, always=True)
         for n in self.nodes:
             n._plan_fwd(self)
         self.join_side()
