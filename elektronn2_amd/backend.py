@@ -195,6 +195,7 @@ def _load():
         "e2_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
         "e2_graph_launch": (C.c_int, [vp, vp]),
         "e2_graph_destroy": (C.c_int, [vp]),
+        "e2_graph_debug_dot": (C.c_int, [vp, C.c_char_p, i]),
         "e2_event_create": (C.c_int, [C.POINTER(vp)]),
         "e2_event_record": (C.c_int, [vp, vp]),
         "e2_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
@@ -968,6 +969,9 @@ class Context:
 
     def graph_destroy(self, g):
         _chk(_lib.e2_graph_destroy(g), "e2_graph_destroy")
+
+    def graph_debug_dot(self, g, path, verbose=True):
+        _chk(_lib.e2_graph_debug_dot(g, str(path).encode(), 1 if verbose else 0), "e2_graph_debug_dot")
 
     def event(self):
         e = C.c_void_p()

@@ -673,6 +673,12 @@ extern "C" int e2_graph_launch(e2_ctx* ctx, e2_graph* g) {
   return 0;
 }
 
+extern "C" int e2_graph_debug_dot(e2_graph* g, const char* path, int verbose) {
+  E2_REQUIRE(g && path, "graph_debug_dot: null argument");
+  E2_CHECK_HIP(hipGraphDebugDotPrint(g->graph, path, verbose ? hipGraphDebugDotFlagsKernelNodeParams : 0));
+  return 0;
+}
+
 extern "C" int e2_graph_destroy(e2_graph* g) {
   if (!g) return 0;
   (void)hipGraphExecDestroy(g->exec);

@@ -502,6 +502,9 @@ int e2_graph_begin(e2_ctx*);                 /* hipStreamBeginCapture      */
 int e2_graph_end(e2_ctx*, e2_graph** out);   /* EndCapture + Instantiate   */
 int e2_graph_launch(e2_ctx*, e2_graph*);     /* hipGraphLaunch on the stream*/
 int e2_graph_destroy(e2_graph*);
+/* the captured graph as a GraphViz file (hipGraphDebugDotPrint; verbose: with the kernels' names) --
+ * how the fork / join structure of a plan with a side stream was looked at (DESIGN finding 54) */
+int e2_graph_debug_dot(e2_graph*, const char* path, int verbose);
 
 /* ---- timing helpers (HIP events on the context's stream) -------------- */
 /* ---- patch extraction with warp + grey augmentation on the device (SURVEY 8f-1;
