@@ -40,6 +40,9 @@ SPEC = {
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),
+    "side_keepalive": ("E2_SIDE_KEEPALIVE", int, 0,
+                       "side stream on, training: a one-float launch on the side stream after every n-th "
+                       "forward node (0 = none), see DESIGN finding 54"),
     "side_pack": ("E2_SIDE_PACK", _b, False, "weight repack as a parallel branch (measured slower)"),
     "fuse_actbwd": ("E2_FUSE_ACTBWD", int, 0, "relu backward in the consumer's dgrad epilogue (finding 17)"),
     "fuse_tail": ("E2_FUSE_TAIL", _b, True, "last 1x1x1 conv + head + loss in one launch (finding 33)"),

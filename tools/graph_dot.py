@@ -8,12 +8,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import bench as B
-from elektronn2_amd import nets, neuromancer as nm, backend
+import elektronn2_amd
+from elektronn2_amd import nets, neuromancer as nm
 
 wl, mode, out = sys.argv[1], sys.argv[2], sys.argv[3]
 builder, sp, _ = B.WORKLOADS[wl]
 if mode == "bf16":
-    backend.get_ctx().set_mfma_dtype("bf16")
+    elektronn2_amd.set_mfma_dtype("bf16")
 np.random.seed(1)
 m = getattr(nets, builder)((None, 1) + sp)
 m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
