@@ -337,6 +337,19 @@ class Plan(object):
             return
         self._run_side(fn)
 
+    def side_rank(self, node):
+        """position of a Conv node among the conv layers whose weight gradient is a launch of its
+        own (forward order: 0 = the one the backward pass reaches last)"""
+        if self._side_order is None:
+            from .neural import Conv
+            self._side_order = [n for n in self.nodes if isinstance(n, Conv) and hasattr(n, '_k3')
+                                and n.parent is not None and not n._fused_first(self)
+                                and n._fused_head(self) is None]
+        try:
+            return self._side_order.index(node)
+        except ValueError:
+            return 1 << 30
+
     def _run_side(self, fn):
         ctx = self.ctx
         main = ctx.stream
@@ -393,7 +406,7 @@ class Plan(object):
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
         self._side_pending = None
-        self._tick, self._ticked = None, False
+        self._side_order = None
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
         # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
@@ -612,18 +625,8 @@ class Plan(object):
                     # (which reads neither) instead of behind it
                     self.ensure_wb()
             self.on_side(packs, always=True)
-        ka = int(self.opt['side_keepalive']) if self.use_side and self.training else 0
-        for i, n in enumerate(self.nodes):
+        for n in self.nodes:
             n._plan_fwd(self)
-            if ka and i % ka == ka - 1 and not self._side_dirty:
-                # a hardware queue that has sat behind a barrier packet for ~300 us wakes up
-                # 150-190 us late (DESIGN finding 54): the side stream gets a one-float launch
-                # every few forward nodes, so that the weight gradients find it awake
-                if self._tick is None:
-                    self._tick = torch.zeros(64, device=self.ctx.device)
-                self.on_side(lambda: self._tick.zero_())
-                self._side_dirty = False          # (not joined here: the backward's join covers it)
-                self._ticked = True
         self.join_side()
 
     def ensure_wb(self):
@@ -653,8 +656,6 @@ class Plan(object):
             self._grad_written = set()
         for n in nodes:
             n._plan_bwd(self)
-        if self._ticked:
-            self._side_dirty, self._ticked = True, False
         self.join_side()
 
     def _dp_cut(self):
