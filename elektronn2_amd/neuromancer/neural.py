@@ -778,10 +778,7 @@ class Conv(NeuralLayer):
                            lambda: wgrad(True), fn_tune=lambda: wgrad(False))
             finally:
                 ctx.set_input_slack(0)
-        if plan.side_rank(self) < int(plan.opt['side_last_main']):
-            wgrad_launch()                    # (one of the last of the backward: see the option)
-        else:
-            plan.on_side(wgrad_launch, defer=True)
+        plan.on_side(wgrad_launch, defer=True)
         if plan.needs_grad(self.parent) and not tail:
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']
