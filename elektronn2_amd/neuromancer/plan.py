@@ -610,7 +610,7 @@ class Plan(object):
                     # bf16 mode: the filter rows of every layer too, beside the fused first layer
                     # (which reads neither) instead of behind it
                     self.ensure_wb()
-            self.on_side(packs, always=True, defer=bool(self.opt['pack_defer']))
+            self.on_side(packs, always=True)
         for n in self.nodes:
             n._plan_fwd(self)
         self.join_side()
