@@ -55,10 +55,10 @@ def prepare(plan):
         return
     a = plan.bf16a
     if not a:
-        # engage once every launch's tiling is known, and only where the kernels with bf16
-        # operands in memory carry most of the GEMM launches: neuro3d_lite@183 (11 of 13) gains
-        # 5 %, neuro3d@185 (11 of 25: its small late layers run the operand-rounding kernels on
-        # f32 tensors) loses 1-2 % to the extra stores of the producers (measured)
+        # engage once every launch's tiling is known -- and, with option bf16_ahead_min > 0, only
+        # where the kernels with bf16 operands in memory carry that share of the GEMM launches
+        # (round 4's rule, 0.6; since the side stream runs on a queue of its own the producers pay
+        # on neuro3d@185 too, whose small late layers run the operand-rounding kernels: default 0)
         mem = tot = 0
         for node in conv_nodes(plan):
             if not eligible(plan, node) or plan.out[node.parent] is None:

@@ -63,7 +63,11 @@ SPEC = {
     "dp_overlap": ("E2_DP_OVERLAP", _b, True, "exchange the late layers' gradients under the early backward"),
     "dp_fused_scale": ("E2_DP_FUSED_SCALE", _b, True, "collectives only sum, the optimiser kernel normalises"),
     "bf16_ahead": ("E2_BF16_AHEAD", _b, True, "bf16 mode: producers write the GEMM operands (finding 43)"),
-    "bf16_ahead_min": ("E2_BF16_AHEAD_MIN", float, 0.6, "... only when this share of the GEMM launches are memory forms"),
+    "bf16_ahead_min": ("E2_BF16_AHEAD_MIN", float, 0.0,
+                       "... only when this share of the GEMM launches are memory forms (round 4: 0.6, neuro3d's "
+                       "11 of 25 stayed out; with the side stream on a queue of its own -- finding 54 -- engaging "
+                       "them pays there too: neuro3d 0.948 -> 0.930 ms, unet3d 6.12 -> 5.84, neuro3d_lite 0.682 -> "
+                       "0.640; unet3d_lite 2.44 -> 2.47 is the one that loses)"),
     "bf16_ahead_wgrad_only": ("E2_BF16_AHEAD_WGRAD_ONLY", _b, False, "... gradient images for the weight gradient alone"),
     "bf16_xkeep": ("E2_BF16_XKEEP", _b, True, "bf16 mode: the forward's channels-last copy of x serves the wgrad"),
     "bf16_wpack": ("E2_BF16_WPACK", str, "step", "'step': one filter-row pack launch per step; 'call': per launch"),
