@@ -40,9 +40,6 @@ SPEC = {
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),
-    "side_priority": ("E2_SIDE_PRIORITY", int, 0,
-                      "stream priority of the side stream (0 = default, -1 = high): whether the weight gradients "
-                      "get CUs while the main chain's kernels queue for every one of them (finding 54)"),
     "side_pack": ("E2_SIDE_PACK", _b, False, "weight repack as a parallel branch (measured slower)"),
     "fuse_actbwd": ("E2_FUSE_ACTBWD", int, 0, "relu backward in the consumer's dgrad epilogue (finding 17)"),
     "fuse_tail": ("E2_FUSE_TAIL", _b, True, "last 1x1x1 conv + head + loss in one launch (finding 33)"),

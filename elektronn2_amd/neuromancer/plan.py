@@ -390,7 +390,7 @@ class Plan(object):
         self.stream = torch.cuda.Stream(device=self.ctx.device)
         # second stream: weight gradients (and the weight repack) run next to the
         # data-gradient chain; inside the captured graph they are parallel branches
-        self.side = torch.cuda.Stream(device=self.ctx.device, priority=int(self.opt['side_priority']))
+        self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
         self._side_pending = None
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
