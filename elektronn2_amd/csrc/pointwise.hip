@@ -903,6 +903,66 @@ extern "C" int e2_fill_multi(e2_ctx* ctx, const void* ptrs_dev, const void* coun
   return 0;
 }
 
+// ---- several steps in one graph: the batches come out of a ring in HBM, the losses go into one ----
+// A captured step is the same launches every time; what changes from step to step are the batch
+// and the loss.  Both become position-independent through a TICKET: every launch of these kernels
+// advances a 64-bit counter in HBM (one atomic per work-group, all work-groups of a launch get
+// consecutive values because launches of one stream do not overlap), and launch number L reads
+// slot L % n of the batch ring / writes slot L % n of the history.  So the SAME captured step can
+// stand k times in one graph (DESIGN finding 55).
+__global__ __launch_bounds__(256) void ring_fetch_kernel(const float* __restrict__ ring, int nSlots,
+                                                         long slotFloats, unsigned long long* ticket,
+                                                         float* __restrict__ dst) {
+  __shared__ unsigned long long t;
+  if (threadIdx.x == 0) t = atomicAdd(ticket, 1ull);
+  __syncthreads();
+  const int slot = (int)((t / gridDim.x) % (unsigned long long)nSlots);
+  const float* src = ring + (long)slot * slotFloats;
+  const long n4 = slotFloats >> 2;
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (slotFloats & 3)) dst[4 * n4 + threadIdx.x] = src[4 * n4 + threadIdx.x];
+}
+
+/* dst[0 .. slot_floats) = ring[(launch number % n_slots)][...]; *ticket (a zeroed 64-bit word in
+ * device memory, owned by the caller, used with ONE (n_slots, slot_floats) only) counts the
+ * launches.  ring, dst: 16-byte aligned; slot_floats * 4 bytes per slot. */
+extern "C" int e2_ring_fetch(e2_ctx* ctx, const float* ring, int n_slots, size_t slot_floats,
+                             void* ticket, float* dst) {
+  E2_REQUIRE(ctx && ring && ticket && dst && n_slots > 0 && slot_floats > 0, "e2_ring_fetch: bad argument");
+  E2_REQUIRE((((uintptr_t)ring | (uintptr_t)dst) & 15) == 0 && ((slot_floats * 4) & 15) == 0 &&
+                 ((uintptr_t)ticket & 7) == 0,
+             "e2_ring_fetch: ring / dst must be 16-byte aligned, slots a multiple of 16 bytes, the ticket 8-byte aligned");
+  const int grid = (int)std::min<size_t>(((slot_floats >> 2) + 255) / 256, 1024);   // (a function of slot_floats ONLY)
+  hipLaunchKernelGGL(ring_fetch_kernel, dim3(grid), dim3(256), 0, ctx->stream, ring, n_slots,
+                     (long)slot_floats, (unsigned long long*)ticket, dst);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ __launch_bounds__(64) void hist_push_kernel(const float* __restrict__ src, int nVals,
+                                                       float* __restrict__ hist, int nSlots,
+                                                       unsigned long long* ticket) {
+  __shared__ unsigned long long t;
+  if (threadIdx.x == 0) t = atomicAdd(ticket, 1ull);
+  __syncthreads();
+  float* d = hist + (long)(t % (unsigned long long)nSlots) * nVals;
+  for (int i = threadIdx.x; i < nVals; i += 64) d[i] = src[i];
+}
+
+/* hist[(launch number % n_slots)][0 .. n_vals) = src[0 .. n_vals): the loss (and whatever else a
+ * step leaves in a small device buffer) of every step of a multi-step graph */
+extern "C" int e2_hist_push(e2_ctx* ctx, const float* src, int n_vals, float* hist, int n_slots,
+                            void* ticket) {
+  E2_REQUIRE(ctx && src && hist && ticket && n_vals > 0 && n_slots > 0 && ((uintptr_t)ticket & 7) == 0,
+             "e2_hist_push: bad argument");
+  hipLaunchKernelGGL(hist_push_kernel, dim3(1), dim3(64), 0, ctx->stream, src, n_vals, hist, n_slots,
+                     (unsigned long long*)ticket);
+  E2_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int e2_set_skip_zero_fill(e2_ctx* ctx, int on) {
   E2_REQUIRE(ctx, "e2_set_skip_zero_fill: null context");
   ctx->skip_zero_fill = on ? 1 : 0;

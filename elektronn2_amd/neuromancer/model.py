@@ -469,6 +469,32 @@ class Model(GraphManager):
             return loss, t, ret[1:]
         return loss, t, None
 
+    def trainingsteps(self, k, optimiser='SGD', ring=None):
+        """``k`` optimiser iterations with ONE graph launch -> ``(losses[k], t)``, t = device
+        seconds of the launch.  ``ring``: a float32 device tensor (n_slots, plan.input_arena.numel())
+        of batches in the layout of the training plan's input arena (``plan.input_slices``); step i
+        takes slot (steps so far) % n_slots.  Without a ring every step re-reads the inputs of
+        the last ``trainingstep``.  The first ``trainingstep`` must have run (it builds the plan).
+        No reference counterpart: training/trainer.py:186-194 is one batch, one step, one loss
+        read-back per iteration; here the ~19 us the device idles between two launches are paid
+        once per k steps (DESIGN finding 55)."""
+        if optimiser not in self.optimisers:
+            logger.warning("No optimiser '%s'. Falling back to SGD" % (optimiser,))
+            optimiser = 'SGD'
+        opt = self.optimisers[optimiser]
+        plan = opt.step.func
+        if plan is None or not plan._built:
+            raise RuntimeError("trainingsteps: call trainingstep once first (it builds the plan)")
+        if ring is not None and (plan._ring is None or plan._ring['ring'] is not ring):
+            plan.set_input_ring(ring)
+        losses, t = opt.steps(k)
+        self.elapsed_time += t
+        for l in losses:
+            self._last_exec_times.append(t / k + 1e-10)
+            self._last_losses.append(l)
+        self.iterations += int(k)
+        return losses, t
+
     def test_run_prediction(self):
         self.prediction_node.test_run()
 

@@ -101,6 +101,29 @@ class Optimiser(object):
         self.step.last_exec_time = plan.last_device_time
         return ret
 
+    def steps(self, k):
+        """``k`` steps with one graph launch (Plan.run_steps) on the batches of the plan's input
+        ring -- or k times on the inputs last set; -> (losses of the k steps, device seconds of
+        all of them).  No reference counterpart (training/trainer.py:186-194 runs one step per
+        batch and reads its loss back before the next)."""
+        plan = self.step.func
+        if plan is None or not plan._built:
+            raise RuntimeError("steps: run one ordinary step first (it builds the plan)")
+        import torch
+        with torch.cuda.stream(plan.stream):
+            self._ensure_state(plan)
+            self._sync_hyper(plan)
+        plan.keep_loss_history()
+        n0 = plan._n_runs
+        t = 0.0
+        plan.run_steps(k)
+        losses = plan.loss_history(k)               # (waits for the steps)
+        if plan._n_runs - n0 == k:
+            t = plan.ctx.elapsed_ms(plan._ev0, plan._ev1) * 1e-3    # (the last launch: all k when it was one)
+        self.last_exec_time = t
+        self.step.last_exec_time = t
+        return losses, t
+
     # subclasses
     def _ensure_state(self, plan):
         raise NotImplementedError

@@ -383,8 +383,8 @@ class Plan(object):
     # ---- build ------------------------------------------------------------------------
     def build(self, batch):
         self.ctx = get_ctx()
-        for g in (getattr(self, '_graphs', None) or []):     # batch size changed: drop the
-            self.ctx.graph_destroy(g)                        # graphs captured for the old one
+        for g in list(getattr(self, '_graphs', None) or []) + list(getattr(self, '_multi', {}).values()):
+            self.ctx.graph_destroy(g)        # batch size changed: drop the graphs captured for the old one
         self._graphs = None
         self.batch = int(batch)
         self.stream = torch.cuda.Stream(device=self.ctx.device)
@@ -459,6 +459,10 @@ class Plan(object):
         self._ev_idx = 0
         self._n_runs = 0                     # run() calls so far (fetch_async pairs slots with runs)
         self._async = None                   # state of fetch_async: pinned loss slots, events
+        # several steps in one graph (run_steps): batches out of a device-side ring, losses into one
+        self._ring = None                    # dict(ring=(n_slots, arena floats), ticket=int64[1])
+        self._hist = None                    # dict(buf=(n_slots, 1), ticket=int64[1])
+        self._multi = {}                     # k -> graph of k steps
         self._built = True
 
     @property
@@ -810,8 +814,9 @@ class Plan(object):
             # (data parallelism switched on / its weighting changed after earlier steps: re-plan
             # and re-capture)
             self._segs, self._segs_key = self._segments(), key
-            for g in (self._graphs or []):
+            for g in list(self._graphs or []) + list(self._multi.values()):
                 ctx.graph_destroy(g)
+            self._multi = {}
             if self._graphs is not None:
                 self._calls = 0          # one eager run of the new segmentation first
             self._graphs = None
@@ -850,9 +855,7 @@ class Plan(object):
                     self._capturing = True
                     ctx.graph_begin()
                     try:
-                        if i in zero_jobs:
-                            ctx.fill_multi(*zero_jobs[i])
-                        emit()
+                        self._emit_seg(i, emit, zero_jobs)
                     except BaseException:
                         # leave capture mode (a stream stuck in capture poisons every later
                         # launch of the context) and drop the partial graph
@@ -888,7 +891,7 @@ class Plan(object):
             if capture:
                 ctx.graph_launch(self._graphs[i])
             else:
-                emit()
+                self._emit_seg(i, emit, None)
             if after is not None:
                 after()
         ctx.record(self._ev1)
@@ -897,6 +900,152 @@ class Plan(object):
             self.model._g_clean = self._upd_zeroes_g()
             if self.step in ('Adam', 'SGD'):       # (this step wrote P: whose images are current?)
                 self.model._img_owner = self if self._upd is not None else None
+
+    def _emit_seg(self, i, emit, zero_jobs):
+        """the launches of segment i: (batch out of the ring) + (batched zero fills) + the segment
+        + (loss into the history)"""
+        ctx = self.ctx
+        if i == 0 and self._ring is not None:
+            ctx.ring_fetch(self._ring['ring'], self._ring['ticket'], self.input_arena)
+        if zero_jobs and i in zero_jobs:
+            ctx.fill_multi(*zero_jobs[i])
+        emit()
+        if self._hist is not None and i == len(self._segs) - 1:
+            ctx.hist_push(self._loss_dev(), self._hist['buf'], self._hist['ticket'])
+
+    def _loss_dev(self):
+        nll = self.loss_node.parent[0] if isinstance(self.loss_node.parent, (list, tuple)) \
+            else self.loss_node.parent
+        return self.scratch[nll, 'loss']
+
+    def _drop_graphs(self):
+        """the captured graphs no longer describe the step (a ring was attached ...): capture again
+        at the next run (no eager run in between: tilings and buffers are unchanged)"""
+        for g in list(self._graphs or []) + list(self._multi.values()):
+            self.ctx.graph_destroy(g)
+        self._graphs, self._multi = None, {}
+
+    # ---- several steps per launch --------------------------------------------------------------
+    def set_input_ring(self, ring):
+        """The step takes its batch out of ``ring[(steps so far) % n_slots]`` -- a float32 device
+        tensor (n_slots, input_arena.numel()), every slot in the layout of ``input_arena``
+        (``input_slices``: image | target, 16-byte aligned slices) -- by a launch of its own graph
+        (e2_ring_fetch) instead of waiting for ``set_inputs``.  ``None`` detaches the ring.  The
+        producer (data/batch.py's sampler on its stream, or host copies) fills slots AHEAD of the
+        steps that read them and orders itself against the plan's stream; the reference's
+        counterpart is the BackgroundProc queue of training/trainer.py:174-186."""
+        if ring is not None:
+            if not self._built:
+                raise RuntimeError("set_input_ring: build the plan first (set_inputs / one step)")
+            if not (isinstance(ring, torch.Tensor) and ring.is_cuda and ring.dtype == torch.float32
+                    and ring.dim() == 2 and ring.is_contiguous()
+                    and ring.shape[1] == self.input_arena.numel() and ring.data_ptr() % 16 == 0):
+                raise ValueError("set_input_ring: a contiguous float32 device tensor (n_slots, %d) is needed"
+                                 % self.input_arena.numel())
+            self._ring = dict(ring=ring, ticket=torch.zeros(1, dtype=torch.int64, device=self.ctx.device))
+        else:
+            self._ring = None
+        self._drop_graphs()
+
+    def ring_position(self):
+        """steps that have taken a batch out of the ring so far (reads the device counter: waits)"""
+        if self._ring is None:
+            return 0
+        self.stream.synchronize()
+        grid = min(((self.input_arena.numel() >> 2) + 255) // 256, 1024)
+        return int(self._ring['ticket'].item()) // grid
+
+    def keep_loss_history(self, n_slots=256):
+        """every step also stores its loss in a device-side ring of ``n_slots`` entries
+        (e2_hist_push); ``loss_history(n)`` reads the last n"""
+        if not self.training:
+            raise RuntimeError("keep_loss_history: a training plan is needed")
+        if self._hist is None or self._hist['buf'].shape[0] != int(n_slots):
+            dev = self.ctx.device
+            self._hist = dict(buf=torch.zeros(int(n_slots), 1, device=dev),
+                              ticket=torch.zeros(1, dtype=torch.int64, device=dev))
+            self._drop_graphs()
+
+    def loss_history(self, n):
+        """the losses of the last n steps, oldest first (waits for the plan's stream)"""
+        if self._hist is None:
+            raise RuntimeError("loss_history: call keep_loss_history() before the steps")
+        self.stream.synchronize()
+        t = int(self._hist['ticket'].item())
+        ns = self._hist['buf'].shape[0]
+        if n > min(t, ns):
+            raise ValueError("loss_history: %d steps asked for, %d kept" % (n, min(t, ns)))
+        h = self._hist['buf'][:, 0].cpu().numpy()
+        return np.array([h[(t - n + j) % ns] for j in range(n)], np.float32)
+
+    def run_steps(self, k):
+        """``k`` training steps on the device with ONE graph launch where the step is a single
+        graph (no data-parallel exchange, no host part between its launches); otherwise k calls
+        of run().  Batches: the input ring if one is attached, else every step re-reads the
+        static input buffers.  Losses: keep_loss_history() is switched on; read them with
+        loss_history(k).  Why: between two graph launches the device idles ~19 us (DESIGN
+        findings 54, 55)."""
+        k = int(k)
+        if k < 1:
+            return
+        if not self.training:
+            raise RuntimeError("run_steps: a training plan is needed")
+        if self._hist is None:
+            self.keep_loss_history()
+        # (the first calls of a plan are the eager run and the capture of the single step)
+        while k > 0 and (self._graphs is None or not self.use_graph or len(self._segs) != 1
+                         or self._segs[0][1] is not None or self._segs_key != self._dp_key()):
+            self.run()
+            k -= 1
+            if not self.use_graph or (self._segs is not None and
+                                      (len(self._segs) != 1 or self._segs[0][1] is not None)):
+                for _ in range(k):
+                    self.run()
+                return
+        if k == 0:
+            return
+        if k == 1:
+            return self.run()
+        self._ev_idx ^= 1
+        ctx = self.ctx
+        old = ctx.stream
+        ctx.set_stream(self.stream)
+        try:
+            with torch.cuda.stream(self.stream):
+                if self._upd_zeroes_g() and not self.model._g_clean:
+                    ctx.fill(self.model.G, 0.0)
+                self.model._g_clean = False
+                if self._upd is not None and getattr(self.model, '_img_owner', None) is not self:
+                    ctx.conv3d_pack_multi(*self._pack_dev)
+                g = self._multi.get(k)
+                if g is None:
+                    emit = self._segs[0][0]
+                    self._seg_idx = 0
+                    self._capturing = True
+                    ctx.graph_begin()
+                    try:
+                        for _ in range(k):
+                            self._emit_seg(0, emit, self._zero_keep)
+                    except BaseException:
+                        self._capturing = False
+                        try:
+                            ctx.graph_destroy(ctx.graph_end())
+                        except Exception:
+                            pass
+                        raise
+                    g = ctx.graph_end()
+                    self._capturing = False
+                    self._multi[k] = g
+                ctx.record(self._ev0)
+                ctx.graph_launch(g)
+                ctx.record(self._ev1)
+                self._calls += k
+                self._n_runs += k
+                self.model._g_clean = self._upd_zeroes_g()
+                if self.step in ('Adam', 'SGD'):
+                    self.model._img_owner = self if self._upd is not None else None
+        finally:
+            ctx.set_stream(old)
 
     # ---- call ----------------------------------------------------------------------------------
     def set_inputs(self, args):

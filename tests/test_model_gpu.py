@@ -486,3 +486,55 @@ def test_plan_tensors_carry_zeroed_slack_and_the_step_uses_the_position_split_wg
                 assert float(tail.abs().max()) == 0.0, node.name
         n = p.input_arena.numel()
         assert float(torch.as_strided(p.input_arena, (Plan.SLACK,), (1,), n).abs().max()) == 0.0
+
+
+def test_several_steps_in_one_graph_launch():
+    """Model.trainingsteps / Plan.run_steps (DESIGN finding 55): k steps captured into ONE graph,
+    the batches taken out of a device-side ring by the graph itself, the losses kept in a
+    device-side history.  Nine steps over a ring of four different batches -- as a run of single
+    steps fed through trainingstep, and as trainingstep + trainingsteps(5) + trainingsteps(3)
+    (the first of which still contains the single step's capture) -- give the same losses step by
+    step and the same parameters (to the weight gradients' atomic order: finding 53)."""
+    spec, sp = O.NEURO3D_LITE, (7, 47, 47)
+    params = O.init_net(spec, 1, seed=3)
+    rng = np.random.RandomState(8)
+    osp = O.net_out_shape(spec, sp)
+    xs = [rng.rand(1, 1, *sp).astype(np.float32) for _ in range(4)]
+    ts = [rng.randint(0, 2, (1, 1) + osp).astype(np.float32) for _ in range(4)]
+    a = build('lite', sp, params)
+    la = [float(a.trainingstep(xs[i % 4], ts[i % 4], optimiser='Adam')[0]) for i in range(9)]
+    pa = [p.get_value() for p in a.loss_node.all_trainable_params.values()]
+
+    b = build('lite', sp, params)
+    lb = [float(b.trainingstep(xs[0], ts[0], optimiser='Adam')[0])]           # builds the plan (eager)
+    plan = b.optimisers['Adam'].step.func
+    ring = torch.zeros(4, plan.input_arena.numel(), device=plan.ctx.device)
+    for j in range(4):
+        for node, src in zip(plan.inputs[:2], (xs[j], ts[j])):
+            o, n = plan.input_slices[node]
+            ring[j, o:o + n] = torch.tensor(src.ravel(), device=ring.device)
+    # the ring's next slot is the one of step 1: start the count there
+    plan.set_input_ring(ring)
+    plan._ring['ticket'] += min(((plan.input_arena.numel() >> 2) + 255) // 256, 1024)
+    l5, t5 = b.trainingsteps(5, optimiser='Adam', ring=ring)
+    assert len(l5) == 5 and plan._multi, "no multi-step graph was captured"
+    k_cap = sorted(plan._multi)
+    l3, t3 = b.trainingsteps(3, optimiser='Adam', ring=ring)
+    assert len(l3) == 3 and 3 in plan._multi and t3 > 0
+    lb += [float(v) for v in l5] + [float(v) for v in l3]
+    assert plan.ring_position() == 9 and b.iterations == 9
+    for i, (u, v) in enumerate(zip(la, lb)):
+        assert abs(u - v) < 1e-5 * abs(u), (i, la, lb, k_cap)
+    for u, v in zip(pa, [p.get_value() for p in b.loss_node.all_trainable_params.values()]):
+        assert rel(v, u) < 1e-4
+    # a second launch of the SAME 3-step graph goes on counting (slots 1, 2, 3)
+    l3b, _ = b.trainingsteps(3, optimiser='Adam')
+    assert plan.ring_position() == 12
+    more = [float(a.trainingstep(xs[i % 4], ts[i % 4], optimiser='Adam')[0]) for i in range(9, 12)]
+    for u, v in zip(more, l3b):
+        assert abs(u - float(v)) < 1e-5 * abs(u)
+    # detaching the ring returns to set_inputs
+    plan.set_input_ring(None)
+    one = float(b.trainingstep(xs[0], ts[0], optimiser='Adam')[0])
+    ref = float(a.trainingstep(xs[0], ts[0], optimiser='Adam')[0])
+    assert abs(one - ref) < 1e-5 * abs(ref)
