@@ -440,19 +440,54 @@ def time_training(workload, args, rank, world, dev, steps, warmup):
             flat[o:o + n_el] = src.reshape(-1)
         staged.append(flat)
 
+    # Steps per graph launch (--steps-per-launch, default 10; 1 = one launch per step as in rounds
+    # 1-4).  With k > 1 on one GPU the staged batches are the slots of the plan's INPUT RING: every
+    # captured step fetches its batch from HBM itself (e2_ring_fetch: the same bytes the copy below
+    # moves), stores its loss in the device-side history (e2_hist_push), and k steps form one graph
+    # -- the ~19 us the device idles between two launches are paid once per k steps (DESIGN finding
+    # 55).  The data-parallel step (an exchange between its graphs) keeps one launch per segment.
+    kpl = max(1, min(int(args.steps_per_launch), steps)) if (world == 1 and not args.exchange_at_1
+                                                            and plan.use_graph) else 1
+    done = [0]
+
     def one_step(i):
         with torch.cuda.stream(plan.stream):
-            arena.copy_(staged[i % n_batches], non_blocking=True)
+            if plan._ring is None:
+                arena.copy_(staged[i % n_batches], non_blocking=True)
             opt._ensure_state(plan)
             opt._sync_hyper(plan)
         plan.run()
+        done[0] += 1
+
+    def advance(n):
+        """n steps: graphs of kpl steps, the remainder as single steps (which fetch from the ring too)"""
+        if kpl == 1:
+            for _ in range(n):
+                one_step(done[0])
+            return
+        with torch.cuda.stream(plan.stream):
+            opt._ensure_state(plan)
+            opt._sync_hyper(plan)
+        for _ in range(n // kpl):
+            plan.run_steps(kpl)
+            done[0] += kpl
+        for _ in range(n % kpl):
+            one_step(done[0])
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    for i in range(warmup):
-        one_step(i)
+    if kpl > 1:
+        # set-up, untimed and not counted as warm-up: the eager step, the capture of the single
+        # step (with the ring attached: it contains the fetch), the capture of the kpl-step graph
+        one_step(0)
+        plan.set_input_ring(torch.stack(staged))
+        plan.keep_loss_history()
+        one_step(1)
+        plan.run_steps(kpl)
+        assert kpl in plan._multi, "the %d-step graph was not captured" % kpl
+    advance(warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -461,8 +496,7 @@ def time_training(workload, args, rank, world, dev, steps, warmup):
     old = ctx.stream
     t0 = time.perf_counter()
     ctx.set_stream(plan.stream); ctx.record(e0); ctx.set_stream(old)
-    for i in range(steps):
-        one_step(warmup + i)
+    advance(steps)
     ctx.set_stream(plan.stream); ctx.record(e1); ctx.set_stream(old)
     torch.cuda.synchronize()
     barrier()
@@ -471,8 +505,12 @@ def time_training(workload, args, rank, world, dev, steps, warmup):
     dev_ms = ctx.elapsed_ms(e0, e1) / steps
     loss = float(plan.scratch[model.loss_node.parent[0], 'loss'].item())
     assert np.isfinite(loss), "non-finite loss"
+    if kpl > 1:
+        # every timed step took a batch and left a loss: the ring and the history counted them
+        hist = plan.loss_history(min(steps, 256))
+        assert np.isfinite(hist).all() and abs(float(hist[-1]) - loss) <= 1e-6 * abs(loss), (hist[-3:], loss)
     return dict(builder=builder, sp=sp, osp=osp, gflop=gflop, params0=params0, model=model,
-                plan=plan, xs=xs, ts=ts, dt=dt, dev_ms=dev_ms, loss=loss)
+                plan=plan, xs=xs, ts=ts, dt=dt, dev_ms=dev_ms, loss=loss, kpl=kpl)
 
 
 _REAL_STDOUT = None
@@ -505,6 +543,9 @@ def main():
     ap.add_argument("--workload", default="lite183", choices=sorted(WORKLOADS) + ["dense183", "dense183mfp", "dense512unet", "warp183", "selftest"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--steps-per-launch", type=int, default=int(os.environ.get("E2_STEPS_PER_LAUNCH", "10")),
+                    help="training steps per graph launch at N = 1 (Plan.run_steps: batches from a "
+                         "device-side ring, losses into a device-side history); 1 = one launch per step")
     ap.add_argument("--no-also", action="store_true",
                     help="lite183 at N = 1 also times neuro3d@185 and the two U-Nets "
                          "(roofline.also.<workload>); skip them")
@@ -624,7 +665,7 @@ def main():
                                                     if args.exchange_at_1 and world == 1 else ""),
                    "ranks": ranks,
                    "output_voxels_per_sec": float(np.prod(osp)) * world * args.steps / dt,
-                   "hipgraph": bool(plan.use_graph), "final_loss": loss},
+                   "hipgraph": bool(plan.use_graph), "steps_per_launch": r["kpl"], "final_loss": loss},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak,
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": None if bf16 else prof["traffic"],
@@ -666,7 +707,7 @@ def main():
                 out["roofline"]["also"][wl] = {
                     "workload": "%s (1,1,%d,%d,%d)->(1,2,%d,%d,%d) fwd+bwd+Adam, 1 sample/GPU"
                                 % ((r2["builder"],) + tuple(r2["sp"]) + tuple(r2["osp"])),
-                    "steps": args.steps, "warmup": args.warmup,
+                    "steps": args.steps, "warmup": args.warmup, "steps_per_launch": r2["kpl"],
                     "ms_per_step": r2["dt"] / args.steps * 1e3, "device_ms_per_step": r2["dev_ms"],
                     "value": float(np.prod((1, 1) + r2["sp"])) * args.steps / r2["dt"], "unit": "voxels/s",
                     "algorithmic_gflop_per_step": r2["gflop"], "achieved": ach2, "peak": peak,
