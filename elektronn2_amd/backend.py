@@ -191,8 +191,7 @@ def _load():
         "e2_adam_pack_step": (C.c_int, [vp, fp, fp, fp, fp, vp, i, i, vp, i, fp, fp, C.c_float, i, sz]),
         "e2_adam_step_ex": (C.c_int, [vp, fp, fp, fp, fp, sz, vp, fp, i, fp, fp, C.c_float, i]),
         "e2_sgd_step_ex": (C.c_int, [vp, fp, fp, fp, sz, vp, fp, i, fp, fp, C.c_float, i]),
-        "e2_ring_fetch": (C.c_int, [vp, fp, i, C.c_size_t, vp, fp]),
-        "e2_hist_push": (C.c_int, [vp, fp, i, fp, i, vp]),
+        "e2_step_prologue": (C.c_int, [vp, fp, i, C.c_size_t, fp, fp, i, fp, i, vp]),
         "e2_graph_begin": (C.c_int, [vp]),
         "e2_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
         "e2_graph_launch": (C.c_int, [vp, vp]),
@@ -957,20 +956,21 @@ class Context:
                                  seg_reg.numel(), _fp(hyper), _fp(gdiv), float(gmul),
                                  int(bool(zero_g))), "e2_sgd_step_ex")
 
-    # ---- rings of a multi-step graph (e2hip.h: e2_ring_fetch / e2_hist_push) --------------
-    def ring_fetch(self, ring, ticket, dst):
-        """dst = ring[launch number % ring.shape[0]]; ring: (n_slots, slot_floats) f32, ticket: a
-        zeroed int64 tensor of one element"""
-        assert ring.dim() == 2 and ring.is_contiguous() and ring.dtype == torch.float32
-        assert dst.is_contiguous() and dst.numel() >= ring.shape[1] and ticket.dtype == torch.int64
-        _chk(_lib.e2_ring_fetch(self.h, _fp(ring), int(ring.shape[0]), int(ring.shape[1]),
-                                C.c_void_p(ticket.data_ptr()), _fp(dst)), "e2_ring_fetch")
-
-    def hist_push(self, src, hist, ticket):
-        """hist[launch number % hist.shape[0]] = src[:hist.shape[1]]"""
-        assert hist.dim() == 2 and hist.is_contiguous() and src.numel() >= hist.shape[1]
-        _chk(_lib.e2_hist_push(self.h, _fp(src), int(hist.shape[1]), _fp(hist), int(hist.shape[0]),
-                               C.c_void_p(ticket.data_ptr())), "e2_hist_push")
+    # ---- first launch of a step that may stand k times in one graph (e2hip.h: e2_step_prologue) ----
+    def step_prologue(self, state, ring=None, dst=None, src=None, hist=None):
+        """with L = launches on ``state`` (zeroed int64[2]) so far: dst = ring[L % n_slots] (ring:
+        (n_slots, slot_floats) f32) and hist[(L - 1) % hist_slots] = src[:hist.shape[1]]"""
+        assert state.dtype == torch.int64 and state.numel() >= 2 and state.is_contiguous()
+        if ring is not None:
+            assert ring.dim() == 2 and ring.is_contiguous() and ring.dtype == torch.float32
+            assert dst is not None and dst.is_contiguous() and dst.numel() >= ring.shape[1]
+        if hist is not None:
+            assert hist.dim() == 2 and hist.is_contiguous() and src is not None and src.numel() >= hist.shape[1]
+        _chk(_lib.e2_step_prologue(self.h, _fp(ring), int(ring.shape[0]) if ring is not None else 0,
+                                   int(ring.shape[1]) if ring is not None else 0, _fp(dst), _fp(src),
+                                   int(hist.shape[1]) if hist is not None else 0, _fp(hist),
+                                   int(hist.shape[0]) if hist is not None else 0,
+                                   C.c_void_p(state.data_ptr())), "e2_step_prologue")
 
     # ---- graph capture / events --------------------------------------------------------
     def graph_begin(self):

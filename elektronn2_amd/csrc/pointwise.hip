@@ -905,60 +905,69 @@ extern "C" int e2_fill_multi(e2_ctx* ctx, const void* ptrs_dev, const void* coun
 
 // ---- several steps in one graph: the batches come out of a ring in HBM, the losses go into one ----
 // A captured step is the same launches every time; what changes from step to step are the batch
-// and the loss.  Both become position-independent through a TICKET: every launch of these kernels
-// advances a 64-bit counter in HBM (one atomic per work-group, all work-groups of a launch get
-// consecutive values because launches of one stream do not overlap), and launch number L reads
-// slot L % n of the batch ring / writes slot L % n of the history.  So the SAME captured step can
-// stand k times in one graph (DESIGN finding 55).
-__global__ __launch_bounds__(256) void ring_fetch_kernel(const float* __restrict__ ring, int nSlots,
-                                                         long slotFloats, unsigned long long* ticket,
-                                                         float* __restrict__ dst) {
-  __shared__ unsigned long long t;
-  if (threadIdx.x == 0) t = atomicAdd(ticket, 1ull);
+// and the loss.  Both become position-independent through a launch COUNT kept in device memory:
+// launch number L of the prologue reads slot L % n of the batch ring and stores the loss the
+// PREVIOUS step left behind in slot (L - 1) % n of the history.  The count is read with plain
+// loads (it was written by the previous launch) and advanced by the work-group that arrives last
+// at the end of the launch -- no load of the copy waits for an atomic.  So the SAME captured step
+// can stand k times in one graph (DESIGN finding 55).
+struct PrologueP {
+  const float* ring; int nSlots; long slotFloats; float* dst;
+  const float* src; int nVals; float* hist; int histSlots;
+  unsigned long long* state;           // [0] launches so far, [1] arrivals of the running launch
+};
+__global__ __launch_bounds__(256) void step_prologue_kernel(PrologueP p) {
+  const unsigned long long L = *(volatile unsigned long long*)p.state;
+  if (p.hist && L > 0 && blockIdx.x == 0) {
+    float* d = p.hist + (long)((L - 1) % (unsigned long long)p.histSlots) * p.nVals;
+    for (int i = threadIdx.x; i < p.nVals; i += 256) d[i] = p.src[i];
+  }
+  if (p.ring) {
+    const float* src = p.ring + (long)(L % (unsigned long long)p.nSlots) * p.slotFloats;
+    const long n4 = p.slotFloats >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(p.dst);
+    const long stride = gridDim.x * 256L;
+    long i = blockIdx.x * 256L + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {       // four 16-byte loads in flight per lane
+      const float4 a = s4[i], b = s4[i + stride], c = s4[i + 2 * stride], d = s4[i + 3 * stride];
+      d4[i] = a; d4[i + stride] = b; d4[i + 2 * stride] = c; d4[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) d4[i] = s4[i];
+    if (blockIdx.x == 0 && threadIdx.x < (p.slotFloats & 3)) p.dst[4 * n4 + threadIdx.x] = src[4 * n4 + threadIdx.x];
+  }
   __syncthreads();
-  const int slot = (int)((t / gridDim.x) % (unsigned long long)nSlots);
-  const float* src = ring + (long)slot * slotFloats;
-  const long n4 = slotFloats >> 2;
-  const float4* s4 = reinterpret_cast<const float4*>(src);
-  float4* d4 = reinterpret_cast<float4*>(dst);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += gridDim.x * 256L) d4[i] = s4[i];
-  if (blockIdx.x == 0 && threadIdx.x < (slotFloats & 3)) dst[4 * n4 + threadIdx.x] = src[4 * n4 + threadIdx.x];
+  if (threadIdx.x == 0) {
+    if (atomicAdd(p.state + 1, 1ull) == (unsigned long long)gridDim.x - 1) {
+      p.state[1] = 0;                  // (every work-group of this launch has read state[0] by now)
+      p.state[0] = L + 1;
+    }
+  }
 }
 
-/* dst[0 .. slot_floats) = ring[(launch number % n_slots)][...]; *ticket (a zeroed 64-bit word in
- * device memory, owned by the caller, used with ONE (n_slots, slot_floats) only) counts the
- * launches.  ring, dst: 16-byte aligned; slot_floats * 4 bytes per slot. */
-extern "C" int e2_ring_fetch(e2_ctx* ctx, const float* ring, int n_slots, size_t slot_floats,
-                             void* ticket, float* dst) {
-  E2_REQUIRE(ctx && ring && ticket && dst && n_slots > 0 && slot_floats > 0, "e2_ring_fetch: bad argument");
-  E2_REQUIRE((((uintptr_t)ring | (uintptr_t)dst) & 15) == 0 && ((slot_floats * 4) & 15) == 0 &&
-                 ((uintptr_t)ticket & 7) == 0,
-             "e2_ring_fetch: ring / dst must be 16-byte aligned, slots a multiple of 16 bytes, the ticket 8-byte aligned");
-  const int grid = (int)std::min<size_t>(((slot_floats >> 2) + 255) / 256, 1024);   // (a function of slot_floats ONLY)
-  hipLaunchKernelGGL(ring_fetch_kernel, dim3(grid), dim3(256), 0, ctx->stream, ring, n_slots,
-                     (long)slot_floats, (unsigned long long*)ticket, dst);
-  E2_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-__global__ __launch_bounds__(64) void hist_push_kernel(const float* __restrict__ src, int nVals,
-                                                       float* __restrict__ hist, int nSlots,
-                                                       unsigned long long* ticket) {
-  __shared__ unsigned long long t;
-  if (threadIdx.x == 0) t = atomicAdd(ticket, 1ull);
-  __syncthreads();
-  float* d = hist + (long)(t % (unsigned long long)nSlots) * nVals;
-  for (int i = threadIdx.x; i < nVals; i += 64) d[i] = src[i];
-}
-
-/* hist[(launch number % n_slots)][0 .. n_vals) = src[0 .. n_vals): the loss (and whatever else a
- * step leaves in a small device buffer) of every step of a multi-step graph */
-extern "C" int e2_hist_push(e2_ctx* ctx, const float* src, int n_vals, float* hist, int n_slots,
-                            void* ticket) {
-  E2_REQUIRE(ctx && src && hist && ticket && n_vals > 0 && n_slots > 0 && ((uintptr_t)ticket & 7) == 0,
-             "e2_hist_push: bad argument");
-  hipLaunchKernelGGL(hist_push_kernel, dim3(1), dim3(64), 0, ctx->stream, src, n_vals, hist, n_slots,
-                     (unsigned long long*)ticket);
+/* The first launch of a captured step that may stand several times in one graph:
+ *   dst[0 .. slot_floats) = ring[L % n_slots]              (ring != NULL)
+ *   hist[(L - 1) % hist_slots][0 .. n_vals) = src[..]       (hist != NULL and L > 0: what the step
+ *                                                            BEFORE this one left in src, its loss)
+ * with L = the number of prologue launches on `state` so far; state: two zeroed 64-bit words in
+ * device memory owned by the caller ([0] = L, readable by the host after a synchronisation).
+ * ring, dst 16-byte aligned, slot_floats a multiple of 4.  Launches on one `state` must be
+ * ordered (one stream). */
+extern "C" int e2_step_prologue(e2_ctx* ctx, const float* ring, int n_slots, size_t slot_floats,
+                                float* dst, const float* src, int n_vals, float* hist,
+                                int hist_slots, void* state) {
+  E2_REQUIRE(ctx && state && ((uintptr_t)state & 7) == 0, "e2_step_prologue: null / misaligned state");
+  E2_REQUIRE(!ring || (dst && n_slots > 0 && slot_floats > 0 &&
+                       (((uintptr_t)ring | (uintptr_t)dst) & 15) == 0 && ((slot_floats * 4) & 15) == 0),
+             "e2_step_prologue: ring / dst must be 16-byte aligned and slots a multiple of 16 bytes");
+  E2_REQUIRE(!hist || (src && n_vals > 0 && hist_slots > 0), "e2_step_prologue: bad history arguments");
+  PrologueP p;
+  p.ring = ring; p.nSlots = n_slots; p.slotFloats = (long)slot_floats; p.dst = dst;
+  p.src = src; p.nVals = n_vals; p.hist = hist; p.histSlots = hist_slots;
+  p.state = (unsigned long long*)state;
+  const int grid = ring ? (int)std::min<size_t>(std::max<size_t>((slot_floats / 4 + 1023) / 1024, 1),
+                                                (size_t)ctx->num_cu) : 1;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(grid), dim3(256), 0, ctx->stream, p);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }

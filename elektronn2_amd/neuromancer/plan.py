@@ -460,8 +460,9 @@ class Plan(object):
         self._n_runs = 0                     # run() calls so far (fetch_async pairs slots with runs)
         self._async = None                   # state of fetch_async: pinned loss slots, events
         # several steps in one graph (run_steps): batches out of a device-side ring, losses into one
-        self._ring = None                    # dict(ring=(n_slots, arena floats), ticket=int64[1])
-        self._hist = None                    # dict(buf=(n_slots, 1), ticket=int64[1])
+        self._ring = None                    # (n_slots, arena floats): the batches
+        self._hist = None                    # (n_slots, 1): the losses
+        self._step_state = None              # int64[2] on the device: steps started, arrivals (e2_step_prologue)
         self._multi = {}                     # k -> graph of k steps
         self._built = True
 
@@ -902,16 +903,15 @@ class Plan(object):
                 self.model._img_owner = self if self._upd is not None else None
 
     def _emit_seg(self, i, emit, zero_jobs):
-        """the launches of segment i: (batch out of the ring) + (batched zero fills) + the segment
-        + (loss into the history)"""
+        """the launches of segment i: (the step's prologue) + (batched zero fills) + the segment"""
         ctx = self.ctx
-        if i == 0 and self._ring is not None:
-            ctx.ring_fetch(self._ring['ring'], self._ring['ticket'], self.input_arena)
+        if i == 0 and (self._ring is not None or self._hist is not None):
+            # ONE launch: this step's batch out of the ring, the previous step's loss into the history
+            ctx.step_prologue(self._step_state, ring=self._ring, dst=self.input_arena,
+                              src=self._loss_dev() if self._hist is not None else None, hist=self._hist)
         if zero_jobs and i in zero_jobs:
             ctx.fill_multi(*zero_jobs[i])
         emit()
-        if self._hist is not None and i == len(self._segs) - 1:
-            ctx.hist_push(self._loss_dev(), self._hist['buf'], self._hist['ticket'])
 
     def _loss_dev(self):
         nll = self.loss_node.parent[0] if isinstance(self.loss_node.parent, (list, tuple)) \
@@ -930,7 +930,7 @@ class Plan(object):
         """The step takes its batch out of ``ring[(steps so far) % n_slots]`` -- a float32 device
         tensor (n_slots, input_arena.numel()), every slot in the layout of ``input_arena``
         (``input_slices``: image | target, 16-byte aligned slices) -- by a launch of its own graph
-        (e2_ring_fetch) instead of waiting for ``set_inputs``.  ``None`` detaches the ring.  The
+        (e2_step_prologue) instead of waiting for ``set_inputs``.  ``None`` detaches the ring.  The
         producer (data/batch.py's sampler on its stream, or host copies) fills slots AHEAD of the
         steps that read them and orders itself against the plan's stream; the reference's
         counterpart is the BackgroundProc queue of training/trainer.py:174-186."""
@@ -942,41 +942,49 @@ class Plan(object):
                     and ring.shape[1] == self.input_arena.numel() and ring.data_ptr() % 16 == 0):
                 raise ValueError("set_input_ring: a contiguous float32 device tensor (n_slots, %d) is needed"
                                  % self.input_arena.numel())
-            self._ring = dict(ring=ring, ticket=torch.zeros(1, dtype=torch.int64, device=self.ctx.device))
+            self._ring = ring
         else:
             self._ring = None
+        self._state_alloc()
         self._drop_graphs()
 
+    def _state_alloc(self):
+        # (the count goes on across attachments: step L reads slot L % n_slots; ring_position() tells L)
+        if self._step_state is None:
+            self._step_state = torch.zeros(2, dtype=torch.int64, device=self.ctx.device)
+
     def ring_position(self):
-        """steps that have taken a batch out of the ring so far (reads the device counter: waits)"""
-        if self._ring is None:
+        """steps that have run their prologue (e2_step_prologue: the next step reads ring slot
+        ring_position() % n_slots) since a ring or the history was first attached; reads the
+        device count: waits"""
+        if self._step_state is None:
             return 0
         self.stream.synchronize()
-        grid = min(((self.input_arena.numel() >> 2) + 255) // 256, 1024)
-        return int(self._ring['ticket'].item()) // grid
+        return int(self._step_state[0].item())
 
     def keep_loss_history(self, n_slots=256):
-        """every step also stores its loss in a device-side ring of ``n_slots`` entries
-        (e2_hist_push); ``loss_history(n)`` reads the last n"""
+        """every step's loss is kept in a device-side ring of ``n_slots`` entries (written by the
+        NEXT step's prologue; the newest loss is the plan's loss scalar); ``loss_history(n)``
+        reads the last n."""
         if not self.training:
             raise RuntimeError("keep_loss_history: a training plan is needed")
-        if self._hist is None or self._hist['buf'].shape[0] != int(n_slots):
-            dev = self.ctx.device
-            self._hist = dict(buf=torch.zeros(int(n_slots), 1, device=dev),
-                              ticket=torch.zeros(1, dtype=torch.int64, device=dev))
+        if self._hist is None or self._hist.shape[0] != int(n_slots):
+            self._hist = torch.zeros(int(n_slots), 1, device=self.ctx.device)
+            self._state_alloc()
+            self._hist_from = self.ring_position()   # steps before this one are not in the history
             self._drop_graphs()
 
     def loss_history(self, n):
         """the losses of the last n steps, oldest first (waits for the plan's stream)"""
         if self._hist is None:
             raise RuntimeError("loss_history: call keep_loss_history() before the steps")
-        self.stream.synchronize()
-        t = int(self._hist['ticket'].item())
-        ns = self._hist['buf'].shape[0]
-        if n > min(t, ns):
-            raise ValueError("loss_history: %d steps asked for, %d kept" % (n, min(t, ns)))
-        h = self._hist['buf'][:, 0].cpu().numpy()
-        return np.array([h[(t - n + j) % ns] for j in range(n)], np.float32)
+        t = self.ring_position()
+        ns = self._hist.shape[0]
+        if n < 1 or n > min(t - self._hist_from, ns + 1):
+            raise ValueError("loss_history: %d steps asked for, %d kept" % (n, min(t - self._hist_from, ns + 1)))
+        h = self._hist[:, 0].cpu().numpy()
+        out = [h[(t - n + j) % ns] for j in range(n - 1)] + [float(self._loss_dev().item())]
+        return np.array(out, np.float32)
 
     def run_steps(self, k):
         """``k`` training steps on the device with ONE graph launch where the step is a single

@@ -355,17 +355,17 @@ int e2_set_skip_zero_fill(e2_ctx*, int on);
  * one batch to model.trainingstep per iteration and reads the loss back before the next).  Between
  * two graph launches the device idles for ~19 us however short the host's part is (DESIGN finding
  * 54); a graph of k steps has that gap once per k steps.  What differs between the k copies of the
- * step -- the batch and the loss -- goes through rings in device memory indexed by a launch counter:
- *   e2_ring_fetch : dst = ring[(number of launches so far) % n_slots]  (slot_floats floats per slot;
- *                   the producer -- data/batch.py's sampler, or a copy from the host -- fills the
- *                   slots ahead of the launch that consumes them);
- *   e2_hist_push  : hist[(number of launches so far) % n_slots][0..n_vals) = src[0..n_vals).
- * ticket: a zeroed, 8-byte aligned 64-bit word in device memory per ring, advanced by the kernels
- * (gridDim atomics per e2_ring_fetch launch, one per e2_hist_push launch); ring / dst 16-byte
- * aligned, slot_floats a multiple of 4.  Launches of one ring must be ordered (one stream). */
-int e2_ring_fetch(e2_ctx*, const float* ring, int n_slots, size_t slot_floats, void* ticket,
-                  float* dst);
-int e2_hist_push(e2_ctx*, const float* src, int n_vals, float* hist, int n_slots, void* ticket);
+ * step -- the batch and the loss -- goes through rings in device memory indexed by a launch count.
+ * e2_step_prologue is the first launch of such a step; with L = its launches on `state` so far:
+ *   dst[0 .. slot_floats) = ring[L % n_slots]            (ring != NULL; the producer -- data/batch.py's
+ *                            sampler, or copies from the host -- fills slots ahead of their step)
+ *   hist[(L - 1) % hist_slots][0 .. n_vals) = src[..]     (hist != NULL, L > 0: what the step BEFORE
+ *                            this one left in src -- its loss; the newest loss is still in src)
+ * state: two zeroed 64-bit words in device memory owned by the caller ([0] = L; advanced by the
+ * work-group that finishes last).  ring / dst 16-byte aligned, slot_floats a multiple of 4;
+ * launches on one state must be ordered (one stream). */
+int e2_step_prologue(e2_ctx*, const float* ring, int n_slots, size_t slot_floats, float* dst,
+                     const float* src, int n_vals, float* hist, int hist_slots, void* state);
 /* the conv launches that follow may read up to `bytes` (finite, readable) bytes behind the last
  * element of their input x (0 withdraws the promise): required (>= 128) by the weight-gradient
  * tiling "MT,NT,9,0,S", csrc/conv_pw_wgrad.hip */

@@ -515,7 +515,8 @@ def test_several_steps_in_one_graph_launch():
             ring[j, o:o + n] = torch.tensor(src.ravel(), device=ring.device)
     # the ring's next slot is the one of step 1: start the count there
     plan.set_input_ring(ring)
-    plan._ring['ticket'] += min(((plan.input_arena.numel() >> 2) + 255) // 256, 1024)
+    plan._step_state[0] += 1
+    assert plan.ring_position() == 1
     l5, t5 = b.trainingsteps(5, optimiser='Adam', ring=ring)
     assert len(l5) == 5 and plan._multi, "no multi-step graph was captured"
     k_cap = sorted(plan._multi)

@@ -1458,38 +1458,39 @@ def test_conv3d_random_shapes_with_the_librarys_own_tilings(ctx, case):
     assert relerr(dw, O.conv3d_wgrad(dy, x, w.shape)) < TOL
 
 
-def test_ring_fetch_and_history_follow_the_launch_count(ctx):
-    """e2_ring_fetch / e2_hist_push (several steps in one graph, DESIGN finding 55): launch number
-    L of a ring copies slot L % n_slots -- bit-exact, for slot sizes with and without a float4
-    tail, one work-group and the grid's cap -- and launch L of a history writes its slot L % n;
-    the same launches replayed from a captured graph keep counting."""
+def test_step_prologue_follows_the_launch_count(ctx):
+    """e2_step_prologue (several steps in one graph, DESIGN finding 55): launch number L copies
+    ring slot L % n_slots -- bit-exact, for slot sizes with and without a float4 tail, one
+    work-group and the grid's cap -- and stores what the step before it left in `src` in history
+    slot (L - 1) % n; the same launches replayed from a captured graph keep counting."""
     dev = ctx.device
     rng = np.random.RandomState(3)
     for n_slots, floats in ((3, 8), (4, 1000), (2, 4 * 256 * 1024 + 4 * 77)):
         ring = torch.tensor(rng.rand(n_slots, floats).astype(np.float32), device=dev)
         dst = torch.zeros(floats + 8, device=dev)
-        ticket = torch.zeros(1, dtype=torch.int64, device=dev)
+        state = torch.zeros(2, dtype=torch.int64, device=dev)
         for L in range(2 * n_slots + 1):
-            ctx.ring_fetch(ring, ticket, dst)
+            ctx.step_prologue(state, ring=ring, dst=dst)
             assert torch.equal(dst[:floats], ring[L % n_slots]), (n_slots, floats, L)
             assert float(dst[floats:].abs().max()) == 0.0
-    # history: 5 values per step, 4 slots
+        assert state.cpu().tolist() == [2 * n_slots + 1, 0]
+    # history alone: 5 values per step, 4 slots; launch L stores what "step L - 1" left in src
     hist = torch.zeros(4, 5, device=dev)
-    ht = torch.zeros(1, dtype=torch.int64, device=dev)
-    src = torch.zeros(8, device=dev)
-    for L in range(6):
-        src[:5] = torch.arange(5, device=dev) + 10.0 * L
-        ctx.hist_push(src, hist, ht)
+    state = torch.zeros(2, dtype=torch.int64, device=dev)
+    src = torch.full((8,), -1.0, device=dev)
+    for L in range(7):
+        ctx.step_prologue(state, src=src, hist=hist)
+        src[:5] = torch.arange(5, device=dev) + 10.0 * L          # "the loss of step L"
     torch.cuda.synchronize()
-    assert int(ht.item()) == 6
+    assert state.cpu().tolist() == [7, 0]
     want = np.array([[40, 41, 42, 43, 44], [50, 51, 52, 53, 54], [20, 21, 22, 23, 24], [30, 31, 32, 33, 34]], np.float32)
     assert np.array_equal(hist.cpu().numpy(), want)
-    # inside a captured graph: three fetches + three pushes per launch, two launches
+    # both, inside a captured graph: three "steps" per launch, two launches
     ring = torch.tensor(rng.rand(4, 64).astype(np.float32), device=dev)
     dst = torch.zeros(64, device=dev)
-    ticket = torch.zeros(1, dtype=torch.int64, device=dev)
-    hist = torch.zeros(8, 64, device=dev)
-    ht = torch.zeros(1, dtype=torch.int64, device=dev)
+    loss = torch.zeros(4, device=dev)
+    hist = torch.zeros(8, 1, device=dev)
+    state = torch.zeros(2, dtype=torch.int64, device=dev)
     s = torch.cuda.Stream(device=dev)
     old = ctx.stream
     torch.cuda.synchronize()
@@ -1498,8 +1499,8 @@ def test_ring_fetch_and_history_follow_the_launch_count(ctx):
         with torch.cuda.stream(s):
             ctx.graph_begin()
             for _ in range(3):
-                ctx.ring_fetch(ring, ticket, dst)
-                ctx.hist_push(dst, hist, ht)
+                ctx.step_prologue(state, ring=ring, dst=dst, src=loss, hist=hist)
+                ctx.copy5(dst[:1].view(1, 1, 1, 1, 1), loss[:1].view(1, 1, 1, 1, 1))   # "the step": loss = batch[0]
             g = ctx.graph_end()
             ctx.graph_launch(g)
             ctx.graph_launch(g)
@@ -1507,9 +1508,9 @@ def test_ring_fetch_and_history_follow_the_launch_count(ctx):
         ctx.graph_destroy(g)
     finally:
         ctx.set_stream(old)
-    got = hist.cpu().numpy()
-    for L in range(6):
-        assert np.array_equal(got[L], ring[L % 4].cpu().numpy()), L
-    assert float(hist[6:].abs().max()) == 0.0
+    got = hist.cpu().numpy()[:, 0]
+    for L in range(5):
+        assert got[L] == float(ring[L % 4, 0]), L
+    assert float(loss[0]) == float(ring[5 % 4, 0]) and float(hist[5:].abs().max()) == 0.0
     with pytest.raises(RuntimeError):
-        ctx.ring_fetch(torch.zeros(2, 6, device=dev), ticket, torch.zeros(8, device=dev))   # 24-byte slots
+        ctx.step_prologue(state, ring=torch.zeros(2, 6, device=dev), dst=torch.zeros(8, device=dev))   # 24-byte slots
