@@ -485,7 +485,7 @@ class Model(GraphManager):
         plan = opt.step.func
         if plan is None or not plan._built:
             raise RuntimeError("trainingsteps: call trainingstep once first (it builds the plan)")
-        if ring is not None and (plan._ring is None or plan._ring['ring'] is not ring):
+        if ring is not None and plan._ring is not ring:
             plan.set_input_ring(ring)
         losses, t = opt.steps(k)
         self.elapsed_time += t
