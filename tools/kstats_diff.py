@@ -5,7 +5,8 @@ the profile of record.
                                 [--steps 25] [--pct 3] [--us 2]
 
 Both files come from `bench.py --workload W --steps 20 --warmup 5` under `rocprofv3
---kernel-trace --stats` (tools/gpu_round.sh), i.e. 25 steps: a kernel's figure is its TOTAL
+--kernel-trace --stats` (tools/gpu_round.sh); the number of steps in a file is the call count of
+the optimiser launch (25 until round 5, more since the set-up of the multi-step graphs): a kernel's figure is its TOTAL
 duration per step (all its launches; a kernel that is launched more or less often than before
 is compared as a whole).  Exit status 1 if any kernel that exists in both grew by more than
 --pct percent AND more than --us microseconds per step, or if the step's kernel sum grew by
@@ -31,7 +32,17 @@ def short(name):
     return name.split("(")[0]
 
 
+def steps_of(path, default):
+    """the optimiser launch runs once per step: its call count is the number of steps in the file
+    (20 + 5 until round 5; since bench.py runs several steps per graph launch the set-up adds more)"""
+    for r in csv.DictReader(open(path)):
+        if short(r["Name"]) in ("adam_kernel", "sgd_kernel"):
+            return int(r["Calls"])
+    return default
+
+
 def load(path, steps):
+    steps = steps_of(path, steps)
     out = {}
     for r in csv.DictReader(open(path)):
         k = short(r["Name"])
