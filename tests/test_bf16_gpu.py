@@ -733,6 +733,29 @@ def test_no_operand_goes_stale_across_optimiser_steps(process_bf16, net, sp, use
     assert np.abs(p1 - p0).max() <= 2e-3 * np.abs(p0).max()
 
 
+def test_several_steps_per_launch_in_bf16_mode(process_bf16):
+    """Plan.run_steps in bf16 mode: the captured step has a side branch (weight gradients) that is
+    joined at the end of EVERY step, so k copies of it in one graph are k steps: six steps as 2 +
+    a four-step graph against six single steps (same bounds as the trajectory test above: 2e-3)."""
+    res = []
+    for multi in (False, True):
+        m, spec, params, x, t = _bf16_net("neuro3d_lite", (9, 71, 71), True)
+        with _pinned():
+            if multi:
+                losses = [float(m.trainingstep(x, t, optimiser='Adam')[0])]
+                l5, _ = m.trainingsteps(5, optimiser='Adam')
+                plan = m.optimisers['Adam'].step.func
+                assert 4 in plan._multi and plan.use_side, (sorted(plan._multi), plan.use_side)
+                losses += [float(v) for v in l5]
+            else:
+                losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(6)]
+        res.append((losses, m.optimisers['Adam'].step.func.model.P.detach().cpu().numpy().copy()))
+    (l0, p0), (l1, p1) = res
+    assert np.isfinite(l1).all() and min(l1[1:]) < l1[0]
+    np.testing.assert_allclose(l1, l0, rtol=2e-3)
+    assert np.abs(p1 - p0).max() <= 2e-3 * np.abs(p0).max()
+
+
 @pytest.mark.parametrize("k,pool,cout,sp", [((1, 4, 4), (1, 2, 2), 20, (3, 35, 73)), ((1, 6, 6), (1, 2, 2), 20, (2, 37, 41)),
                                             ((1, 3, 3), (1, 1, 1), 32, (2, 20, 70)), ((1, 4, 4), (1, 2, 2), 7, (1, 19, 23))])
 def test_first_layer_writes_the_next_layers_input_image(ctx, k, pool, cout, sp):
