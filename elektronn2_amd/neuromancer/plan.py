@@ -921,6 +921,8 @@ class Plan(object):
     def _drop_graphs(self):
         """the captured graphs no longer describe the step (a ring was attached ...): capture again
         at the next run (no eager run in between: tilings and buffers are unchanged)"""
+        if self._graphs or self._multi:
+            self.stream.synchronize()        # (a launch of them may still be running)
         for g in list(self._graphs or []) + list(self._multi.values()):
             self.ctx.graph_destroy(g)
         self._graphs, self._multi = None, {}
