@@ -153,3 +153,42 @@ class PatchSampler(object):
                 return images, aff
             return images, aff, torch.from_numpy(seg[:, None].astype(np.float32)).to(dev)
         return images, target
+
+
+class RingFeeder(object):
+    """Keeps the input ring of a training plan (Plan.set_input_ring) filled ``k`` batches at a time,
+    one launch ahead of ``Model.trainingsteps(k, ring=feeder.ring, sync=False)``:
+
+        feeder = RingFeeder(sampler, model, 'Adam', k, grey_augment_channels=[0], warp=0.5)
+        feeder.fill()                                   # the first k slots
+        for b in range(n_launches):
+            losses, t = model.trainingsteps(k, optimiser='Adam', ring=feeder.ring, sync=False)
+            feeder.fill()                               # the other half, while the launch runs
+
+    The ring has 2 k slots; ``fill`` writes the k slots the NEXT launch will read.  They were last
+    read by the launch before the one just submitted, whose losses ``trainingsteps(sync=False)``
+    has just waited for -- so the slots are free without any further synchronisation.  The
+    reference's counterpart is the BackgroundProc queue in front of trainingstep
+    (training/trainer.py:174-186)."""
+
+    def __init__(self, sampler, model, optimiser, k, **getbatch_kwargs):
+        opt = model.optimisers[optimiser]
+        plan = opt.step.func
+        if plan is None or not plan._built:
+            raise RuntimeError("RingFeeder: call trainingstep once first (it builds the plan)")
+        self.sampler, self.plan, self.k, self.kw = sampler, plan, int(k), getbatch_kwargs
+        self.ring = torch.zeros(2 * self.k, plan.input_arena.numel(), device=plan.ctx.device)
+        plan.set_input_ring(self.ring)
+        self.next = plan.ring_position()        # the step that reads the next slot to fill
+        self.batch = plan.batch
+
+    def fill(self):
+        n = self.ring.shape[0]
+        for j in range(self.k):
+            batch = self.sampler.getbatch(self.batch, 'train', **self.kw)
+            row = self.ring[(self.next + j) % n]
+            for node, src in zip(self.plan.inputs, batch):
+                o, cnt = self.plan.input_slices[node]
+                row[o:o + cnt].copy_(src.reshape(-1), non_blocking=True)
+        self.next += self.k
+

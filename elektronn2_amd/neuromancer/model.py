@@ -469,9 +469,11 @@ class Model(GraphManager):
             return loss, t, ret[1:]
         return loss, t, None
 
-    def trainingsteps(self, k, optimiser='SGD', ring=None):
+    def trainingsteps(self, k, optimiser='SGD', ring=None, sync=True):
         """``k`` optimiser iterations with ONE graph launch -> ``(losses[k], t)``, t = device
-        seconds of the launch.  ``ring``: a float32 device tensor (n_slots, plan.input_arena.numel())
+        seconds of the launch (``sync=False``: the launch is submitted and the losses / time of
+        the launch BEFORE it are returned -- ``(None, None)`` the first time -- so that the host
+        fills the ring's next slots while the device works: data/batch.py RingFeeder).  ``ring``: a float32 device tensor (n_slots, plan.input_arena.numel())
         of batches in the layout of the training plan's input arena (``plan.input_slices``); step i
         takes slot (steps so far) % n_slots.  Without a ring every step re-reads the inputs of
         the last ``trainingstep``.  The first ``trainingstep`` must have run (it builds the plan).
@@ -487,12 +489,13 @@ class Model(GraphManager):
             raise RuntimeError("trainingsteps: call trainingstep once first (it builds the plan)")
         if ring is not None and plan._ring is not ring:
             plan.set_input_ring(ring)
-        losses, t = opt.steps(k)
-        self.elapsed_time += t
-        for l in losses:
-            self._last_exec_times.append(t / k + 1e-10)
-            self._last_losses.append(l)
+        losses, t = opt.steps(k, sync=sync)
         self.iterations += int(k)
+        if losses is not None:
+            self.elapsed_time += t
+            for l in losses:
+                self._last_exec_times.append(t / len(losses) + 1e-10)
+                self._last_losses.append(l)
         return losses, t
 
     def test_run_prediction(self):

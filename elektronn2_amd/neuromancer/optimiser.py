@@ -101,25 +101,59 @@ class Optimiser(object):
         self.step.last_exec_time = plan.last_device_time
         return ret
 
-    def steps(self, k):
+    def steps(self, k, sync=True):
         """``k`` steps with one graph launch (Plan.run_steps) on the batches of the plan's input
         ring -- or k times on the inputs last set; -> (losses of the k steps, device seconds of
-        all of them).  No reference counterpart (training/trainer.py:186-194 runs one step per
-        batch and reads its loss back before the next)."""
+        the launch).  ``sync=False``: the launch is only SUBMITTED and the call returns the losses
+        and time of the launch BEFORE it (None, None the first time): the host fills the next
+        slots of the ring while the device works.  No reference counterpart (training/trainer.py:
+        186-194 runs one step per batch and reads its loss back before the next)."""
         plan = self.step.func
         if plan is None or not plan._built:
             raise RuntimeError("steps: run one ordinary step first (it builds the plan)")
         import torch
+        # batches written into the ring on the caller's stream: the launch is ordered behind them
+        plan.stream.wait_stream(torch.cuda.current_stream(plan.ctx.device))
         with torch.cuda.stream(plan.stream):
             self._ensure_state(plan)
             self._sync_hyper(plan)
         plan.keep_loss_history()
         n0 = plan._n_runs
-        t = 0.0
         plan.run_steps(k)
-        losses = plan.loss_history(k)               # (waits for the steps)
-        if plan._n_runs - n0 == k:
-            t = plan.ctx.elapsed_ms(plan._ev0, plan._ev1) * 1e-3    # (the last launch: all k when it was one)
+        one = plan._n_runs - n0 == k
+        if sync:
+            losses = plan.loss_history(k)               # (waits for the steps)
+            t = plan.ctx.elapsed_ms(plan._ev0, plan._ev1) * 1e-3 if one else 0.0   # (the last launch: all k when it was one)
+            self.last_exec_time = t
+            self.step.last_exec_time = t
+            self._steps_async = None
+            return losses, t
+        # deferred: a snapshot of (history, count, newest loss) goes into pinned memory behind the launch
+        a = getattr(self, '_steps_async', None)
+        if a is None:
+            ns = plan._hist.shape[0]
+            a = self._steps_async = dict(n=0, slots=[dict(
+                hist=torch.empty(ns, dtype=torch.float32).pin_memory(),
+                state=torch.empty(2, dtype=torch.int64).pin_memory(),
+                loss=torch.empty(1, dtype=torch.float32).pin_memory(),
+                ev=torch.cuda.Event(), k=0, evs=None) for _ in range(2)])
+        cur, prev = a['slots'][a['n'] & 1], a['slots'][(a['n'] & 1) ^ 1]
+        with torch.cuda.stream(plan.stream):
+            cur['hist'].copy_(plan._hist[:, 0], non_blocking=True)
+            cur['state'].copy_(plan._step_state, non_blocking=True)
+            cur['loss'].copy_(plan._loss_dev().reshape(1), non_blocking=True)
+            cur['ev'].record(plan.stream)
+        cur['k'], cur['evs'] = k, (plan._ev0, plan._ev1) if one else None
+        a['n'] += 1
+        if prev['k'] == 0:
+            return None, None
+        prev['ev'].synchronize()
+        t_cnt, ns, kk = int(prev['state'][0]), prev['hist'].numel(), prev['k']
+        h = prev['hist'].numpy()
+        import numpy as np
+        losses = np.array([h[(t_cnt - kk + j) % ns] for j in range(kk - 1)] + [float(prev['loss'][0])], np.float32)
+        t = plan.ctx.elapsed_ms(*prev['evs']) * 1e-3 if prev['evs'] else 0.0
+        prev['k'] = 0
         self.last_exec_time = t
         self.step.last_exec_time = t
         return losses, t
