@@ -235,6 +235,57 @@ def test_training_fed_by_the_device_sampler(ctx):
     assert after < 0.9 * before, (before, after)
 
 
+@pytest.mark.gpu
+def test_ring_feeder_and_deferred_multi_step_launches(ctx):
+    """data.RingFeeder + Model.trainingsteps(k, ring, sync=False): the sampler fills the ring's
+    next k slots while a launch of k steps runs; every launch returns the losses of the one before
+    it.  The same sampler seed through single trainingstep calls gives the same losses step by
+    step (to the weight gradients' atomic order) -- i.e. every step read the batch that was meant
+    for it, across the ring's wrap-around and the two halves."""
+    from elektronn2_amd import nets, neuromancer as nm
+    from elektronn2_amd.data import PatchSampler, RingFeeder
+    rng = np.random.RandomState(0)
+    vol = rng.rand(1, 30, 100, 100).astype(np.float32)
+    lab = (vol > 0.5).astype(np.float32)
+    k, launches = 3, 4
+
+    def make():
+        nm.model_manager.reset()
+        np.random.seed(0)
+        model = nets.neuro3d_lite((None, 1, 9, 47, 47))
+        model.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        tn = model.target_node
+        smp = PatchSampler([vol], [lab], model.input_node.shape.spatial_shape, tn.shape.strides,
+                           tn.shape.offsets, seed=5)
+        return model, smp
+    kw = dict(grey_augment_channels=[0], warp=0.5)
+    model, smp = make()
+    ref = []
+    for i in range(1 + k * launches):
+        d, t = smp.getbatch(1, 'train', **kw)
+        ref.append(float(model.trainingstep(d, t, optimiser='Adam')[0]))
+
+    model, smp = make()
+    d, t = smp.getbatch(1, 'train', **kw)
+    got = [float(model.trainingstep(d, t, optimiser='Adam')[0])]
+    feeder = RingFeeder(smp, model, 'Adam', k, **kw)
+    assert feeder.ring.shape[0] == 2 * k
+    feeder.fill()
+    for b in range(launches):
+        losses, tl = model.trainingsteps(k, optimiser='Adam', ring=feeder.ring, sync=False)
+        feeder.fill()
+        assert (losses is None) == (b == 0)
+        if losses is not None:
+            assert len(losses) == k
+            got += [float(v) for v in losses]
+    plan = model.optimisers['Adam'].step.func
+    got += [float(v) for v in plan.loss_history(k)]          # the last launch's (waits for it)
+    assert model.iterations == 1 + k * launches and k in plan._multi
+    assert len(got) == len(ref)
+    for i, (u, v) in enumerate(zip(ref, got)):
+        assert abs(u - v) <= 1e-5 * abs(u), (i, ref, got)
+
+
 def torch_eq(a, b):
     import torch
     return bool(torch.equal(a, b))
