@@ -37,10 +37,6 @@ SPEC = {
                    "side stream on: a weight gradient's launches are ISSUED behind the main stream's next "
                    "launches (same dependencies): in the captured graph the main chain then stays on one "
                    "hardware queue (DESIGN finding 54)"),
-    "side_fork_every": ("E2_SIDE_FORK_EVERY", int, 1,
-                        "side stream on, side_defer: only every n-th weight gradient records a fork on the main "
-                        "stream (the ones in between wait for the next fork): fewer completion signals on the "
-                        "main chain (finding 54)"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),

@@ -324,32 +324,18 @@ class Plan(object):
         ``defer``: see plan option side_defer"""
         if not (self.use_side or (always and self.use_side_pack)):
             return fn()
-        self._side_dirty = True
-        if defer and self.opt['side_defer']:
-            # issue the launches later (at a later on_side / join_side), i.e. BEHIND the next
-            # launches of the main stream: what they wait for is unchanged (or a LATER point of
-            # the main stream), but in the captured graph the main chain's next kernel becomes the
-            # fork node's FIRST child -- the runtime keeps first children on their parent's queue,
-            # so the main chain stays on one queue instead of hopping (a hop costs 6-10 us, DESIGN
-            # finding 54).  Option side_fork_every = n: only every n-th call records a fork (a
-            # node with a child on another queue carries a completion signal that delays the next
-            # kernel of its own queue by 4.5 us); the calls in between wait for the next fork.
-            self._flush_side()             # (what was forked before is issued now, in order)
-            self._side_unforked.append(fn)
-            self._side_calls += 1
-            if self._side_calls % max(1, int(self.opt['side_fork_every'])) == 0:
-                self._fork_pending()
-            return
-        self._fork_pending()
         self._flush_side()                 # (the side stream keeps the order of the on_side calls)
         self.ctx.stream_fork(self.side)    # the dependency is fixed HERE: main's launches so far
+        self._side_dirty = True
+        if defer and self.opt['side_defer']:
+            # issue the launches later (at the next on_side / join_side), i.e. BEHIND the next
+            # launches of the main stream: what they wait for is unchanged, but in the captured
+            # graph the main chain's next kernel becomes the fork node's FIRST child -- the
+            # runtime keeps first children on their parent's queue, so the main chain stays on
+            # one queue instead of hopping (a hop costs 6-10 us, DESIGN finding 54)
+            self._side_pending = fn
+            return
         self._run_side(fn)
-
-    def _fork_pending(self):
-        if self._side_unforked:
-            self.ctx.stream_fork(self.side)
-            self._side_pending += self._side_unforked
-            self._side_unforked = []
 
     def _run_side(self, fn):
         ctx = self.ctx
@@ -362,13 +348,12 @@ class Plan(object):
             ctx.set_stream(main)
 
     def _flush_side(self):
-        fns, self._side_pending = self._side_pending, []
-        for fn in fns:
+        fn, self._side_pending = self._side_pending, None
+        if fn is not None:
             self._run_side(fn)
 
     def join_side(self):
         """main stream waits for the side stream (no-op when nothing ran there)"""
-        self._fork_pending()
         self._flush_side()
         if self._side_dirty:
             self.ctx.stream_join(self.side)
@@ -407,7 +392,7 @@ class Plan(object):
         # data-gradient chain; inside the captured graph they are parallel branches
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
-        self._side_pending, self._side_unforked, self._side_calls = [], [], 0
+        self._side_pending = None
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
         # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
