@@ -210,9 +210,13 @@ def _rccl_worker(port, q):
         m.loss(x, t)
         if mode != "plain":
             m.enable_data_parallel(exchange_at_world_1=True)
-        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(6)]
+        losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(4)]
+        # ... and two more through the several-steps entry point: one graph of two steps for the
+        # plain plan; a data-parallel step (an exchange between its graphs) stays one step per launch
+        l2, _ = m.trainingsteps(2, optimiser='Adam')
+        losses += [float(v) for v in l2]
         plan = m.optimisers['Adam'].step.func
-        out[mode] = dict(P=m.P.cpu().numpy().copy(), losses=losses,
+        out[mode] = dict(P=m.P.cpu().numpy().copy(), losses=losses, multi=sorted(plan._multi),
                          n_graphs=len(plan._graphs or []), backend=torch.distributed.get_backend())
     q.put(out)
     torch.distributed.destroy_process_group()
@@ -239,6 +243,7 @@ def test_exchange_over_rccl_with_a_one_rank_communicator():
     assert res["rccl-overlap"]["backend"] == "nccl"
     assert res["plain"]["n_graphs"] == 1
     assert res["rccl-overlap"]["n_graphs"] == 3 and res["rccl-single"]["n_graphs"] == 2
+    assert res["rccl-overlap"]["multi"] == [] and res["rccl-single"]["multi"] == [], res
     for mode in ("rccl-overlap", "rccl-single"):
         for a, b in zip(res[mode]["losses"], res["plain"]["losses"]):
             assert abs(a - b) <= 2e-5 * abs(b), (mode, res[mode]["losses"], res["plain"]["losses"])
