@@ -333,30 +333,22 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(WbP p) {
   }
 }
 
-// dw[oc][ic][tap] (+)= dwt[oc][tap][ic], through an LDS tile so that both sides are coalesced: a
-// work-group takes one out channel and kOC = 128 input channels (rows of 512 B on the dwt side, one
-// contiguous run of kOC * T floats on the dw side).  (Round 5: 128 instead of 32 channels per
-// work-group -- the pass ran at 0.75 TB/s on the side stream, 365 us per unet3d step.)
-// (kOC: 128, or 32 for tap volumes whose 128-wide tile would not fit 64 KB of LDS)
+// dw[oc][ic][tap] (+)= dwt[oc][tap][ic], through an LDS tile so that both sides are coalesced
 __global__ __launch_bounds__(256) void wgrad_bf16_out_kernel(float* __restrict__ dwt, float* __restrict__ dw,
-                                                             int Cin, int CinP, int T, int accumulate, int rezero,
-                                                             int kOC) {
-  extern __shared__ float tile[];                // [T][kOC + 1]
-  const int oc = blockIdx.y, ic0 = blockIdx.x * kOC;
-  const int nicP = min(kOC, CinP - ic0);         // (CinP is a multiple of 32: whole 128-byte rows)
-  const int nic = min(kOC, Cin - ic0);
-  float* src = dwt + (long)oc * T * CinP + ic0;
-  for (int i = threadIdx.x; i < T * nicP; i += 256) {
-    const int t = i / nicP, c = i - t * nicP;
-    tile[t * (kOC + 1) + c] = src[(long)t * CinP + c];
-    if (rezero) src[(long)t * CinP + c] = 0.f;   // (a caller-owned sum buffer stays zero between calls)
+                                                             int Cin, int CinP, int T, int accumulate, int rezero) {
+  extern __shared__ float tile[];                // [T][33]
+  const int oc = blockIdx.y, ic0 = blockIdx.x * 32;
+  const int nic = min(32, Cin - ic0);
+  for (int i = threadIdx.x; i < T * 32; i += 256) {
+    const int t = i >> 5, c = i & 31;
+    tile[t * 33 + c] = dwt[((long)oc * T + t) * CinP + ic0 + c];
+    if (rezero) dwt[((long)oc * T + t) * CinP + ic0 + c] = 0.f;   // (a caller-owned sum buffer stays zero between calls)
   }
   __syncthreads();
-  if (nic <= 0) return;
   float* o = dw + ((long)oc * Cin + ic0) * T;
   for (int i = threadIdx.x; i < nic * T; i += 256) {
     const int c = i / T, t = i - c * T;
-    const float v = tile[t * (kOC + 1) + c];
+    const float v = tile[t * 33 + c];
     o[i] = accumulate ? o[i] + v : v;
   }
 }
@@ -514,9 +506,8 @@ static int wgrad_bf16(e2_ctx* ctx, const e2_tensor5* x, const void* xcl_ext, int
   E2_L(1, 1) E2_L(1, 2) E2_L(1, 3) E2_L(1, 4) E2_L(2, 1) E2_L(2, 2) E2_L(2, 3) E2_L(2, 4)
 #undef E2_L
   if (rc) return rc;
-  const int kOC = (size_t)T * 129 * 4 <= 64 * 1024 ? 128 : 32;
-  hipLaunchKernelGGL(wgrad_bf16_out_kernel, dim3((unsigned)((g.CinP + kOC - 1) / kOC), (unsigned)Cout), dim3(256),
-                     (size_t)T * (kOC + 1) * 4, ctx->stream, dwt, dw, Cin, g.CinP, T, accumulate, dwt_ext ? 1 : 0, kOC);
+  hipLaunchKernelGGL(wgrad_bf16_out_kernel, dim3((unsigned)(g.CinP / 32), (unsigned)Cout), dim3(256),
+                     (size_t)T * 33 * 4, ctx->stream, dwt, dw, Cin, g.CinP, T, accumulate, dwt_ext ? 1 : 0);
   E2_CHECK_HIP(hipGetLastError());
   return 0;
 }
