@@ -778,12 +778,7 @@ class Conv(NeuralLayer):
                            lambda: wgrad(True), fn_tune=lambda: wgrad(False))
             finally:
                 ctx.set_input_slack(0)
-        if plan.use_side and plan.side_rank(self) < int(plan.opt['side_tail_main']):
-            # one of the LAST weight gradients of the backward pass: the main stream runs it once
-            # its own chain is through, beside what the side stream still has to do (option text)
-            plan._bwd_tail.append(wgrad_launch)
-        else:
-            plan.on_side(wgrad_launch, defer=True)
+        plan.on_side(wgrad_launch, defer=True)
         if plan.needs_grad(self.parent) and not tail:
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

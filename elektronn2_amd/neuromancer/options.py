@@ -37,11 +37,6 @@ SPEC = {
                    "side stream on: a weight gradient's launches are ISSUED behind the main stream's next "
                    "launches (same dependencies): in the captured graph the main chain then stays on one "
                    "hardware queue (DESIGN finding 54)"),
-    "side_tail_main": ("E2_SIDE_TAIL_MAIN", int, 0,
-                       "side stream on: the weight gradients of the FIRST n conv layers (the last n of the "
-                       "backward pass) are issued on the MAIN stream behind the last launch of its own chain -- "
-                       "where the side stream lags (kernels that take a CU's whole register file leave it no "
-                       "room) both queues then work to the end instead of the main one waiting (finding 54)"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),

@@ -337,19 +337,6 @@ class Plan(object):
             return
         self._run_side(fn)
 
-    def side_rank(self, node):
-        """position of a Conv node among the conv layers whose weight gradient is a launch of its
-        own (forward order: 0 = the one the backward pass reaches last)"""
-        if self._side_order is None:
-            from .neural import Conv
-            self._side_order = [n for n in self.nodes if isinstance(n, Conv) and hasattr(n, '_k3')
-                                and n.parent is not None and not n._fused_first(self)
-                                and n._fused_head(self) is None]
-        try:
-            return self._side_order.index(node)
-        except ValueError:
-            return 1 << 30
-
     def _run_side(self, fn):
         ctx = self.ctx
         main = ctx.stream
@@ -406,7 +393,6 @@ class Plan(object):
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
         self._side_pending = None
-        self._side_order, self._bwd_tail = None, []
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
         # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
@@ -661,11 +647,6 @@ class Plan(object):
             self._grad_written = set()
         for n in nodes:
             n._plan_bwd(self)
-        tail, self._bwd_tail = self._bwd_tail, []
-        if tail:
-            self._flush_side()             # (the side stream's last launches first: they are older)
-            for fn in tail:
-                fn()
         self.join_side()
 
     def _dp_cut(self):
