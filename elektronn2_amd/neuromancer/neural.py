@@ -778,11 +778,7 @@ class Conv(NeuralLayer):
                            lambda: wgrad(True), fn_tune=lambda: wgrad(False))
             finally:
                 ctx.set_input_slack(0)
-        # (side stream off -- f32 mode -- : option side_last_n still sends the LAST n weight gradients
-        # of the backward pass there, beside the first conv's data gradient and the issue-bound
-        # backward of the fused first layer)
-        plan.on_side(wgrad_launch, defer=True,
-                     force=plan.side_rank(self) < int(plan.opt['side_last_n']))
+        plan.on_side(wgrad_launch, defer=True)
         if plan.needs_grad(self.parent) and not tail:
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

@@ -37,10 +37,6 @@ SPEC = {
                    "side stream on: a weight gradient's launches are ISSUED behind the main stream's next "
                    "launches (same dependencies): in the captured graph the main chain then stays on one "
                    "hardware queue (DESIGN finding 54)"),
-    "side_last_n": ("E2_SIDE_LAST_N", int, 0,
-                    "side stream OFF (f32 mode): the weight gradients of the first n conv layers (the last n of "
-                    "the backward pass) still run on the side stream, beside the first conv's data gradient and "
-                    "the backward of the fused first layer, which is bound by instruction issue (finding 54)"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),
