@@ -373,3 +373,64 @@ def test_build_check_enforces_the_register_budget(tmp_path):
                             "igemm4_kernel|wgrad_direct_kernel|igemm_kernel|pw_gemm_kernel",
                             os.path.join(csrc, "reg_budget.txt")], capture_output=True, text=True)
         assert (r.returncode != 0) == bool(want), (i, r.stderr)
+
+
+def test_plan_options_are_named_arguments_with_environment_defaults(monkeypatch):
+    """neuromancer/options.py: every host switch of the launch plan is a named
+    option -- set process-wide, inside a context manager, or per plan; the E2_* variable is the
+    DEFAULT only; unknown names are errors; tools/kstats_diff.py takes the number of steps in a
+    profile from the optimiser launch's call count."""
+    from elektronn2_amd.neuromancer import options as opt
+    assert opt.get("graph") is True and opt.get("side_defer") is True and opt.get("adam_pack") is False
+    monkeypatch.setenv("E2_NO_GRAPH", "1")
+    monkeypatch.setenv("E2_BF16_AHEAD_MIN", "0.5")
+    assert opt.get("graph") is False and opt.get("bf16_ahead_min") == 0.5
+    nm.set_plan_options(graph=True)                       # an explicit value beats the environment
+    try:
+        assert opt.get("graph") is True
+        with nm.plan_options(graph=False, fuse_tail=False):
+            snap = opt.snapshot()
+            assert snap["graph"] is False and snap["fuse_tail"] is False
+        assert opt.get("graph") is True and opt.get("fuse_tail") is True
+        assert opt.snapshot({"dp_overlap": False})["dp_overlap"] is False
+        with pytest.raises(KeyError):
+            nm.set_plan_options(no_such_switch=1)
+        with pytest.raises(KeyError):
+            opt.snapshot({"no_such_switch": 1})
+        nm.set_plan_options(side_stream=True)
+        assert opt.get("side_stream") is True
+        nm.set_plan_options(reset=("side_stream",))
+        assert opt.get("side_stream") is None
+    finally:
+        nm.set_plan_options(graph=None)
+    assert opt.get("graph") is False                      # back to the environment's default
+    # every option documents itself and names its variable exactly once
+    envs = [v[0] for v in opt.SPEC.values()]
+    assert len(set(envs)) == len(envs) and all(e.startswith("E2_") for e in envs)
+    assert all(len(v) == 4 and len(v[3]) > 10 for v in opt.SPEC.values())
+
+
+def test_kstats_diff_counts_steps_by_the_optimiser_launch(tmp_path):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import kstats_diff
+    finally:
+        sys.path.pop(0)
+    head = '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+
+    def write(name, steps, gemm_us):
+        f = tmp_path / name
+        f.write_text(head + '"adam_kernel(float*)",%d,%d,10000,1,1,1,0\n' % (steps, steps * 10000)
+                     + '"void igemm_kernel<7, 2, 3, 1, false>(IgemmP)",%d,%d,1,1,1,1,0\n'
+                     % (3 * steps, int(3 * steps * gemm_us * 1000)))
+        return str(f)
+    import io
+    old = write("old.csv", 25, 100.0)
+    assert kstats_diff.steps_of(old, 7) == 25
+    same = write("same.csv", 37, 100.0)                   # more steps in the file, same kernels
+    assert kstats_diff.diff(same, old, out=io.StringIO()) == []
+    slow = write("slow.csv", 37, 104.0)                   # + 12 us per step, + 4 %
+    assert kstats_diff.diff(slow, old, out=io.StringIO()) == ["igemm_kernel<7, 2, 3, 1, false>", "SUM"]
