@@ -37,6 +37,9 @@ SPEC = {
                    "side stream on: a weight gradient's launches are ISSUED behind the main stream's next "
                    "launches (same dependencies): in the captured graph the main chain then stays on one "
                    "hardware queue (DESIGN finding 54)"),
+    "side_mask": ("E2_SIDE_MASK", int, 0,
+                  "side stream OFF (f32 mode): bit r set = the weight gradient of the r-th conv layer (forward "
+                  "order, fused first layer and head not counted) runs on the side stream all the same"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),

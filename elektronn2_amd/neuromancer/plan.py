@@ -317,12 +317,12 @@ class Plan(object):
         return jobs
 
     # ---- second stream ----------------------------------------------------------------
-    def on_side(self, fn, always=False, defer=False):
+    def on_side(self, fn, always=False, defer=False, force=False):
         """run the launches of ``fn`` on the side stream, ordered after everything
         issued on the main stream so far.  ``always``: also when the general side-stream
         switch is off (the weight repack: it overlaps the first layer's HBM-bound kernel).
         ``defer``: see plan option side_defer"""
-        if not (self.use_side or (always and self.use_side_pack)):
+        if not (self.use_side or force or (always and self.use_side_pack)):
             return fn()
         self._flush_side()                 # (the side stream keeps the order of the on_side calls)
         self.ctx.stream_fork(self.side)    # the dependency is fixed HERE: main's launches so far
@@ -336,6 +336,28 @@ class Plan(object):
             self._side_pending = fn
             return
         self._run_side(fn)
+
+    def side_rank(self, node):
+        """position of a Conv node among the conv layers whose weight gradient is a launch of its
+        own (forward order: 0 = the one the backward pass reaches last)"""
+        if self._side_order is None:
+            from .neural import Conv
+            self._side_order = [n for n in self.nodes if isinstance(n, Conv) and hasattr(n, '_k3')
+                                and n.parent is not None and not n._fused_first(self)
+                                and n._fused_head(self) is None]
+        try:
+            return self._side_order.index(node)
+        except ValueError:
+            return 1 << 30
+
+    def side_forced(self, node):
+        """side stream off (f32 mode): does this conv's weight gradient run there all the same?
+        (option side_mask: bit r = the conv of side_rank r)"""
+        m = int(self.opt['side_mask'])
+        if not m or self.use_side:
+            return False
+        r = self.side_rank(node)
+        return r < 62 and bool((m >> r) & 1)
 
     def _run_side(self, fn):
         ctx = self.ctx
@@ -393,6 +415,7 @@ class Plan(object):
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
         self._side_pending = None
+        self._side_order = None
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
         # one stream; the bf16 kernels leave the matrix pipe idle most of the time and the
