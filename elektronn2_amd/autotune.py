@@ -343,6 +343,26 @@ def known(ctx, kind, sig):
     return _load().get(key)
 
 
+def side_flag(ctx, sig):
+    """f32 mode: does the weight gradient of problem ``sig`` (the 'wgrad' signature) run on the
+    plan's side stream?  A measured, per-problem entry of the table like the tilings
+    ("side|<sig>": "1"; tools/tune_side.py writes them, DESIGN finding 56)"""
+    if getattr(ctx, "mfma_dtype", "f32") == "bf16":
+        return False
+    return _load().get("side|" + ",".join(str(int(v)) for v in sig)) == "1"
+
+
+def set_side_flag(sig, on):
+    global _dirty
+    key = "side|" + ",".join(str(int(v)) for v in sig)
+    c = _load()
+    if on:
+        c[key] = "1"
+    else:
+        c.pop(key, None)
+    _dirty = True
+
+
 def _time(ctx, fn, iters=4):
     fn()
     e0, e1 = ctx.event(), ctx.event()

@@ -40,6 +40,10 @@ SPEC = {
     "side_mask": ("E2_SIDE_MASK", int, 0,
                   "side stream OFF (f32 mode): bit r set = the weight gradient of the r-th conv layer (forward "
                   "order, fused first layer and head not counted) runs on the side stream all the same"),
+    "side_table": ("E2_SIDE_TABLE", _b, True,
+                   "side stream OFF (f32 mode): weight gradients whose problem carries a 'side|...' entry in the "
+                   "tuning table run on the side stream (tools/tune_side.py measured them inside the step: "
+                   "neuro3d_lite's three 200-channel layers, -1.3 % of its step; DESIGN finding 56)"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),

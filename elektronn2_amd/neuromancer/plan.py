@@ -352,12 +352,21 @@ class Plan(object):
 
     def side_forced(self, node):
         """side stream off (f32 mode): does this conv's weight gradient run there all the same?
-        (option side_mask: bit r = the conv of side_rank r)"""
-        m = int(self.opt['side_mask'])
-        if not m or self.use_side:
+        Option side_mask (experiments: bit r = the conv of side_rank r), else the tuning table's
+        per-problem flag (autotune.side_flag; option side_table)"""
+        if self.use_side or self.opt['side_stream'] is False:
             return False
-        r = self.side_rank(node)
-        return r < 62 and bool((m >> r) & 1)
+        m = int(self.opt['side_mask'])
+        if m:
+            r = self.side_rank(node)
+            return r < 62 and bool((m >> r) & 1)
+        if not self.opt['side_table']:
+            return False
+        from .. import autotune
+        try:
+            return autotune.side_flag(self.ctx, node._sig_wgrad(self))
+        except Exception:
+            return False
 
     def _run_side(self, fn):
         ctx = self.ctx

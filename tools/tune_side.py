@@ -1,0 +1,93 @@
+"""f32 mode: which weight gradients of a workload should run on the plan's side stream?
+
+The f32 step keeps ONE stream (two GEMMs whose work-groups each take a CU's whole register file
+thrash when they share the chip: DESIGN findings 7, 54) -- but for some layers a weight gradient
+beside the data-gradient chain does pay (neuro3d_lite's 200-channel layers: 220 work-groups of
+~100 us each on 256 CUs).  Like a tiling, that is decided by measurement inside the captured
+step and kept per PROBLEM in the tuning table ("side|<wgrad signature>": "1").
+
+usage: python tools/tune_side.py <workload> [max_run=4] [steps=40]
+       tries every run of consecutive conv layers (length 1 .. max_run) as the set whose weight
+       gradients go to the side stream, re-measures the best one three times against none,
+       interleaved, and writes its flags to $E2HIP_TUNE_CACHE if it wins every time by > 0.4 %."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench as B
+from elektronn2_amd import autotune, nets, neuromancer as nm
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "lite183"
+max_run = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+builder, sp, _ = B.WORKLOADS[wl]
+
+
+def measure(mask):
+    """ms per step of the captured training step with the weight gradients of `mask` on the side stream"""
+    nm.model_manager.reset()
+    np.random.seed(1)
+    with nm.plan_options(side_mask=mask, side_table=False):
+        m = getattr(nets, builder)((None, 1) + sp)
+        m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
+        osp = tuple(m.prediction_node.shape.spatial_shape)
+        rng = np.random.RandomState(0)
+        x = rng.rand(1, 1, *sp).astype(np.float32)
+        t = rng.randint(0, 2, (1, 1) + osp).astype(np.float32)
+        for _ in range(3):
+            m.trainingstep(x, t, optimiser='Adam')
+    plan = m.optimisers['Adam'].step.func
+    ctx = plan.ctx
+    for _ in range(5):
+        plan.run()
+    torch.cuda.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    old = ctx.stream
+    ctx.set_stream(plan.stream); ctx.record(e0); ctx.set_stream(old)
+    for _ in range(steps):
+        plan.run()
+    ctx.set_stream(plan.stream); ctx.record(e1); ctx.set_stream(old)
+    torch.cuda.synchronize()
+    ms = ctx.elapsed_ms(e0, e1) / steps
+    order = plan._side_order if plan._side_order is not None else []
+    if not order:
+        plan.side_rank(None)
+        order = plan._side_order
+    sigs = [n._sig_wgrad(plan) for n in order]
+    names = [n.name for n in order]
+    del m, plan
+    torch.cuda.empty_cache()
+    return ms, sigs, names
+
+
+base, sigs, names = measure(0)
+n = len(sigs)
+print("%s: %d conv layers with a weight-gradient launch (%s); no side stream: %.4f ms" % (wl, n, " ".join(names), base), flush=True)
+best = (base, 0)
+for length in range(1, max_run + 1):
+    for lo in range(0, n - length + 1):
+        mask = ((1 << length) - 1) << lo
+        ms, _, _ = measure(mask)
+        tag = " ".join(names[lo:lo + length])
+        print("  side: %-40s mask %5d  %.4f ms (%+.1f us)" % (tag, mask, ms, (ms - base) * 1e3), flush=True)
+        if ms < best[0]:
+            best = (ms, mask)
+if best[1] == 0:
+    print("nothing beats the single stream")
+    sys.exit(0)
+wins = []
+for _ in range(3):
+    a, _, _ = measure(0)
+    b, _, _ = measure(best[1])
+    wins.append((a, b))
+    print("  confirm: none %.4f ms, mask %d %.4f ms" % (a, best[1], b), flush=True)
+if all(b < a * 0.996 for a, b in wins):
+    for r in range(n):
+        if (best[1] >> r) & 1:
+            autotune.set_side_flag(sigs[r], True)
+            print("  side|%s = 1   (%s)" % (",".join(str(int(v)) for v in sigs[r]), names[r]))
+    autotune.save()
+    print("written to", os.environ.get("E2HIP_TUNE_CACHE", "(the default cache)"))
+else:
+    print("mask %d does not win every round by > 0.4 %%: nothing written" % best[1])
