@@ -342,7 +342,7 @@ class Plan(object):
         own (forward order: 0 = the one the backward pass reaches last)"""
         if self._side_order is None:
             from .neural import Conv
-            self._side_order = [n for n in self.nodes if isinstance(n, Conv) and hasattr(n, '_k3')
+            self._side_order = [n for n in self.nodes if type(n) is Conv and hasattr(n, '_k3')
                                 and n.parent is not None and not n._fused_first(self)
                                 and n._fused_head(self) is None]
         try:
