@@ -7,9 +7,10 @@ beside the data-gradient chain does pay (neuro3d_lite's 200-channel layers: 220 
 step and kept per PROBLEM in the tuning table ("side|<wgrad signature>": "1").
 
 usage: python tools/tune_side.py <workload> [max_run=4] [steps=40]
-       tries every run of consecutive conv layers (length 1 .. max_run) as the set whose weight
-       gradients go to the side stream, re-measures the best one three times against none,
-       interleaved, and writes its flags to $E2HIP_TUNE_CACHE if it wins every time by > 0.4 %."""
+       greedy: tries every run of consecutive conv layers (length 1 .. max_run) as a set whose weight
+       gradients go to the side stream, keeps the best if it gains > 0.2 %, tries to add another run
+       on top (three rounds), re-measures the result three times against none, interleaved, and
+       writes its flags to $E2HIP_TUNE_CACHE if it wins every time by > 0.3 %."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -64,30 +65,39 @@ def measure(mask):
 base, sigs, names = measure(0)
 n = len(sigs)
 print("%s: %d conv layers with a weight-gradient launch (%s); no side stream: %.4f ms" % (wl, n, " ".join(names), base), flush=True)
-best = (base, 0)
-for length in range(1, max_run + 1):
-    for lo in range(0, n - length + 1):
-        mask = ((1 << length) - 1) << lo
-        ms, _, _ = measure(mask)
-        tag = " ".join(names[lo:lo + length])
-        print("  side: %-40s mask %5d  %.4f ms (%+.1f us)" % (tag, mask, ms, (ms - base) * 1e3), flush=True)
-        if ms < best[0]:
-            best = (ms, mask)
-if best[1] == 0:
+# greedy over runs of consecutive layers: add the run that helps most, measure again on top of it
+cur, cur_ms = 0, base
+for it in range(3):
+    best = (cur_ms, cur)
+    for length in range(1, max_run + 1):
+        for lo in range(0, n - length + 1):
+            run = ((1 << length) - 1) << lo
+            if run & cur:
+                continue
+            ms, _, _ = measure(cur | run)
+            print("  %d: + %-36s mask %6d  %.4f ms (%+.1f us)" % (it, " ".join(names[lo:lo + length]), cur | run, ms,
+                                                                (ms - cur_ms) * 1e3), flush=True)
+            if ms < best[0]:
+                best = (ms, cur | run)
+    if best[1] == cur or best[0] > cur_ms * 0.998:
+        break
+    cur_ms, cur = best
+    print("  -> mask %d: %.4f ms" % (cur, cur_ms), flush=True)
+if cur == 0:
     print("nothing beats the single stream")
     sys.exit(0)
 wins = []
 for _ in range(3):
     a, _, _ = measure(0)
-    b, _, _ = measure(best[1])
+    b, _, _ = measure(cur)
     wins.append((a, b))
-    print("  confirm: none %.4f ms, mask %d %.4f ms" % (a, best[1], b), flush=True)
-if all(b < a * 0.996 for a, b in wins):
+    print("  confirm: none %.4f ms, mask %d %.4f ms" % (a, cur, b), flush=True)
+if all(b < a * 0.997 for a, b in wins):
     for r in range(n):
-        if (best[1] >> r) & 1:
+        if (cur >> r) & 1:
             autotune.set_side_flag(sigs[r], True)
             print("  side|%s = 1   (%s)" % (",".join(str(int(v)) for v in sigs[r]), names[r]))
     autotune.save()
     print("written to", os.environ.get("E2HIP_TUNE_CACHE", "(the default cache)"))
 else:
-    print("mask %d does not win every round by > 0.4 %%: nothing written" % best[1])
+    print("mask %d does not win every round by > 0.3 %%: nothing written" % cur)
