@@ -9,7 +9,7 @@ step and kept per PROBLEM in the tuning table ("side|<wgrad signature>": "1").
 usage: python tools/tune_side.py <workload> [max_run=4] [steps=40]
        greedy: tries every run of consecutive conv layers (length 1 .. max_run) as a set whose weight
        gradients go to the side stream, keeps the best if it gains > 0.2 %, tries to add another run
-       on top (three rounds), re-measures the result three times against none, interleaved, and
+       on top (up to six rounds), re-measures the result three times against none, interleaved, and
        writes its flags to $E2HIP_TUNE_CACHE if it wins every time by > 0.3 %."""
 import os
 import sys
@@ -67,7 +67,7 @@ n = len(sigs)
 print("%s: %d conv layers with a weight-gradient launch (%s); no side stream: %.4f ms" % (wl, n, " ".join(names), base), flush=True)
 # greedy over runs of consecutive layers: add the run that helps most, measure again on top of it
 cur, cur_ms = 0, base
-for it in range(3):
+for it in range(int(os.environ.get("E2_TUNE_SIDE_ROUNDS", "6"))):
     best = (cur_ms, cur)
     for length in range(1, max_run + 1):
         for lo in range(0, n - length + 1):
