@@ -65,33 +65,62 @@ def measure(mask):
 base, sigs, names = measure(0)
 n = len(sigs)
 print("%s: %d conv layers with a weight-gradient launch (%s); no side stream: %.4f ms" % (wl, n, " ".join(names), base), flush=True)
-# greedy over runs of consecutive layers: add the run that helps most, measure again on top of it
-cur, cur_ms = 0, base
-for it in range(int(os.environ.get("E2_TUNE_SIDE_ROUNDS", "6"))):
-    best = (cur_ms, cur)
-    for length in range(1, max_run + 1):
-        for lo in range(0, n - length + 1):
-            run = ((1 << length) - 1) << lo
-            if run & cur:
-                continue
-            ms, _, _ = measure(cur | run)
-            print("  %d: + %-36s mask %6d  %.4f ms (%+.1f us)" % (it, " ".join(names[lo:lo + length]), cur | run, ms,
-                                                                (ms - cur_ms) * 1e3), flush=True)
-            if ms < best[0]:
-                best = (ms, cur | run)
-    if best[1] == cur or best[0] > cur_ms * 0.998:
-        break
-    cur_ms, cur = best
-    print("  -> mask %d: %.4f ms" % (cur, cur_ms), flush=True)
+def finals(cands):
+    """re-measure the best few masks against none, interleaved; -> (mask, wins) of the best average"""
+    res = {}
+    for mask in cands:
+        pairs = []
+        for _ in range(3):
+            a, _, _ = measure(0)
+            b, _, _ = measure(mask)
+            pairs.append((a, b))
+        res[mask] = pairs
+        print("  final: mask %6d  %s" % (mask, "  ".join("%.4f / %.4f" % p for p in pairs)), flush=True)
+    best = min(res, key=lambda m: sum(b - a for a, b in res[m]))
+    return best, res[best]
+
+
+if n <= int(os.environ.get("E2_TUNE_SIDE_EXHAUSTIVE", "9")):
+    # few layers: every subset (the gains are not additive -- a chain on the side stream shares one
+    # join, a lone launch pays it alone -- so greedy steps miss sets like neuro3d's {1, 5, 7, 8, 9})
+    table = []
+    for mask in range(1, 1 << n):
+        ms, _, _ = measure(mask)
+        table.append((ms, mask))
+        print("  mask %6d  %.4f ms (%+.1f us)" % (mask, ms, (ms - base) * 1e3), flush=True)
+    table.sort()
+    cur, wins = finals([m for _, m in table[:5]])
+else:
+    # greedy over runs of consecutive layers: add the run that helps most, measure again on top of it
+    cur, cur_ms = 0, base
+    for it in range(int(os.environ.get("E2_TUNE_SIDE_ROUNDS", "6"))):
+        best = (cur_ms, cur)
+        for length in range(1, max_run + 1):
+            for lo in range(0, n - length + 1):
+                run = ((1 << length) - 1) << lo
+                if run & cur:
+                    continue
+                ms, _, _ = measure(cur | run)
+                print("  %d: + %-36s mask %6d  %.4f ms (%+.1f us)" % (it, " ".join(names[lo:lo + length]), cur | run, ms,
+                                                                    (ms - cur_ms) * 1e3), flush=True)
+                if ms < best[0]:
+                    best = (ms, cur | run)
+        if best[1] == cur or best[0] > cur_ms * 0.998:
+            break
+        # (a step is kept only if it shows again)
+        a2, _, _ = measure(cur)
+        b2, _, _ = measure(best[1])
+        if b2 > a2 * 0.9985:
+            print("  -> mask %d did not repeat (%.4f against %.4f)" % (best[1], b2, a2), flush=True)
+            break
+        cur_ms, cur = min(best[0], b2), best[1]
+        print("  -> mask %d: %.4f ms" % (cur, cur_ms), flush=True)
+    wins = []
+    if cur:
+        cur, wins = finals([cur])
 if cur == 0:
     print("nothing beats the single stream")
     sys.exit(0)
-wins = []
-for _ in range(3):
-    a, _, _ = measure(0)
-    b, _, _ = measure(cur)
-    wins.append((a, b))
-    print("  confirm: none %.4f ms, mask %d %.4f ms" % (a, cur, b), flush=True)
 if all(b < a * 0.997 for a, b in wins):
     for r in range(n):
         if (cur >> r) & 1:
