@@ -308,10 +308,15 @@ def test_tiling_candidate_lists():
     # every shipped choice is a well-formed string of one of the known forms
     shipped = json.load(open(os.path.join(os.path.dirname(autotune.__file__), "tuned.json")))
     forms = {"igemm": r"\d+,\d+,\d+,\d+|4(,\d+){7}|1,\d+,[12](,(32|64|128),0)?|32,\d+,\d+",
-             "wgrad": r"\d+,\d+,\d+,\d+,\d+"}
+             "wgrad": r"\d+,\d+,\d+,\d+,\d+",
+             "side": r"1"}         # f32: this weight gradient runs on the side stream (tools/tune_side.py)
     for key, val in shipped.items():
         kind = key.split("|")[0].replace("_bf16", "")
         assert val == "" or re.fullmatch(forms[kind], val), (key, val)
+    # a side flag belongs to a weight-gradient problem that has a shipped tiling too
+    for key in shipped:
+        if key.startswith("side|"):
+            assert "wgrad|" + key.split("|", 1)[1] in shipped, key
 
 
 def test_per_kernel_regression_gate_on_the_committed_profiles():

@@ -539,3 +539,45 @@ def test_several_steps_in_one_graph_launch():
     one = float(b.trainingstep(xs[0], ts[0], optimiser='Adam')[0])
     ref = float(a.trainingstep(xs[0], ts[0], optimiser='Adam')[0])
     assert abs(one - ref) < 1e-5 * abs(ref)
+
+
+def test_weight_gradients_on_the_side_stream_in_f32_mode():
+    """Per-problem side-stream flags (autotune.side_flag / plan option side_mask; DESIGN finding
+    56): in f32 mode the plan keeps one stream, except for the weight gradients the tuning table
+    marks -- their launches form a side branch of the captured graph, issued behind the main
+    stream's next launches (side_defer).  Any choice of layers gives the losses and parameters of
+    the single-stream plan (to the weight gradients' atomic order); eager, capture, replay."""
+    from elektronn2_amd.neuromancer import plan_options
+    spec, sp = O.NEURO3D, (17, 109, 109)
+    params = O.init_net(spec, 1, seed=7)
+    rng = np.random.RandomState(9)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    res = {}
+    for mask in (0, 465, 511, 2):
+        with plan_options(side_mask=mask, side_table=False):
+            m = build('full', sp, params)
+            losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(4)]
+            plan = m.optimisers['Adam'].step.func
+            assert not plan.use_side
+            forced = [n.name for n in plan._side_order or [] if plan.side_forced(n)]
+            assert len(forced) == bin(mask).count("1"), (mask, forced)
+            res[mask] = (losses, [q.get_value() for q in m.loss_node.all_trainable_params.values()])
+    for mask in (465, 511, 2):
+        for a, b in zip(res[mask][0], res[0][0]):
+            assert abs(a - b) < 1e-5 * abs(b), (mask, res[mask][0], res[0][0])
+        for a, b in zip(res[mask][1], res[0][1]):
+            assert rel(a, b) < 1e-4
+    # the shipped table's flags are honoured when no mask is given -- and ignored in bf16 mode
+    from elektronn2_amd import autotune
+    m = build('full', (23, 185, 185), O.init_net(spec, 1, seed=7))
+    plan = m.optimisers['Adam'].step
+    plan.compile()
+    plan = plan.func
+    plan.set_inputs([np.zeros((1, 1, 23, 185, 185), np.float32),
+                     np.zeros((1, 1) + O.net_out_shape(spec, (23, 185, 185)), np.float32)])
+    plan.side_rank(None)
+    flagged = [n.name for n in plan._side_order if plan.side_forced(n)]
+    assert flagged == [n.name for n in plan._side_order if autotune.side_flag(plan.ctx, n._sig_wgrad(plan))]
+    assert len(flagged) >= 3, flagged
+
