@@ -54,7 +54,7 @@ _ORDER = ["test_oracle", "test_host_logic", "test_cabi", "test_malis",        # 
           "test_golden_gpu", "test_ops_gpu", "test_native_size_gpu", "test_model_gpu",
           "test_autotune_gpu", "test_dp_gloo", "test_dp_gpu", "test_bench_launcher",
           "test_mnist_gpu", "test_checkpoint", "test_warp", "test_mfp_gpu",
-          "test_malis_nll_gpu", "test_unet_config5_gpu"]
+          "test_malis_nll_gpu", "test_unet_config5_gpu", "test_plan_options_gpu"]
 _LAST = ["test_bf16_gpu"]
 
 

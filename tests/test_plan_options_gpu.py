@@ -1,0 +1,80 @@
+"""Plan options that are OFF by default (neuromancer/options.py) against the default plan: the
+activation backward fused into the consumer's data gradient (fuse_actbwd, DESIGN finding 17) and
+the optimiser launch that writes the packed weight images (adam_pack, finding 47).  Both measured
+slower and stayed off; their tests run AFTER the hot path and the "next" rows (conftest.py: a
+failure here must not hide anything the default plan is judged by).  Same oracle, helpers and
+tolerances as tests/test_model_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import e2_oracle as O
+from test_model_gpu import CASES, build, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,spec,sp", CASES, ids=['lite', 'full'])
+def test_activation_backward_fused_into_the_consumers_dgrad(name, spec, sp, monkeypatch):
+    """plan.fuse_actbwd (off by default, DESIGN.md finding 17): the relu backward + bias
+    gradient of an un-pooled conv produced by the next conv's data-gradient launch
+    (e2_conv3d_dgrad_packed_actbwd) -- same gradients as the separate kernels, also under
+    graph replay (training steps)."""
+    params = O.init_net(spec, 1, seed=1)
+    rng = np.random.RandomState(3)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    res = {}
+    for fuse in ("0", "1"):
+        from elektronn2_amd.neuromancer import plan_options
+        with plan_options(fuse_actbwd=int(fuse)):
+            m = build(name, sp, params)
+            g = m.gradients(x, t)
+            losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(3)]
+        res[fuse] = (g, losses, [p.get_value() for p in m.loss_node.all_trainable_params.values()])
+        plan = m.optimisers['Adam'].step.func
+        assert bool(plan.fuse_actbwd) == (fuse == "1")
+        fused = [k for k in plan.scratch if isinstance(k, tuple) and len(k) == 2 and k[1] == 'dy_done']
+        assert (len(fused) > 0) == (fuse == "1")
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert rel(a, b) < 1e-5
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert abs(a - b) < 1e-5 * abs(b)
+    for a, b in zip(res["0"][2], res["1"][2]):
+        assert rel(a, b) < 1e-4
+
+
+def test_optimiser_launch_that_writes_the_weight_images_in_the_step():
+    """Plan option adam_pack (e2_adam_pack_step, csrc/update_pack.hip; measured slower and OFF by
+    default, DESIGN finding 46): with it the training plan has no repack launch -- the Adam launch
+    leaves the conv weight images current -- and must notice every OTHER writer of the parameters:
+    six steps with a set_value() in the middle, an SGD step of the same model and a graph replay
+    in between give the losses and parameters of the default plan (to the weight gradients'
+    atomic order)."""
+    from elektronn2_amd.neuromancer import plan_options
+    spec, sp = O.NEURO3D_LITE, (7, 47, 47)
+    params = O.init_net(spec, 1, seed=2)
+    rng = np.random.RandomState(5)
+    x = rng.rand(1, 1, *sp).astype(np.float32)
+    t = rng.randint(0, 2, (1, 1) + O.net_out_shape(spec, sp)).astype(np.float32)
+    res = {}
+    for fused in (False, True):
+        with plan_options(adam_pack=fused):
+            m = build('lite', sp, params)
+            losses = [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(3)]   # eager, capture, replay
+            plan = m.optimisers['Adam'].step.func
+            assert (plan._upd is not None) == fused
+            assert (m._img_owner is plan) == fused
+            w = m.nodes['conv2'].w
+            w.set_value(w.get_value() * 0.5)                  # someone else writes P ...
+            assert m._img_owner is None
+            losses.append(float(m.trainingstep(x, t, optimiser='Adam')[0]))   # ... the plan repacks
+            m.lr = 1e-4
+            m.trainingstep(x, t, optimiser='SGD')             # another optimiser's step
+            assert m._img_owner is None
+            losses += [float(m.trainingstep(x, t, optimiser='Adam')[0]) for _ in range(2)]
+            res[fused] = (losses, [p.get_value() for p in m.loss_node.all_trainable_params.values()])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) < 1e-5 * abs(b), (res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert rel(a, b) < 1e-4
