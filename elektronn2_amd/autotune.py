@@ -352,25 +352,6 @@ def side_flag(ctx, sig):
     return _load().get("side|" + ",".join(str(int(v)) for v in sig)) == "1"
 
 
-def main_flag(ctx, sig):
-    """bf16 mode (every weight gradient on the side stream): is this one kept on the main stream?
-    ("side_bf16|<sig>": "0")"""
-    if getattr(ctx, "mfma_dtype", "f32") != "bf16":
-        return False
-    return _load().get("side_bf16|" + ",".join(str(int(v)) for v in sig)) == "0"
-
-
-def set_main_flag(sig, on):
-    global _dirty
-    key = "side_bf16|" + ",".join(str(int(v)) for v in sig)
-    c = _load()
-    if on:
-        c[key] = "0"
-    else:
-        c.pop(key, None)
-    _dirty = True
-
-
 def set_side_flag(sig, on):
     global _dirty
     key = "side|" + ",".join(str(int(v)) for v in sig)

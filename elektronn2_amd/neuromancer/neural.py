@@ -778,10 +778,7 @@ class Conv(NeuralLayer):
                            lambda: wgrad(True), fn_tune=lambda: wgrad(False))
             finally:
                 ctx.set_input_slack(0)
-        if plan.main_forced(self):
-            wgrad_launch()                # (side stream on, but this layer is marked for the main one)
-        else:
-            plan.on_side(wgrad_launch, defer=True, force=plan.side_forced(self))
+        plan.on_side(wgrad_launch, defer=True, force=plan.side_forced(self))
         if plan.needs_grad(self.parent) and not tail:
             wp = plan.scratch[self, 'wp_d']
             dyp = plan.scratch[self, 'dy_pad']

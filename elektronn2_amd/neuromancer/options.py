@@ -40,9 +40,6 @@ SPEC = {
     "side_mask": ("E2_SIDE_MASK", int, 0,
                   "side stream OFF (f32 mode): bit r set = the weight gradient of the r-th conv layer (forward "
                   "order, fused first layer and head not counted) runs on the side stream all the same"),
-    "main_mask": ("E2_MAIN_MASK", int, 0,
-                  "side stream ON (bf16 mode): bit r set = the weight gradient of the r-th conv layer stays on "
-                  "the main stream (experiments; the table's 'side_bf16|...': '0' entries do the same per problem)"),
     "side_table": ("E2_SIDE_TABLE", _b, True,
                    "side stream OFF (f32 mode): weight gradients whose problem carries a 'side|...' entry in the "
                    "tuning table run on the side stream (tools/tune_side.py measured them inside the step: "

@@ -368,24 +368,6 @@ class Plan(object):
         except Exception:
             return False
 
-    def main_forced(self, node):
-        """side stream ON (bf16 mode): does this conv's weight gradient stay on the main stream all the
-        same?  Option main_mask (bit r = the conv of side_rank r), else the table's flag
-        ("side_bf16|<sig>": "0")"""
-        if not self.use_side:
-            return False
-        m = int(self.opt['main_mask'])
-        if m:
-            r = self.side_rank(node)
-            return r < 62 and bool((m >> r) & 1)
-        if not self.opt['side_table']:
-            return False
-        from .. import autotune
-        try:
-            return autotune.main_flag(self.ctx, node._sig_wgrad(self))
-        except Exception:
-            return False
-
     def _run_side(self, fn):
         ctx = self.ctx
         main = ctx.stream

@@ -19,12 +19,6 @@ import torch
 import bench as B
 from elektronn2_amd import autotune, nets, neuromancer as nm
 
-BF16 = "--mfma" in sys.argv and sys.argv[sys.argv.index("--mfma") + 1] == "bf16"
-if BF16:
-    # bf16 mode: every weight gradient is on the side stream; the masks are the layers kept on MAIN
-    del sys.argv[sys.argv.index("--mfma"):sys.argv.index("--mfma") + 2]
-    import elektronn2_amd
-    elektronn2_amd.set_mfma_dtype("bf16")
 wl = sys.argv[1] if len(sys.argv) > 1 else "lite183"
 max_run = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 40
@@ -35,7 +29,7 @@ def measure(mask):
     """ms per step of the captured training step with the weight gradients of `mask` on the side stream"""
     nm.model_manager.reset()
     np.random.seed(1)
-    with nm.plan_options(**({'main_mask': mask} if BF16 else {'side_mask': mask}), side_table=False):
+    with nm.plan_options(side_mask=mask, side_table=False):
         m = getattr(nets, builder)((None, 1) + sp)
         m.set_opt_meta_params('Adam', dict(lr=5e-4, mom=0.9, beta2=0.999, wd=0.5e-4))
         osp = tuple(m.prediction_node.shape.spatial_shape)
@@ -130,9 +124,8 @@ if cur == 0:
 if all(b < a * 0.997 for a, b in wins):
     for r in range(n):
         if (cur >> r) & 1:
-            (autotune.set_main_flag if BF16 else autotune.set_side_flag)(sigs[r], True)
-            print("  %s|%s = %s   (%s)" % ("side_bf16" if BF16 else "side", ",".join(str(int(v)) for v in sigs[r]),
-                                           "0" if BF16 else "1", names[r]))
+            autotune.set_side_flag(sigs[r], True)
+            print("  side|%s = 1   (%s)" % (",".join(str(int(v)) for v in sigs[r]), names[r]))
     autotune.save()
     print("written to", os.environ.get("E2HIP_TUNE_CACHE", "(the default cache)"))
 else:
