@@ -808,7 +808,6 @@ class Conv(NeuralLayer):
                            autotune.igemm_candidates(cin, self.n_f, self._k3, osp),
                            lambda: launch(plan.pgrad(par.b)), fn_tune=lambda: launch(None),
                            fn_once=lambda: launch(plan.pgrad(par.b)), out=pdyp)
-                plan.side_after_main()
                 return
             dst, first = plan.grad_slot(self.parent)
             out = dst if first else plan.tmp_like(dst)
@@ -846,7 +845,6 @@ class Conv(NeuralLayer):
                 plan.scratch[self.parent, 'grad_nparts'] = got[0]
             if not first:
                 ctx.copy5(out, dst, accumulate=True)
-            plan.side_after_main()        # (a main-stream launch has been issued since the fork)
 
     def _actbwd_into_parent(self, plan):
         """this conv's data gradient can carry the activation backward of its parent: the

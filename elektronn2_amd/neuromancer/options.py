@@ -44,10 +44,6 @@ SPEC = {
                    "side stream OFF (f32 mode): weight gradients whose problem carries a 'side|...' entry in the "
                    "tuning table run on the side stream (tools/tune_side.py measured them inside the step: "
                    "neuro3d_lite's three 200-channel layers, -1.3 % of its step; DESIGN finding 56)"),
-    "side_flush_late": ("E2_SIDE_FLUSH_LATE", _b, False,
-                        "side_defer: the deferred launches go out right behind the layer's data gradient (not at "
-                        "the next fork): two forks with no main launch between them -- the tail's conv and its "
-                        "parent -- then leave the main chain on its queue too"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),

@@ -324,8 +324,7 @@ class Plan(object):
         ``defer``: see plan option side_defer"""
         if not (self.use_side or force or (always and self.use_side_pack)):
             return fn()
-        if not (defer and self.opt['side_defer'] and self.opt['side_flush_late']):
-            self._flush_side()             # (the side stream keeps the order of the on_side calls)
+        self._flush_side()                 # (the side stream keeps the order of the on_side calls)
         self.ctx.stream_fork(self.side)    # the dependency is fixed HERE: main's launches so far
         self._side_dirty = True
         if defer and self.opt['side_defer']:
@@ -334,17 +333,9 @@ class Plan(object):
             # graph the main chain's next kernel becomes the fork node's FIRST child -- the
             # runtime keeps first children on their parent's queue, so the main chain stays on
             # one queue instead of hopping (a hop costs 6-10 us, DESIGN finding 54)
-            # (side_flush_late: two forks with no main launch in between -- the tail's conv and the one
-            # before it -- must not issue the first one's launches yet: they would become the fork
-            # node's first child; the flush comes from side_after_main(), behind the data gradient)
-            self._side_pending.append(fn)
+            self._side_pending = fn
             return
         self._run_side(fn)
-
-    def side_after_main(self):
-        """a launch of the main stream has just been issued: the side launches waiting for that may go"""
-        if self.opt['side_flush_late']:
-            self._flush_side()
 
     def side_rank(self, node):
         """position of a Conv node among the conv layers whose weight gradient is a launch of its
@@ -388,8 +379,8 @@ class Plan(object):
             ctx.set_stream(main)
 
     def _flush_side(self):
-        fns, self._side_pending = self._side_pending, []
-        for fn in fns:
+        fn, self._side_pending = self._side_pending, None
+        if fn is not None:
             self._run_side(fn)
 
     def join_side(self):
@@ -432,7 +423,7 @@ class Plan(object):
         # data-gradient chain; inside the captured graph they are parallel branches
         self.side = torch.cuda.Stream(device=self.ctx.device)
         self._side_dirty = False
-        self._side_pending = []
+        self._side_pending = None
         self._side_order = None
         # measured: two MFMA-bound f32 kernels sharing the chip finish no sooner than
         # back to back (lite183 1.69 / 1.70 ms, neuro3d 2.04 / 2.15 with the branch), so f32 keeps
