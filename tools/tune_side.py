@@ -80,7 +80,18 @@ def finals(cands):
     return best, res[best]
 
 
-if n <= int(os.environ.get("E2_TUNE_SIDE_EXHAUSTIVE", "9")):
+WIN = os.environ.get("E2_TUNE_SIDE_WINDOW")            # "lo,hi": every subset of the layers lo .. hi - 1 only
+if WIN:
+    lo_w, hi_w = (int(v) for v in WIN.split(","))
+    table = []
+    for sub in range(1, 1 << (hi_w - lo_w)):
+        mask = sub << lo_w
+        ms, _, _ = measure(mask)
+        table.append((ms, mask))
+        print("  mask %6d  %.4f ms (%+.1f us)" % (mask, ms, (ms - base) * 1e3), flush=True)
+    table.sort()
+    cur, wins = finals([m for _, m in table[:5]])
+elif n <= int(os.environ.get("E2_TUNE_SIDE_EXHAUSTIVE", "9")):
     # few layers: every subset (the gains are not additive -- a chain on the side stream shares one
     # join, a lone launch pays it alone -- so greedy steps miss sets like neuro3d's {1, 5, 7, 8, 9})
     table = []
