@@ -7,6 +7,9 @@ beside the data-gradient chain does pay (neuro3d_lite's 200-channel layers: 220 
 step and kept per PROBLEM in the tuning table ("side|<wgrad signature>": "1").
 
 usage: python tools/tune_side.py <workload> [max_run=4] [steps=40]
+       E2_TUNE_SIDE_WINDOW=lo,hi  every subset of the layers lo .. hi - 1 (a net too deep for all subsets)
+       E2_TUNE_SIDE_EXHAUSTIVE=n  nets of up to n layers are searched exhaustively (default 9)
+       E2_TUNE_SIDE_ROUNDS=n      greedy rounds for deeper nets (default 6)
        greedy: tries every run of consecutive conv layers (length 1 .. max_run) as a set whose weight
        gradients go to the side stream, keeps the best if it gains > 0.2 %, tries to add another run
        on top (up to six rounds), re-measures the result three times against none, interleaved, and
