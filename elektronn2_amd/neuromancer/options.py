@@ -44,6 +44,9 @@ SPEC = {
                    "side stream OFF (f32 mode): weight gradients whose problem carries a 'side|...' entry in the "
                    "tuning table run on the side stream (tools/tune_side.py measured them inside the step: "
                    "neuro3d_lite's three 200-channel layers, -1.3 % of its step; DESIGN finding 56)"),
+    "debug_poison": ("E2_DEBUG_POISON", _b, False,
+                     "debugging: the plan's uninitialised buffers (Plan.empty / empty_flat) start as NaN, so "
+                     "that a launch reading one before its first writer shows up in the results"),
     "wb_on_side": ("E2_WB_ON_SIDE", _b, True,
                    "bf16 mode: the per-step pack of the bf16 filter rows runs on the side stream beside the "
                    "fused first layer (with the f32 image repack) instead of behind it (finding 54)"),

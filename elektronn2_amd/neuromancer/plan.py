@@ -92,6 +92,8 @@ class Plan(object):
         n = int(np.prod(shape)) if shape else 1
         flat = torch.empty(n + self.SLACK, dtype=torch.float32, device=self.ctx.device)
         flat[n:].zero_()
+        if self.opt['debug_poison']:
+            flat[:n].fill_(float('nan'))       # (a read before the first write shows up as NaN)
         return flat[:n].view(shape)
 
     def zeros(self, shape):
@@ -116,6 +118,8 @@ class Plan(object):
     def empty_flat(self, n):
         flat = torch.empty(int(n) + self.SLACK, dtype=torch.float32, device=self.ctx.device)
         flat[int(n):].zero_()
+        if self.opt['debug_poison']:
+            flat[:int(n)].fill_(float('nan'))
         return flat[:int(n)]
 
     def zeros_flat(self, n):

@@ -36,8 +36,17 @@ def test_activation_backward_fused_into_the_consumers_dgrad(name, spec, sp, monk
         assert bool(plan.fuse_actbwd) == (fuse == "1")
         fused = [k for k in plan.scratch if isinstance(k, tuple) and len(k) == 2 and k[1] == 'dy_done']
         assert (len(fused) > 0) == (fuse == "1")
+    # Gradients: NOT a 1e-5 claim.  With fuse_actbwd the split-K partial sums of a forward conv are
+    # added with atomics (the default plan adds them in a fixed order in its bias / activation pass),
+    # so a pre-activation differs in its last bit from run to run, and where a pooling window holds
+    # two all-but-equal values the max-pool backward routes the gradient differently: ONE voxel of
+    # one layer, 1e-3 of that small layer's dW and 4e-4 of the layers below it (tools/fuse_diag.py:
+    # the same evaluation twice differs by exactly that in half of the runs once the tuner has
+    # picked a split-K tiling for the pooled layer; DESIGN finding 56).  The exactness of the fused
+    # epilogue itself is the op test's (tests/test_ops_gpu.py, 2e-5 against the oracle); here: the
+    # plumbing -- same loss, gradients within one such decision, same losses / parameters after steps.
     for a, b in zip(res["0"][0], res["1"][0]):
-        assert rel(a, b) < 1e-5
+        assert rel(a, b) < 2e-3
     for a, b in zip(res["0"][1], res["1"][1]):
         assert abs(a - b) < 1e-5 * abs(b)
     for a, b in zip(res["0"][2], res["1"][2]):
